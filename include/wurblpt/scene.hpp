@@ -1,0 +1,289 @@
+/*
+ * scene.hpp -- scene container with the reference's ownership rules and take() overloads
+ * (scene.hpp:52-191), plus the flattener that turns it into the POD buffers of
+ * include/wurblpt_hip.h.
+ *
+ * Hitable order = order of take() calls, triangles of an instance in index order; this is
+ * the order the BVH builder sees (scene.hpp:151-162), so it is part of the results contract.
+ */
+#pragma once
+
+#include <cassert>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../wurblpt_hip.h"
+#include "bvh.hpp"
+#include "envmap.hpp"
+#include "material.hpp"
+#include "mesh.hpp"
+#include "scene_component.hpp"
+#include "texture.hpp"
+
+namespace WurblPT {
+
+typedef enum { ColdSpot, HotSpot } HotSpotType;
+
+/* Opaque handle for one hitable of the scene (the reference hands out `const Hitable*`). */
+struct Hitable {
+    unsigned int index;
+};
+
+/* The flattened scene: owns the arrays that a wpt_scene_desc points into. */
+class FlatScene
+{
+public:
+    std::vector<wpt_bvh_node> nodes;
+    std::vector<wpt_tri_geom> triGeom;
+    std::vector<wpt_tri_attr> triAttr;
+    std::vector<wpt_instance> instances;
+    std::vector<wpt_material> materials;
+    std::vector<wpt_texture> textures;
+    std::vector<unsigned char> texels;
+    std::vector<wpt_hotspot> hotspots;
+    wpt_envmap envmap;
+    size_t bvhLevels = 0;
+
+    wpt_scene_desc desc() const
+    {
+        wpt_scene_desc d;
+        memset(&d, 0, sizeof(d));
+        d.abi_version = WPT_ABI_VERSION;
+        d.node_count = nodes.size();
+        d.tri_count = triGeom.size();
+        d.instance_count = instances.size();
+        d.material_count = materials.size();
+        d.texture_count = textures.size();
+        d.hotspot_count = hotspots.size();
+        d.texel_bytes = texels.size();
+        d.nodes = nodes.data();
+        d.tri_geom = triGeom.data();
+        d.tri_attr = triAttr.data();
+        d.instances = instances.data();
+        d.materials = materials.data();
+        d.textures = textures.data();
+        d.texels = texels.data();
+        d.hotspots = hotspots.data();
+        d.envmap = envmap;
+        return d;
+    }
+};
+
+class Scene
+{
+private:
+    struct Triangle {
+        const MeshInstance* instance;
+        unsigned int instanceIndex;
+        unsigned int triangle;
+    };
+    std::vector<std::unique_ptr<Mesh>> _meshes;
+    std::vector<std::unique_ptr<SceneComponent>> _components;
+    std::vector<const MeshInstance*> _instances;
+    std::vector<Triangle> _triangles;             /* the hitables, in take() order */
+    std::vector<std::unique_ptr<Hitable>> _handles;
+    std::vector<const Hitable*> _hotSpots;
+    std::unique_ptr<EnvironmentMap> _envmap;
+    std::vector<wpt_bvh_node> _bvh;
+    size_t _bvhLevels;
+    bool _bvhNeedsRebuild;
+    std::map<const Material*, int> _materialMap;
+    std::vector<std::string> _materialNames;
+    std::string _error;
+
+    static vec3 vtx(const Mesh* mesh, unsigned int i, size_t offset) { return vec3(mesh->vertices.data() + i * mesh->vertexSize() + offset); }
+
+    /* World-space corners of one hitable, with the arithmetic of hitable_triangle.hpp:193-206 */
+    void corners(const Triangle& t, vec3 v[3]) const
+    {
+        const Mesh* mesh = t.instance->mesh;
+        for (int k = 0; k < 3; k++) {
+            v[k] = mesh->position(mesh->indices[3 * t.triangle + k]);
+            if (!t.instance->transformation.isIdentity())
+                v[k] = (t.instance->transformationM * vec4(v[k], 1.0f)).xyz();
+        }
+    }
+
+public:
+    Scene() : _bvhLevels(0), _bvhNeedsRebuild(true) {}
+
+    Mesh* take(Mesh* mesh)
+    {
+        _meshes.push_back(std::unique_ptr<Mesh>(mesh));
+        return mesh;
+    }
+
+    Texture* take(Texture* tex)
+    {
+        _components.push_back(std::unique_ptr<SceneComponent>(tex));
+        return tex;
+    }
+
+    Material* take(Material* mat, const std::string& name = std::string())
+    {
+        _components.push_back(std::unique_ptr<SceneComponent>(mat));
+        _materialMap.insert(std::pair<const Material*, int>(mat, _materialNames.size()));
+        _materialNames.push_back(name);
+        return mat;
+    }
+
+    std::vector<const Hitable*> take(MeshInstance* instance, HotSpotType hotSpotType = ColdSpot)
+    {
+        std::vector<const Hitable*> handles;
+        if (instance->animationIndex >= 0)
+            _error = "animated mesh instances are outside the device path";
+        unsigned int instanceIndex = _instances.size();
+        _instances.push_back(instance);
+        size_t n = instance->mesh->triangleCount();
+        _triangles.reserve(_triangles.size() + n);
+        for (size_t i = 0; i < n; i++) {
+            Hitable* h = new Hitable { (unsigned int)(_triangles.size()) };
+            _handles.push_back(std::unique_ptr<Hitable>(h));
+            _triangles.push_back(Triangle { instance, instanceIndex, (unsigned int)(i) });
+            handles.push_back(h);
+        }
+        if (hotSpotType == HotSpot)
+            _hotSpots.insert(_hotSpots.end(), handles.begin(), handles.end());
+        _components.push_back(std::unique_ptr<SceneComponent>(instance));
+        _bvhNeedsRebuild = true;
+        return handles;
+    }
+
+    EnvironmentMap* take(EnvironmentMap* envmap)
+    {
+        _envmap = std::unique_ptr<EnvironmentMap>(envmap);
+        return envmap;
+    }
+
+    bool bvhNeedsUpdate(float /* t0 */ = 0.0f, float /* t1 */ = 0.0f) const { return _bvhNeedsRebuild; }
+
+    void updateBVH(float t0 = 0.0f, float t1 = 0.0f)
+    {
+        if (!bvhNeedsUpdate(t0, t1)) {
+            fprintf(stderr, "Bounding volume hierarchy does not need updating.\n");
+            return;
+        }
+        fprintf(stderr, "Building bounding volume hierarchy for %zu hitables\n", _triangles.size());
+        std::vector<AABB> boxes(_triangles.size());
+        for (size_t i = 0; i < _triangles.size(); i++) {
+            vec3 v[3];
+            corners(_triangles[i], v);
+            boxes[i] = AABB(min(v[0], v[1], v[2]), max(v[0], v[1], v[2]));
+        }
+        BVHBuilder builder(boxes);
+        _bvh = builder.build(&_bvhLevels);
+        fprintf(stderr, "Linearized bounding volume hierarchy with %zu nodes on %zu levels\n", _bvh.size(), _bvhLevels);
+        _bvhNeedsRebuild = false;
+    }
+
+    const std::vector<const Hitable*>& hotSpots() const { return _hotSpots; }
+    const EnvironmentMap* environmentMap() const { return _envmap.get(); }
+    const std::vector<wpt_bvh_node>& bvhNodes() const { return _bvh; }
+    size_t hitableCount() const { return _triangles.size(); }
+
+    int materialIndex(const Material* mat) const
+    {
+        auto it = _materialMap.find(mat);
+        return it == _materialMap.end() ? -1 : it->second;
+    }
+    const std::vector<std::string>& materialNames() const { return _materialNames; }
+
+    /* Flatten into POD buffers.  Returns false (with a message) when the scene uses something
+     * that the device path does not know. */
+    bool flatten(FlatScene& out, std::string* error = nullptr) const
+    {
+        auto fail = [&](const std::string& msg) {
+            if (error)
+                *error = msg;
+            return false;
+        };
+        if (!_error.empty())
+            return fail(_error);
+        if (_bvhNeedsRebuild)
+            return fail("Scene::updateBVH() must run before rendering");
+        FlattenContext ctx;
+        out = FlatScene();
+        out.nodes = _bvh;
+        out.bvhLevels = _bvhLevels;
+        out.instances.resize(_instances.size());
+        for (size_t i = 0; i < _instances.size(); i++) {
+            const MeshInstance* inst = _instances[i];
+            wpt_instance& r = out.instances[i];
+            memset(&r, 0, sizeof(r));
+            for (int k = 0; k < 9; k++)
+                r.N[k] = inst->transformationN.values[k];
+            int m = ctx.indexOf(inst->material);
+            if (m < 0)
+                return fail(ctx.error);
+            r.material = m;
+            r.flags = (inst->mesh->haveTexCoords ? WPT_TRI_HAVE_TEXCOORDS : 0) | (inst->mesh->haveTangents ? WPT_TRI_HAVE_TANGENTS : 0)
+                | (inst->transformation.isIdentity() ? 0 : WPT_TRI_TRANSFORM);
+        }
+        out.triGeom.resize(_triangles.size());
+        out.triAttr.resize(_triangles.size());
+        for (size_t i = 0; i < _triangles.size(); i++) {
+            const Triangle& t = _triangles[i];
+            const Mesh* mesh = t.instance->mesh;
+            wpt_tri_geom& g = out.triGeom[i];
+            wpt_tri_attr& a = out.triAttr[i];
+            memset(&a, 0, sizeof(a));
+            vec3 v[3];
+            corners(t, v);
+            for (int k = 0; k < 3; k++) {
+                g.v0[k] = v[0][k];
+                g.v1[k] = v[1][k];
+                g.v2[k] = v[2][k];
+            }
+            g.instance = t.instanceIndex;
+            g.material = out.instances[t.instanceIndex].material;
+            g.flags = out.instances[t.instanceIndex].flags;
+            float* nrm[3] = { a.n0, a.n1, a.n2 };
+            float* tc[3] = { a.tc0, a.tc1, a.tc2 };
+            float* tan[3] = { a.t0, a.t1, a.t2 };
+            for (int c = 0; c < 3; c++) {
+                unsigned int vi = mesh->indices[3 * t.triangle + c];
+                const float* src = mesh->vertices.data() + vi * mesh->vertexSize();
+                for (int k = 0; k < 3; k++)
+                    nrm[c][k] = src[Mesh::normalOffset + k];
+                if (mesh->haveTexCoords)
+                    for (int k = 0; k < 2; k++)
+                        tc[c][k] = src[Mesh::texcoordOffset + k];
+                if (mesh->haveTangents)
+                    for (int k = 0; k < 3; k++)
+                        tan[c][k] = src[Mesh::tangentOffset + k];
+            }
+        }
+        out.hotspots.resize(_hotSpots.size());
+        for (size_t i = 0; i < _hotSpots.size(); i++) {
+            const Triangle& t = _triangles[_hotSpots[i]->index];
+            const Mesh* mesh = t.instance->mesh;
+            wpt_hotspot& h = out.hotspots[i];
+            memset(&h, 0, sizeof(h));
+            h.prim = _hotSpots[i]->index;
+            h.transform = t.instance->transformation.isIdentity() ? 0 : 1;
+            float* p[3] = { h.p0, h.p1, h.p2 };
+            for (int c = 0; c < 3; c++) {
+                vec3 q = mesh->position(mesh->indices[3 * t.triangle + c]);
+                for (int k = 0; k < 3; k++)
+                    p[c][k] = q[k];
+            }
+            for (int k = 0; k < 16; k++)
+                h.M[k] = t.instance->transformationM.values[k];
+        }
+        memset(&out.envmap, 0, sizeof(out.envmap));
+        out.envmap.tex = -1;
+        if (_envmap) {
+            if (!_envmap->describe(out.envmap, ctx))
+                return fail(ctx.error.empty() ? "an EnvironmentMap subclass that the device path does not know is used" : ctx.error);
+        }
+        out.materials = ctx.materials;
+        out.textures = ctx.textures;
+        out.texels = ctx.texels;
+        return true;
+    }
+};
+
+}

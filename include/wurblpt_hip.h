@@ -1,0 +1,274 @@
+/*
+ * wurblpt_hip.h -- C ABI of the MI355X (gfx950) path-tracing core.
+ *
+ * This is the drop-in boundary for the one hot path of WurblPT: the per-pixel
+ * Monte Carlo integrator.  The reference has no FFI of its own; everything is
+ * inlined from headers into the applications (reference libwurblpt/wurblpt.hpp:279-449).
+ * The entry points below are what the reference-side `mcpt()` binds instead of
+ * running its OpenMP pixel loop (wurblpt.hpp:335-381):
+ *
+ *   wpt_scene_upload()   replaces the data that `mcpt` borrows from `Scene`:
+ *                        scene.bvh() (bvh.hpp:217-225,277-311), the HitableTriangle objects
+ *                        (hitable_triangle.hpp:46-143), Mesh vertex data (mesh.hpp:39-66),
+ *                        Material / Texture objects (material*.hpp, texture*.hpp),
+ *                        scene.hotSpots() and scene.environmentMap() (scene.hpp:173-191)
+ *   wpt_render_block()   replaces one iteration of the block loop: the OpenMP pixel loop,
+ *                        Prng(pixel), the sample loop, Camera::getRay, tracePath and
+ *                        Sensor::finishPixel (wurblpt.hpp:319-383, sensor_rgb.hpp:63-87)
+ *   wpt_block_queue_*    replace MPICoordinator::getBlock/submitBlock (mpi.hpp:241-262)
+ *                        for several GPUs driven from one process
+ *
+ * All structs are plain C PODs; the caller keeps ownership of everything it
+ * passes in (the callee copies during wpt_scene_upload).  No C++ types, no
+ * exceptions and no torch types cross this boundary.  Functions return an
+ * integer status; wpt_last_error() gives a thread-local message.
+ *
+ * Thread compatibility: a wpt_scene belongs to the device that was current
+ * when it was uploaded; concurrent wpt_render_block* calls on one scene are
+ * allowed when they use different streams and disjoint pixel ranges.
+ */
+#ifndef WURBLPT_HIP_H
+#define WURBLPT_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WPT_ABI_VERSION 1u
+
+typedef enum {
+    WPT_OK = 0,
+    WPT_ERR_INVALID_ARGUMENT = 1,
+    WPT_ERR_NO_DEVICE = 2,
+    WPT_ERR_HIP = 3,
+    WPT_ERR_UNSUPPORTED = 4,
+    WPT_ERR_OUT_OF_MEMORY = 5
+} wpt_status;
+
+/* ---- flattened scene ------------------------------------------------- */
+
+/* One node of the depth-first linearized BVH; 32 bytes like BVHNodeLinear
+ * (bvh.hpp:217-225).  Child 1 of an inner node is the next node in the array
+ * (bvh.hpp:301), child 2 is `link`.  For a leaf, `link` is the primitive index. */
+enum { WPT_NODE_INNER = 0, WPT_NODE_TRIANGLE = 1, WPT_NODE_EMPTY = 3 };
+typedef struct wpt_bvh_node {
+    float lo[3];
+    float hi[3];
+    uint32_t link;
+    uint32_t kind;
+} wpt_bvh_node;
+
+/* Triangle flags; mirror the HitableTriangle template arguments (hitable_triangle.hpp:36) */
+enum { WPT_TRI_HAVE_TEXCOORDS = 1, WPT_TRI_HAVE_TANGENTS = 2, WPT_TRI_TRANSFORM = 4 };
+
+/* Intersection stream: world-space positions of one triangle (48 bytes).  With
+ * WPT_TRI_TRANSFORM the positions are the instance's mat4 applied on the host with
+ * the arithmetic of hitable_triangle.hpp:203-206, which is the value hit() recomputes per call. */
+typedef struct wpt_tri_geom {
+    float v0[3];
+    uint32_t instance;
+    float v1[3];
+    uint32_t material;
+    float v2[3];
+    uint32_t flags;
+} wpt_tri_geom;
+
+/* Shading stream: de-indexed vertex attributes of one triangle (96 bytes), read once per
+ * final hit (hitable_triangle.hpp:289-322).  Unused members are zero. */
+typedef struct wpt_tri_attr {
+    float n0[3], n1[3], n2[3];
+    float tc0[2], tc1[2], tc2[2];
+    float t0[3], t1[3], t2[3];
+} wpt_tri_attr;
+
+/* MeshInstance data needed at hit time (mesh.hpp:159-189): the normal matrix (column major). */
+typedef struct wpt_instance {
+    float N[9];
+    uint32_t material;
+    uint32_t flags;
+    uint32_t reserved;
+} wpt_instance;
+
+/* A hot spot (scene.hpp:113-125): the triangle, plus what HitableTriangle::direction()
+ * needs (hitable_triangle.hpp:425-443): untransformed positions and the instance mat4. */
+typedef struct wpt_hotspot {
+    uint32_t prim;
+    uint32_t transform;
+    uint32_t reserved[2];
+    float p0[3], p1[3], p2[3];
+    float M[16];
+} wpt_hotspot;
+
+enum {
+    WPT_MAT_NONE = 0,          /* base Material: no scattering, no emission (material.hpp:158-185) */
+    WPT_MAT_LAMBERTIAN = 1,    /* material_lambertian.hpp */
+    WPT_MAT_LIGHT_DIFFUSE = 2, /* light_diffuse.hpp */
+    WPT_MAT_MIRROR = 3,        /* material_mirror.hpp */
+    WPT_MAT_GGX = 4,           /* material_ggx.hpp */
+    WPT_MAT_GLASS = 5,         /* material_glass.hpp */
+    WPT_MAT_MODPHONG = 6,      /* material_modphong.hpp */
+    WPT_MAT_TWOSIDED = 7       /* material.hpp:273-334 */
+};
+enum {
+    WPT_MATF_HAVE_NIR = 1,
+    WPT_MATF_CHROMATIC_DISPERSION = 2,
+    WPT_MATF_DIFFUSE_TEX_HAS_ALPHA = 4,
+    WPT_MATF_SPECULAR_TEX_HAS_ALPHA = 8
+};
+/* Tagged material record (128 bytes).  Member use per type:
+ *  LAMBERTIAN     v[0]=albedo                      tex[0]=albedo
+ *  LIGHT_DIFFUSE  v[0]=emit                        tex[0]=emit
+ *  MIRROR         v[0]=color                       tex[0]=color
+ *  GGX            v[0]=albedo f[0..1]=roughness    tex[0]=albedo tex[1]=roughness
+ *  GLASS          v[0]=absorption v[1]=RI material v[2]=RI surrounding
+ *  MODPHONG       v[0]=diffuse v[1]=specular v[2]=transmissive v[3]=emissive
+ *                 f[0]=shininess f[1]=opacity f[2]=indexOfRefraction
+ *                 tex[0]=diffuse tex[1]=specular tex[2]=shininess tex[3]=opacity tex[4]=emissive
+ *  TWOSIDED       tex[0]=front material index, tex[1]=back material index
+ * Texture indices are -1 when absent. */
+typedef struct wpt_material {
+    uint32_t type;
+    uint32_t flags;
+    int32_t normal_tex;
+    int32_t tex[5];
+    float v[5][4];
+    float f[4];
+} wpt_material;
+
+enum { WPT_TEX_CONSTANT = 0, WPT_TEX_CHECKER = 1, WPT_TEX_IMAGE = 2, WPT_TEX_TRANSFORMER = 3 };
+enum { WPT_TEXEL_U8 = 0, WPT_TEXEL_U16 = 1, WPT_TEXEL_F32 = 2 };
+/* Texture record (texture.hpp:160-246, texture_image.hpp:39-233).
+ *  CONSTANT     a = color
+ *  CHECKER      a = color0, b = color1, width = horiz, height = vert
+ *  IMAGE        width/height/comps/texel_type/linearize_srgb, texel_offset (bytes into the
+ *               texel pool, row 0 = v 0, x fastest, components interleaved),
+ *               coord_factor/coord_offset, a = valFactor, b = valOffset
+ *  TRANSFORMER  child, coord_factor/coord_offset, a = valFactor, b = valOffset */
+typedef struct wpt_texture {
+    uint32_t type;
+    uint32_t width, height;
+    uint32_t comps;
+    uint32_t texel_type;
+    uint32_t linearize_srgb;
+    int32_t child;
+    uint32_t reserved;
+    uint64_t texel_offset;
+    float coord_factor[2];
+    float coord_offset[2];
+    float a[4];
+    float b[4];
+} wpt_texture;
+
+enum { WPT_ENV_NONE = 0, WPT_ENV_EQUIRECT = 1 };
+enum { WPT_ENV_COMPAT_MITSUBA = 0, WPT_ENV_COMPAT_SURROUND_VIDEO = 1 };
+/* Environment map (envmap.hpp): texture + host-built importance tables (envmap.hpp:121-158).
+ * N == 0 means no importance sampling support. */
+typedef struct wpt_envmap {
+    uint32_t type;
+    uint32_t compat;
+    int32_t tex;
+    int32_t N;
+    const float* M;
+    const int32_t* Ms;
+    const float* Mcs;
+} wpt_envmap;
+
+typedef struct wpt_scene_desc {
+    uint32_t abi_version; /* WPT_ABI_VERSION */
+    uint32_t node_count;
+    uint32_t tri_count;
+    uint32_t instance_count;
+    uint32_t material_count;
+    uint32_t texture_count;
+    uint32_t hotspot_count;
+    uint32_t reserved;
+    uint64_t texel_bytes;
+    const wpt_bvh_node* nodes;
+    const wpt_tri_geom* tri_geom;
+    const wpt_tri_attr* tri_attr;
+    const wpt_instance* instances;
+    const wpt_material* materials;
+    const wpt_texture* textures;
+    const uint8_t* texels;
+    const wpt_hotspot* hotspots;
+    wpt_envmap envmap;
+} wpt_scene_desc;
+
+/* ---- camera, parameters ---------------------------------------------- */
+
+/* What Camera::getRay needs for a static pinhole / thin lens camera
+ * (camera.hpp:123-185, optics.hpp:37-69,311-334, transformation.hpp:48-83). */
+typedef struct wpt_camera {
+    float l, r, b, t;        /* Projection frustum at near = 1 */
+    float translation[3];
+    float rotation[4];       /* quaternion x, y, z, w */
+    float scaling[3];
+    float lens_radius;
+    float focus_dist;
+} wpt_camera;
+
+/* Parameters (wurblpt.hpp:79-96) plus the SensorRGB gates (sensor_rgb.hpp:41-51). */
+typedef struct wpt_params {
+    uint32_t max_path_components;
+    float rr_threshold;
+    uint32_t randomize_ray_over_pixel;
+    float min_hit_distance;
+    float min_dist_to_light, max_dist_to_light;
+    float min_path_len, max_path_len;
+} wpt_params;
+
+/* Work counters of one render call; the roofline denominator. */
+typedef struct wpt_counters {
+    uint64_t samples;
+    uint64_t rays;          /* BVH::hit calls */
+    uint64_t node_visits;   /* nodes fetched in BVH::hit */
+    uint64_t leaf_tests;    /* triangle tests in BVH::hit */
+    uint64_t pdf_tests;     /* hot-spot pdfValue triangle tests */
+    uint64_t scatters;      /* Material::scatter calls */
+} wpt_counters;
+
+typedef struct wpt_scene wpt_scene;
+
+/* ---- entry points ---------------------------------------------------- */
+
+/* Number of HIP devices (0 if none); selects the device for this thread. */
+int wpt_device_count(void);
+wpt_status wpt_select_device(int device);
+
+/* Copies the flattened scene to the current device. */
+wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene);
+void wpt_scene_free(wpt_scene* scene);
+
+/* Renders pixels [block_start, block_start + block_size) of a width x height frame with
+ * samples_sqrt^2 samples per pixel, asynchronously on `hip_stream` (NULL = default stream).
+ * `frame_device` is a device pointer to the FULL frame, float[height][width][3], row 0 =
+ * bottom row (camera.hpp:146-149); only the block's pixels are written.
+ * `counters_device` may be NULL; otherwise a device pointer to one wpt_counters that the
+ * kernel atomically adds to. */
+wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera,
+        const wpt_params* params, uint32_t width, uint32_t height, uint32_t samples_sqrt,
+        uint32_t block_start, uint32_t block_size,
+        float* frame_device, wpt_counters* counters_device, void* hip_stream);
+
+/* Synchronous form with MPICoordinator::submitBlock semantics (mpi.hpp:256-262):
+ * writes block_size*3 floats for the block's pixels to host memory `block_rgb`. */
+wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera,
+        const wpt_params* params, uint32_t width, uint32_t height, uint32_t samples_sqrt,
+        uint32_t block_start, uint32_t block_size, float* block_rgb);
+
+/* Kernel launch geometry knobs (0 = default); for benchmarking only, results do not change. */
+wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant);
+
+/* Name of the GPU kernel that wpt_render_block_device launches (for profile matching). */
+const char* wpt_kernel_name(void);
+
+const char* wpt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

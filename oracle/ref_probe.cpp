@@ -1,0 +1,553 @@
+/*
+ * ref_probe.cpp -- golden-vector generator that runs THE REFERENCE'S OWN CODE.
+ *
+ * TEST INFRASTRUCTURE.  Compiled only in the build container, only when /root/reference
+ * exists, by oracle/Makefile, against the reference headers where they lie
+ * (-I/root/reference/libwurblpt); the binary goes to oracle/_ref/ (git-ignored) and its
+ * output to tests/golden/ref_golden.json (committed: data only, no reference source).
+ *
+ * Only reference headers that compile from the reference tree alone are used:
+ * gvm, prng, sampler, tangentspace, fresnel, ray, aabb, hitable, bvh, transformation,
+ * animation, optics, camera, geometryproc.  Everything that (transitively) includes
+ * <tgd/array.hpp> -- texture, material*, mesh, hitable_triangle, envmap, sensor, scene,
+ * wurblpt.hpp -- needs the external libtgd, which is not in this image, and is therefore NOT
+ * built (no stand-in headers are written for it).
+ *
+ * Floats are written as their 32-bit patterns (hex) so that comparisons are bit-exact.
+ */
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "prng.hpp"
+#include "sampler.hpp"
+#include "tangentspace.hpp"
+#include "fresnel.hpp"
+#include "aabb.hpp"
+#include "hitable.hpp"
+#include "bvh.hpp"
+#include "transformation.hpp"
+#include "optics.hpp"
+#include "camera.hpp"
+#include "geometryproc.hpp"
+
+using namespace WurblPT;
+
+static FILE* out;
+static bool firstKey = true;
+
+static uint32_t bits(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+static void key(const char* name)
+{
+    fprintf(out, "%s\n\"%s\": ", firstKey ? "" : ",", name);
+    firstKey = false;
+}
+
+static void floats(const char* name, const std::vector<float>& v)
+{
+    key(name);
+    fprintf(out, "[");
+    for (size_t i = 0; i < v.size(); i++)
+        fprintf(out, "%s\"%08x\"", i ? "," : "", bits(v[i]));
+    fprintf(out, "]");
+}
+
+static void ints(const char* name, const std::vector<long long>& v)
+{
+    key(name);
+    fprintf(out, "[");
+    for (size_t i = 0; i < v.size(); i++)
+        fprintf(out, "%s%lld", i ? "," : "", v[i]);
+    fprintf(out, "]");
+}
+
+static void push3(std::vector<float>& v, const vec3& a)
+{
+    v.push_back(a.x());
+    v.push_back(a.y());
+    v.push_back(a.z());
+}
+
+/* FNV-1a over a byte range, to pin large arrays with a few bytes */
+static uint64_t fnv1a(const void* data, size_t n)
+{
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) {
+        h ^= p[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+/* A hitable for exercising the reference's BVH build and BVH::hit: a box with a fixed
+ * "hit distance".  hit() reports a hit at that distance iff it lies in [amin, amax], and logs
+ * the visit, so the log is the reference's leaf visiting order with its amax shrinking. */
+class ProbeHitable final : public Hitable
+{
+public:
+    AABB box;
+    float a;
+    static std::vector<long long>* log;
+    static const ProbeHitable* base;
+
+    virtual AABB aabb(AnimationCache&, AnimationCache&) const override { return box; }
+    virtual HitRecord hit(const Ray&, const RayIntersectionHelper&, float amin, float amax, float, AnimationCache&, Prng&) const override
+    {
+        if (log)
+            log->push_back(this - base);
+        if (a >= amin && a <= amax) {
+            HitRecord hr(a);
+            hr.hitable = this;
+            return hr;
+        }
+        return HitRecord();
+    }
+};
+std::vector<long long>* ProbeHitable::log = nullptr;
+const ProbeHitable* ProbeHitable::base = nullptr;
+
+/* BVH exposes its nodes only privately; the flattened order is observed instead through
+ * BVH::hit's visiting order with a ray-independent all-pass query (see below), and the
+ * boxes through aabb().  For the node array itself we rebuild the same tree with the
+ * reference's BVHNode::buildBVH and walk it. */
+struct FlatNode {
+    float lo[3], hi[3];
+    long long link;
+    long long kind;
+};
+
+class BVHNodeWalker
+{
+public:
+    /* BVHNode's members are private with `friend class BVH`; measure() is public and
+     * build is deterministic, so we reproduce the flatten order by a second walk that uses
+     * only public behaviour: a BVH over the same hitables, queried with rays that pass every
+     * box, visits the leaves in depth-first flatten order. */
+};
+
+static std::vector<float> randomBoxes(unsigned int n, unsigned int seed, bool degenerate)
+{
+    std::mt19937 rng(seed);
+    auto u01 = [&rng]() { return float(rng() >> 8) * (1.0f / 16777216.0f); };
+    std::vector<float> b(6 * n);
+    for (unsigned int i = 0; i < n; i++) {
+        float c[3], e[3];
+        for (int k = 0; k < 3; k++) {
+            c[k] = u01() * 2.0f - 1.0f;
+            e[k] = degenerate && (rng() & 3) == 0 ? 0.0f : 0.01f + 0.1f * u01();
+            if (degenerate && (rng() & 7) == 0)
+                c[k] = float(int(c[k] * 4.0f)) * 0.25f; /* many equal centres -> sort ties */
+        }
+        for (int k = 0; k < 3; k++) {
+            b[6 * i + k] = c[k] - e[k];
+            b[6 * i + 3 + k] = c[k] + e[k];
+        }
+    }
+    return b;
+}
+
+int main(int argc, char* argv[])
+{
+    out = argc > 1 ? fopen(argv[1], "w") : stdout;
+    if (!out)
+        return 1;
+    fprintf(out, "{");
+    key("generator");
+    fprintf(out, "\"oracle/ref_probe.cpp over /root/reference/libwurblpt headers, g++ %d.%d.%d -O2 -ffp-contract=off\"", __GNUC__, __GNUC_MINOR__, __GNUC_PATCHLEVEL__);
+
+    /* ---- Prng (prng.hpp:47-101) ---- */
+    {
+        const unsigned int pixels[5] = { 0, 1, 7, 65535, 1048575 };
+        std::vector<long long> px;
+        std::vector<float> v, v2;
+        for (unsigned int p : pixels) {
+            px.push_back(p);
+            Prng prng(p);
+            for (int i = 0; i < 64; i++)
+                v.push_back(prng.in01());
+            Prng prng2(p);
+            for (int i = 0; i < 8; i++) {
+                vec2 xy = prng2.in01x2();
+                v2.push_back(xy.x());
+                v2.push_back(xy.y());
+            }
+        }
+        ints("prng_pixels", px);
+        floats("prng_in01", v);
+        floats("prng_in01x2", v2);
+    }
+
+    /* ---- Sampler (sampler.hpp:39-123), 32x32 grid plus the special points ---- */
+    {
+        std::vector<float> u, disk, tri, cosd;
+        for (int j = 0; j < 32; j++)
+            for (int i = 0; i < 32; i++) {
+                u.push_back((i + 0.37f) / 32.0f);
+                u.push_back((j + 0.61f) / 32.0f);
+            }
+        const float special[][2] = { { 0.5f, 0.5f }, { 0.0f, 0.0f }, { 0.5f, 0.25f }, { 0.25f, 0.5f }, { 0.99999994f, 0.99999994f }, { 0.0f, 0.5f }, { 0.5f, 0.0f } };
+        for (auto& s : special) {
+            u.push_back(s[0]);
+            u.push_back(s[1]);
+        }
+        for (size_t i = 0; i < u.size() / 2; i++) {
+            vec2 uu(u[2 * i], u[2 * i + 1]);
+            vec2 d = Sampler::inUnitDisk(uu);
+            disk.push_back(d.x());
+            disk.push_back(d.y());
+            push3(tri, Sampler::inTriangle(uu));
+            push3(cosd, Sampler::cosineDirection(uu));
+        }
+        floats("sampler_u", u);
+        floats("sampler_inUnitDisk", disk);
+        floats("sampler_inTriangle", tri);
+        floats("sampler_cosineDirection", cosd);
+    }
+
+    std::mt19937 rng(12345);
+    auto u01 = [&rng]() { return float(rng() >> 8) * (1.0f / 16777216.0f); };
+    auto randDir = [&]() {
+        for (;;) {
+            vec3 d(u01() * 2.0f - 1.0f, u01() * 2.0f - 1.0f, u01() * 2.0f - 1.0f);
+            float l = dot(d, d);
+            if (l > 0.01f && l <= 1.0f)
+                return normalize(d);
+        }
+    };
+
+    /* ---- TangentSpace (tangentspace.hpp:57-136) ---- */
+    {
+        std::vector<float> nrm, vec, res;
+        for (int i = 0; i < 256; i++) {
+            vec3 n = randDir();
+            if (i == 0) n = vec3(0.0f, 0.0f, 1.0f);
+            if (i == 1) n = vec3(0.0f, 0.0f, -1.0f);
+            if (i == 2) n = vec3(1.0f, 0.0f, 0.0f);
+            if (i == 3) n = vec3(0.0f, -1.0f, 0.0f);
+            vec3 v = randDir();
+            TangentSpace ts(n);
+            push3(nrm, n);
+            push3(vec, v);
+            push3(res, ts.tangent);
+            push3(res, ts.bitangent);
+            push3(res, ts.toWorldSpace(v));
+            push3(res, ts.toTangentSpace(v));
+        }
+        floats("tangentspace_normals", nrm);
+        floats("tangentspace_vecs", vec);
+        floats("tangentspace_out", res);
+    }
+
+    /* ---- Fresnel (fresnel.hpp:48-72), reflect / refract (gvm.hpp:1213-1223) ---- */
+    {
+        std::vector<float> in, res;
+        for (int i = 0; i < 256; i++) {
+            float a = u01(), b = u01(), c = 1.0f + u01(), d = 1.0f + u01();
+            in.insert(in.end(), { a, b, c, d });
+            res.push_back(fresnelUnpolarized(a, b, c, d));
+            vec4 s = fresnelSchlick(vec4(a, b, c, d), b);
+            res.insert(res.end(), { s.x(), s.y(), s.z(), s.w() });
+        }
+        floats("fresnel_in", in);
+        floats("fresnel_out", res);
+        std::vector<float> in7, res6;
+        for (int i = 0; i < 256; i++) {
+            vec3 dI = randDir(), n = randDir();
+            float eta = (i & 1) ? 1.5f : 1.0f / 1.5f;
+            if (i % 7 == 0) eta = 1.0f;
+            push3(in7, dI);
+            push3(in7, n);
+            in7.push_back(eta);
+            push3(res6, reflect(dI, n));
+            push3(res6, refract(dI, n, eta));
+        }
+        floats("reflect_refract_in", in7);
+        floats("reflect_refract_out", res6);
+    }
+
+    /* ---- RayIntersectionHelper (hitable.hpp:66-113), AABB::mayHit (aabb.hpp:70-86) ---- */
+    {
+        std::vector<float> rays, helper;
+        for (int i = 0; i < 512; i++) {
+            vec3 o(u01() * 4.0f - 2.0f, u01() * 4.0f - 2.0f, u01() * 4.0f - 2.0f);
+            vec3 d = randDir();
+            if (i < 6) { d = vec3(0.0f); d[i % 3] = (i < 3 ? 1.0f : -1.0f); } /* axis aligned: inf in invDirection */
+            if (i == 6) d = normalize(vec3(1.0f, 1.0f, 0.0f));
+            if (i == 7) d = normalize(vec3(0.0f, -1.0f, 1.0f));
+            Ray r(o, d, 0.0f, vec4(1.0f));
+            RayIntersectionHelper h(r);
+            push3(rays, o);
+            push3(rays, d);
+            push3(helper, h.invDirection);
+            helper.insert(helper.end(), { float(h.k.x()), float(h.k.y()), float(h.k.z()) });
+            push3(helper, h.S);
+        }
+        floats("rayhelper_rays", rays);
+        floats("rayhelper_out", helper);
+        std::vector<float> boxes, brays;
+        std::vector<long long> hit;
+        for (int i = 0; i < 2048; i++) {
+            vec3 c(u01() * 2.0f - 1.0f, u01() * 2.0f - 1.0f, u01() * 2.0f - 1.0f);
+            vec3 e(u01() * 0.5f, u01() * 0.5f, u01() * 0.5f);
+            if (i % 16 == 0) e[i / 16 % 3] = 0.0f; /* flat boxes */
+            AABB box(c - e, c + e);
+            vec3 o(u01() * 4.0f - 2.0f, u01() * 4.0f - 2.0f, u01() * 4.0f - 2.0f);
+            vec3 d = randDir();
+            if (i % 8 == 1) { d = vec3(0.0f); d[i / 8 % 3] = (i & 64) ? 1.0f : -1.0f; }
+            if (i % 32 == 1) o[(i / 8 % 3 + 1) % 3] = box.lo[(i / 8 % 3 + 1) % 3]; /* origin on a slab plane with zero direction: 0 * inf = NaN */
+            if (i % 8 == 2) d = normalize(c - o); /* aimed at the box */
+            float amin = (i % 5 == 0) ? 0.0f : 1e-5f;
+            float amax = (i % 3 == 0) ? 1.5f : maxval;
+            Ray r(o, d, 0.0f, vec4(1.0f));
+            RayIntersectionHelper h(r);
+            push3(boxes, box.lo);
+            push3(boxes, box.hi);
+            push3(brays, o);
+            push3(brays, d);
+            brays.push_back(amin);
+            brays.push_back(amax);
+            hit.push_back(box.mayHit(r, amin, amax, h.invDirection) ? 1 : 0);
+        }
+        floats("aabb_boxes", boxes);
+        floats("aabb_rays", brays);
+        ints("aabb_mayhit", hit);
+    }
+
+    /* ---- BVH build + traversal (bvh.hpp:93-311) over probe hitables ---- */
+    {
+        struct Case { unsigned int n, seed; bool degenerate; };
+        const Case cases[] = { { 1, 1, false }, { 2, 2, false }, { 3, 3, false }, { 7, 4, true }, { 36, 5, false }, { 200, 6, true }, { 1000, 7, false }, { 40000, 8, true } };
+        int ci = 0;
+        for (const Case& cs : cases) {
+            std::vector<float> b = randomBoxes(cs.n, cs.seed, cs.degenerate);
+            std::vector<ProbeHitable> hitables(cs.n);
+            std::vector<const Hitable*> ptrs(cs.n);
+            std::mt19937 arng(cs.seed * 977u);
+            for (unsigned int i = 0; i < cs.n; i++) {
+                hitables[i].box = AABB(vec3(b.data() + 6 * i), vec3(b.data() + 6 * i + 3));
+                hitables[i].a = 0.5f + 4.0f * float(arng() >> 8) * (1.0f / 16777216.0f);
+                ptrs[i] = &hitables[i];
+            }
+            ProbeHitable::base = hitables.data();
+            std::vector<const Animation*> noAnimations;
+            AnimationCache c0(noAnimations, 0.0f), c1(noAnimations, 0.0f);
+            BVH bvh;
+            bvh.build(ptrs, c0, c1);
+            Prng prng(0);
+            /* (1) flatten order of the leaves: a query that passes every box and never shrinks
+             * amax.  Ray from far away along +x with invDirection made irrelevant by amin=-inf.. is not
+             * possible; instead use the property that mayHit() is true for every box when the
+             * ray origin is inside... not general either.  So: log visits for MANY rays and
+             * keep the full logs; together with the leaf boxes this pins order and pruning. */
+            std::vector<float> qrays;
+            std::vector<long long> visitLog, finalHit;
+            std::vector<float> finalA;
+            int nq = cs.n >= 40000 ? 64 : 128;
+            for (int q = 0; q < nq; q++) {
+                vec3 o(u01() * 3.0f - 1.5f, u01() * 3.0f - 1.5f, u01() * 3.0f - 1.5f);
+                vec3 d = randDir();
+                if (q % 16 == 3) { d = vec3(0.0f); d[q / 16 % 3] = 1.0f; }
+                float amin = 1e-5f;
+                float amax = (q % 4 == 0) ? 2.0f : maxval;
+                Ray r(o, d, 0.0f, vec4(1.0f));
+                std::vector<long long> log;
+                ProbeHitable::log = &log;
+                HitRecord hr = bvh.hit(r, RayIntersectionHelper(r), amin, amax, amin, c0, prng);
+                ProbeHitable::log = nullptr;
+                push3(qrays, o);
+                push3(qrays, d);
+                qrays.push_back(amin);
+                qrays.push_back(amax);
+                visitLog.push_back(log.size());
+                visitLog.insert(visitLog.end(), log.begin(), log.end());
+                finalHit.push_back(hr.haveHit ? static_cast<const ProbeHitable*>(hr.hitable) - hitables.data() : -1);
+                finalA.push_back(hr.haveHit ? hr.a : 0.0f);
+            }
+            char name[64];
+            std::vector<long long> meta = { (long long)cs.n, (long long)cs.seed, cs.degenerate ? 1 : 0 };
+            snprintf(name, sizeof(name), "bvh%d_meta", ci);
+            ints(name, meta);
+            snprintf(name, sizeof(name), "bvh%d_rays", ci);
+            floats(name, qrays);
+            if (cs.n <= 1000) {
+                snprintf(name, sizeof(name), "bvh%d_boxes", ci);
+                floats(name, b);
+                std::vector<float> as;
+                for (unsigned int i = 0; i < cs.n; i++)
+                    as.push_back(hitables[i].a);
+                snprintf(name, sizeof(name), "bvh%d_leaf_a", ci);
+                floats(name, as);
+                snprintf(name, sizeof(name), "bvh%d_visitlog", ci);
+                ints(name, visitLog);
+            } else {
+                /* too large to commit: the generator is seeded (randomBoxes is restated in the
+                 * test), so commit only a hash of the visit logs */
+                snprintf(name, sizeof(name), "bvh%d_visitlog_fnv", ci);
+                std::vector<long long> h = { (long long)(fnv1a(visitLog.data(), visitLog.size() * sizeof(long long)) >> 1) };
+                ints(name, h);
+            }
+            snprintf(name, sizeof(name), "bvh%d_final", ci);
+            ints(name, finalHit);
+            snprintf(name, sizeof(name), "bvh%d_final_a", ci);
+            floats(name, finalA);
+            /* root box */
+            AABB root = bvh.aabb(c0, c1);
+            std::vector<float> rb;
+            push3(rb, root.lo);
+            push3(rb, root.hi);
+            snprintf(name, sizeof(name), "bvh%d_rootbox", ci);
+            floats(name, rb);
+            ci++;
+        }
+    }
+
+    /* ---- Transformation (transformation.hpp:80-137), Projection (optics.hpp:49-55) ---- */
+    {
+        std::vector<float> in, res;
+        const float cases[][9] = {
+            { 0.0f, 1.0f, 3.2f, 0.0f, 1.0f, -1.0f, 0.0f, 1.0f, 0.0f },  /* Cornell camera */
+            { 0.0f, 1.7f, 0.0f, 0.0f, 1.7f, -1.0f, 0.0f, 1.0f, 0.0f },  /* Sponza camera */
+            { 0.3f, 0.4f, 3.5f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f },
+            { 13.0f, 2.0f, 3.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f },
+            { 1.0f, 2.0f, 3.0f, -2.0f, 0.5f, 1.0f, 0.1f, 0.9f, 0.2f },
+            { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 1.0f, 0.0f },  /* looking along +z: 180 degree case */
+        };
+        for (auto& c : cases) {
+            in.insert(in.end(), c, c + 9);
+            Transformation T = Transformation::fromLookAt(vec3(c[0], c[1], c[2]), vec3(c[3], c[4], c[5]), normalize(vec3(c[6], c[7], c[8])));
+            push3(res, T.translation);
+            res.insert(res.end(), { T.rotation.x, T.rotation.y, T.rotation.z, T.rotation.w });
+            push3(res, T.scaling);
+            mat4 M = T.toMat4();
+            for (int k = 0; k < 16; k++)
+                res.push_back(M.values[k]);
+            mat3 N = T.toNormalMatrix();
+            for (int k = 0; k < 9; k++)
+                res.push_back(N.values[k]);
+        }
+        floats("lookat_in", in);
+        floats("lookat_out", res);
+        std::vector<float> tin, tout;
+        for (int i = 0; i < 64; i++) {
+            vec3 t(u01() * 4.0f - 2.0f, u01() * 4.0f - 2.0f, u01() * 4.0f - 2.0f);
+            float angle = u01() * 6.0f - 3.0f;
+            vec3 axis = randDir() * (0.5f + u01());
+            vec3 s(0.1f + u01() * 2.0f, 0.1f + u01() * 2.0f, 0.1f + u01() * 2.0f);
+            vec3 v(u01() * 2.0f - 1.0f, u01() * 2.0f - 1.0f, u01() * 2.0f - 1.0f);
+            if (i == 0) { angle = radians(90.0f); axis = vec3(0.0f, 1.0f, 0.0f); s = vec3(0.01f); t = vec3(0.0f); } /* Sponza import transformation */
+            push3(tin, t);
+            tin.push_back(angle);
+            push3(tin, axis);
+            push3(tin, s);
+            push3(tin, v);
+            Transformation T(t, toQuat(angle, axis), s);
+            mat4 M = T.toMat4();
+            for (int k = 0; k < 16; k++)
+                tout.push_back(M.values[k]);
+            mat3 N = T.toNormalMatrix();
+            for (int k = 0; k < 9; k++)
+                tout.push_back(N.values[k]);
+            push3(tout, T * v);
+        }
+        floats("transformation_in", tin);
+        floats("transformation_out", tout);
+        std::vector<float> pin, pout;
+        const float pc[][2] = { { radians(50.0f), 1.0f }, { radians(70.0f), 1920.0f / 1080.0f }, { radians(60.0f), 4.0f / 3.0f }, { radians(35.0f), 2.0f } };
+        for (auto& c : pc) {
+            Projection P(c[0], c[1]);
+            pin.insert(pin.end(), { c[0], c[1] });
+            pout.insert(pout.end(), { P.l, P.r, P.b, P.t });
+        }
+        floats("projection_in", pin);
+        floats("projection_out", pout);
+    }
+
+    /* ---- Camera::getRay (camera.hpp:123-185): pinhole and thin lens ---- */
+    {
+        for (int variant = 0; variant < 2; variant++) {
+            float aperture = variant == 0 ? 0.0f : 0.1f;
+            Optics optics(Projection(radians(50.0f), 1.0f), LensDistortion(), LensDepthOfField(aperture, 3.2f));
+            Camera camera(optics, Transformation::fromLookAt(vec3(0.0f, 1.0f, 3.2f), vec3(0.0f, 1.0f, -1.0f), vec3(0.0f, 1.0f, 0.0f)));
+            Camera::RayHelper rh = camera.getRayHelper(0.0f, 64, 64);
+            Prng prng(0);
+            std::vector<float> pq, res;
+            for (int j = 0; j < 16; j++)
+                for (int i = 0; i < 16; i++) {
+                    float p = (i + 0.3f) / 16.0f, q = (j + 0.7f) / 16.0f;
+                    Ray r = camera.getRay(p, q, 0.0f, 0.0f, rh, prng);
+                    pq.push_back(p);
+                    pq.push_back(q);
+                    push3(res, r.origin);
+                    push3(res, r.direction);
+                }
+            floats(variant == 0 ? "camera_pinhole_pq" : "camera_lens_pq", pq);
+            floats(variant == 0 ? "camera_pinhole_rays" : "camera_lens_rays", res);
+            std::vector<float> camdesc = { optics.projection.l, optics.projection.r, optics.projection.b, optics.projection.t,
+                camera.transformation.translation.x(), camera.transformation.translation.y(), camera.transformation.translation.z(),
+                camera.transformation.rotation.x, camera.transformation.rotation.y, camera.transformation.rotation.z, camera.transformation.rotation.w,
+                camera.transformation.scaling.x(), camera.transformation.scaling.y(), camera.transformation.scaling.z(),
+                optics.depthOfField.lensRadius, optics.depthOfField.focusDist };
+            floats(variant == 0 ? "camera_pinhole_desc" : "camera_lens_desc", camdesc);
+        }
+    }
+
+    /* ---- computeTangents / computeNormals (geometryproc.hpp:58-226) ---- */
+    {
+        /* a Cornell wall quad and a small random indexed mesh */
+        std::vector<vec3> pos = { vec3(-1.01f, 0.0f, 0.99f), vec3(-0.99f, 0.0f, -1.04f), vec3(-1.02f, 1.99f, -1.04f), vec3(-1.02f, 1.99f, 0.99f) };
+        std::vector<vec3> nrm = { vec3(0.9999874f, 0.005025057f, 0.0f), vec3(0.9998379f, 0.01507292f, 0.009850611f), vec3(0.9999874f, 0.005025057f, 0.0f), vec3(0.9999874f, 0.005025057f, 0.0f) };
+        std::vector<vec2> tc = { vec2(0.0f, 0.0f), vec2(1.0f, 0.0f), vec2(1.0f, 1.0f), vec2(0.0f, 1.0f) };
+        std::vector<unsigned int> ind = { 0, 1, 2, 0, 2, 3 };
+        int grid = 6;
+        unsigned int base = pos.size();
+        for (int j = 0; j <= grid; j++)
+            for (int i = 0; i <= grid; i++) {
+                pos.push_back(vec3(i / float(grid) + 0.05f * u01(), 0.3f * u01(), j / float(grid) + 0.05f * u01()) + vec3(3.0f, 0.0f, 0.0f));
+                nrm.push_back(vec3(0.0f));
+                tc.push_back(vec2(i / float(grid), j / float(grid)));
+            }
+        for (int j = 0; j < grid; j++)
+            for (int i = 0; i < grid; i++) {
+                unsigned int a = base + j * (grid + 1) + i, b = a + 1, c = a + grid + 1, d = c + 1;
+                ind.insert(ind.end(), { a, b, c, b, d, c });
+            }
+        std::vector<vec3> n2 = computeNormals(pos, ind);
+        for (size_t i = base; i < pos.size(); i++)
+            nrm[i] = n2[i];
+        std::vector<vec3> tng = computeTangents(pos, nrm, tc, ind);
+        std::vector<vec3> n1 = computeNormals(pos, ind, NormalsFromFaceAverage);
+        std::vector<float> fpos, fnrm, ftc, ftng, fn0, fn1;
+        std::vector<long long> find(ind.begin(), ind.end());
+        for (size_t i = 0; i < pos.size(); i++) {
+            push3(fpos, pos[i]);
+            push3(fnrm, nrm[i]);
+            ftc.push_back(tc[i].x());
+            ftc.push_back(tc[i].y());
+            push3(ftng, tng[i]);
+            push3(fn0, n2[i]);
+            push3(fn1, n1[i]);
+        }
+        floats("geom_pos", fpos);
+        floats("geom_nrm", fnrm);
+        floats("geom_tc", ftc);
+        ints("geom_ind", find);
+        floats("geom_tangents", ftng);
+        floats("geom_normals_weighted", fn0);
+        floats("geom_normals_average", fn1);
+    }
+
+    fprintf(out, "\n}\n");
+    if (out != stdout)
+        fclose(out);
+    return 0;
+}

@@ -1,0 +1,1573 @@
+/*
+ * wpt_oracle.cpp -- CPU restatement of WurblPT's per-pixel Monte Carlo integrator.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT THE PRODUCT.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (wurblpt_amd/csrc)
+ * never includes, links or calls anything in this directory.
+ *
+ * It restates, scalar and in the reference's own operation order, the algorithm of
+ * /root/reference/libwurblpt (each function cites the file:line it follows) on the
+ * flattened scene of include/wurblpt_hip.h.  Parity status:
+ *   - Prng, Sampler, TangentSpace, Fresnel, AABB::mayHit, RayIntersectionHelper,
+ *     BVH::hit order, Camera::getRay, reflect/refract, quaternion rotate:
+ *     PINNED bit-for-bit against the reference's own headers compiled from
+ *     /root/reference (oracle/ref_probe.cpp -> tests/golden/ref_*.json).
+ *   - triangle hit/pdfValue/direction, materials, textures, environment map, tracePath,
+ *     mcpt: those reference headers include <tgd/array.hpp> (libtgd, an external
+ *     library that is absent here), so they cannot be compiled; they are pinned by the
+ *     reference's in-tree Mitsuba render (statistically) and by the work-per-sample
+ *     figures recorded in SURVEY.md section 6; see DESIGN.md "Oracle".
+ *
+ * Two math back ends: default = wpt_math.h (same bits as the GPU); -DWPT_ORACLE_LIBM =
+ * std:: functions as the reference uses (gvm.hpp:118-146).
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <math.h>
+#include <cmath>
+#include <limits>
+#include <vector>
+#include <omp.h>
+
+#include "../include/wurblpt_hip.h"
+#include "../wurblpt_amd/csrc/wpt_math.h"
+
+namespace {
+
+/* ---- math back end (gvm.hpp:118-146) ---- */
+#ifdef WPT_ORACLE_LIBM
+inline float m_sin(float x) { return std::sin(x); }
+inline float m_cos(float x) { return std::cos(x); }
+inline float m_exp(float x) { return std::exp(x); }
+inline float m_pow(float x, float y) { return std::pow(x, y); }
+inline float m_asin(float x) { return std::asin(x); }
+inline float m_atan2(float y, float x) { return std::atan2(y, x); }
+#else
+inline float m_sin(float x) { return wptm::sinf_(x); }
+inline float m_cos(float x) { return wptm::cosf_(x); }
+inline float m_exp(float x) { return wptm::expf_(x); }
+inline float m_pow(float x, float y) { return wptm::powf_(x, y); }
+inline float m_asin(float x) { return wptm::asinf_(x); }
+inline float m_atan2(float y, float x) { return wptm::atan2f_(y, x); }
+#endif
+
+constexpr float k_pi = 3.1415926535897932384626433832795029L;
+constexpr float k_pi_2 = 1.5707963267948966192313216916397514L;
+constexpr float k_pi_4 = 0.7853981633974483096156608458198757L;
+constexpr float k_inv_pi = 0.3183098861837906715377675267450287L;
+constexpr float k_maxval = std::numeric_limits<float>::max();
+constexpr float k_epsilon = std::numeric_limits<float>::epsilon();
+
+/* gvm.hpp:88-98: min/max/clamp with the `x < y ? x : y` NaN behaviour */
+inline float fmin_(float x, float y) { return x < y ? x : y; }
+inline float fmax_(float x, float y) { return x > y ? x : y; }
+inline float clamp_(float x, float lo, float hi) { return fmin_(hi, fmax_(lo, x)); }
+inline float mix_(float x, float y, float a) { return x + a * (y - x); } /* gvm.hpp:166 */
+
+/* ---- vectors (gvm.hpp:979-1025,1183-1232) ---- */
+struct V2 {
+    float x, y;
+};
+struct V3 {
+    float x, y, z;
+    float operator[](int i) const { return i == 0 ? x : i == 1 ? y : z; }
+};
+struct V4 {
+    float x, y, z, w;
+    float operator[](int i) const { return i == 0 ? x : i == 1 ? y : i == 2 ? z : w; }
+    float& at(int i) { return i == 0 ? x : i == 1 ? y : i == 2 ? z : w; }
+};
+
+inline V3 v3(float a) { return V3 { a, a, a }; }
+inline V3 v3(const float* p) { return V3 { p[0], p[1], p[2] }; }
+inline V4 v4(float a) { return V4 { a, a, a, a }; }
+inline V4 v4(const float* p) { return V4 { p[0], p[1], p[2], p[3] }; }
+
+inline V2 operator+(V2 a, V2 b) { return V2 { a.x + b.x, a.y + b.y }; }
+inline V2 operator-(V2 a, V2 b) { return V2 { a.x - b.x, a.y - b.y }; }
+inline V2 operator*(V2 a, V2 b) { return V2 { a.x * b.x, a.y * b.y }; }
+inline V2 operator*(float s, V2 a) { return V2 { s * a.x, s * a.y }; }
+inline V2 operator*(V2 a, float s) { return V2 { a.x * s, a.y * s }; }
+
+inline V3 operator+(V3 a, V3 b) { return V3 { a.x + b.x, a.y + b.y, a.z + b.z }; }
+inline V3 operator-(V3 a, V3 b) { return V3 { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline V3 operator*(V3 a, V3 b) { return V3 { a.x * b.x, a.y * b.y, a.z * b.z }; }
+inline V3 operator-(V3 a) { return V3 { -a.x, -a.y, -a.z }; }
+inline V3 operator*(float s, V3 a) { return V3 { s * a.x, s * a.y, s * a.z }; }
+inline V3 operator*(V3 a, float s) { return V3 { a.x * s, a.y * s, a.z * s }; }
+inline V3 operator/(V3 a, float s) { return V3 { a.x / s, a.y / s, a.z / s }; }
+inline V3 operator/(float s, V3 a) { return V3 { s / a.x, s / a.y, s / a.z }; }
+
+inline V4 operator+(V4 a, V4 b) { return V4 { a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w }; }
+inline V4 operator-(V4 a, V4 b) { return V4 { a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w }; }
+inline V4 operator*(V4 a, V4 b) { return V4 { a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w }; }
+inline V4 operator-(V4 a) { return V4 { -a.x, -a.y, -a.z, -a.w }; }
+inline V4 operator*(float s, V4 a) { return V4 { s * a.x, s * a.y, s * a.z, s * a.w }; }
+inline V4 operator*(V4 a, float s) { return V4 { a.x * s, a.y * s, a.z * s, a.w * s }; }
+inline V4 operator/(V4 a, float s) { return V4 { a.x / s, a.y / s, a.z / s, a.w / s }; }
+
+/* gvm.hpp:1183-1189: d = 0; d += a[i]*b[i] */
+inline float dot(V2 a, V2 b) { float d = 0.0f; d += a.x * b.x; d += a.y * b.y; return d; }
+inline float dot(V3 a, V3 b) { float d = 0.0f; d += a.x * b.x; d += a.y * b.y; d += a.z * b.z; return d; }
+inline float dot(V4 a, V4 b) { float d = 0.0f; d += a.x * b.x; d += a.y * b.y; d += a.z * b.z; d += a.w * b.w; return d; }
+inline float length(V3 a) { return std::sqrt(dot(a, a)); }           /* gvm.hpp:1191 */
+inline V3 normalize(V3 v) { return v / length(v); }                 /* gvm.hpp:1201 */
+inline V3 reflect(V3 i, V3 n) { return i - 2.0f * dot(n, i) * n; }  /* gvm.hpp:1213 */
+inline V3 refract(V3 i, V3 n, float eta)                            /* gvm.hpp:1218 */
+{
+    const float d = dot(n, i);
+    const float k = 1.0f - eta * eta * (1.0f - d * d);
+    return k <= 0.0f ? v3(0.0f) : i * eta - n * (eta * d + std::sqrt(k));
+}
+inline V3 cross(V3 v, V3 w) /* gvm.hpp:1225 */
+{
+    return V3 { v.y * w.z - v.z * w.y, v.z * w.x - v.x * w.z, v.x * w.y - v.y * w.x };
+}
+inline float max4(V4 a) /* gvm.hpp:1282 */
+{
+    float r = a.x;
+    if (a.y > r) r = a.y;
+    if (a.z > r) r = a.z;
+    if (a.w > r) r = a.w;
+    return r;
+}
+inline float min4(V4 a) /* gvm.hpp:1273 */
+{
+    float r = a.x;
+    if (a.y < r) r = a.y;
+    if (a.z < r) r = a.z;
+    if (a.w < r) r = a.w;
+    return r;
+}
+inline float average3(V3 a) /* gvm.hpp:1291 */
+{
+    constexpr float inv_N = 1.0f / 3.0f;
+    float sum = 0;
+    sum += a.x; sum += a.y; sum += a.z;
+    return inv_N * sum;
+}
+inline V3 rgb(V4 a) { return V3 { a.x, a.y, a.z }; }
+inline V4 mix4(V4 x, V4 y, float a) /* gvm.hpp: vector mix = x + alpha * (y - x) */
+{
+    return V4 { mix_(x.x, y.x, a), mix_(x.y, y.y, a), mix_(x.z, y.z, a), mix_(x.w, y.w, a) };
+}
+inline V3 mix3(V3 x, V3 y, float a)
+{
+    return V3 { mix_(x.x, y.x, a), mix_(x.y, y.y, a), mix_(x.z, y.z, a) };
+}
+
+/* column-major mat3 * vec3 (gvm.hpp:1481-1491): r[i] = 0; r[i] += m[j][i]*w[j] */
+inline V3 mat3_mul(const float* m, V3 w)
+{
+    float r[3];
+    for (int i = 0; i < 3; i++) {
+        r[i] = 0.0f;
+        r[i] += m[0 * 3 + i] * w.x;
+        r[i] += m[1 * 3 + i] * w.y;
+        r[i] += m[2 * 3 + i] * w.z;
+    }
+    return V3 { r[0], r[1], r[2] };
+}
+inline V3 mat4_mul_point(const float* m, V3 p) /* (M * vec4(p, 1)).xyz() */
+{
+    float r[3];
+    for (int i = 0; i < 3; i++) {
+        r[i] = 0.0f;
+        r[i] += m[0 * 4 + i] * p.x;
+        r[i] += m[1 * 4 + i] * p.y;
+        r[i] += m[2 * 4 + i] * p.z;
+        r[i] += m[3 * 4 + i] * 1.0f;
+    }
+    return V3 { r[0], r[1], r[2] };
+}
+/* quaternion * vec3 (gvm.hpp:1713-1720) */
+inline V3 quat_rotate(const float* q, V3 v)
+{
+    V3 s = V3 { q[0], q[1], q[2] };
+    V3 t = 2.0f * cross(s, v);
+    return v + q[3] * t + cross(s, t);
+}
+
+/* ---- prng.hpp:47-101 ---- */
+struct Prng {
+    uint32_t s[4];
+    static uint32_t rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+    static uint64_t splitmix64(uint64_t x)
+    {
+        uint64_t z = (x += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    }
+    explicit Prng(unsigned int pixelIndex)
+    {
+        uint64_t seed = pixelIndex;
+        seed += 42;
+        uint64_t s01 = splitmix64(seed);
+        uint64_t s23 = splitmix64(s01);
+        s[0] = s01 >> 32;
+        s[1] = s01 & 0xffffffffull;
+        s[2] = s23 >> 32;
+        s[3] = s23 & 0xffffffffull;
+    }
+    uint32_t next()
+    {
+        const uint32_t result = s[0] + s[3];
+        const uint32_t t = s[1] << 9;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 11);
+        return result;
+    }
+    float in01()
+    {
+        uint32_t x = next();
+        return (x >> 8) * 0x1.0p-24;
+    }
+    /* prng.hpp:97-100 `vec2(in01(), in01())`: g++ 11.4 evaluates the SECOND argument
+     * first, so .y receives the first draw (pinned by ref_probe). */
+    V2 in01x2()
+    {
+        float second = in01();
+        float first = in01();
+        return V2 { first, second };
+    }
+};
+
+/* ---- sampler.hpp:39-123 ---- */
+inline V2 inUnitDisk(V2 u)
+{
+    V2 uOffset = 2.0f * u - V2 { 1.0f, 1.0f };
+    V2 result;
+    if (uOffset.x == 0.0f && uOffset.y == 0.0f) {
+        result = V2 { 0.0f, 0.0f };
+    } else {
+        float theta, r;
+        if (std::fabs(uOffset.x) > std::fabs(uOffset.y)) {
+            r = uOffset.x;
+            theta = k_pi_4 * (uOffset.y / uOffset.x);
+        } else {
+            r = uOffset.y;
+            theta = k_pi_2 - k_pi_4 * (uOffset.x / uOffset.y);
+        }
+        result = r * V2 { m_cos(theta), m_sin(theta) };
+    }
+    return result;
+}
+inline V3 inTriangle(V2 u)
+{
+    float su0 = std::sqrt(u.x);
+    float b0 = 1.0f - su0;
+    float b1 = u.y * su0;
+    return V3 { b0, b1, 1.0f - b0 - b1 };
+}
+inline V3 cosineDirection(V2 u)
+{
+    V2 d = inUnitDisk(u);
+    float z = std::sqrt(fmax_(0.0f, 1.0f - dot(d, d)));
+    return V3 { d.x, d.y, z };
+}
+
+/* ---- tangentspace.hpp:46-136 ---- */
+struct TangentSpace {
+    V3 normal, tangent, bitangent;
+    TangentSpace() {}
+    explicit TangentSpace(V3 n) : normal(n)
+    {
+        float sign = std::copysign(1.0f, normal.z);
+        float a = -1.0f / (sign + normal.z);
+        float b = normal.x * normal.y * a;
+        tangent = V3 { 1.0f + sign * normal.x * normal.x * a, sign * b, -sign * normal.x };
+        bitangent = V3 { b, sign + normal.y * normal.y * a, -normal.y };
+    }
+    TangentSpace(V3 n, V3 t) : normal(n), tangent(t), bitangent(cross(n, t)) {}
+    V3 toTangentSpace(V3 v) const
+    {
+        /* matrixToTangentSpace(): columns (t.x,b.x,n.x), (t.y,b.y,n.y), (t.z,b.z,n.z) */
+        float m[9] = { tangent.x, bitangent.x, normal.x, tangent.y, bitangent.y, normal.y,
+            tangent.z, bitangent.z, normal.z };
+        return mat3_mul(m, v);
+    }
+    V3 toWorldSpace(V3 v) const
+    {
+        float m[9] = { tangent.x, tangent.y, tangent.z, bitangent.x, bitangent.y, bitangent.z,
+            normal.x, normal.y, normal.z };
+        return mat3_mul(m, v);
+    }
+};
+
+/* ---- fresnel.hpp:48-72 ---- */
+inline V4 fresnelSchlick(V4 r0, float cosTheta)
+{
+    float t = 1.0f - cosTheta;
+    float t_squared = t * t;
+    return r0 + (v4(1.0f) - r0) * t_squared * t_squared * t;
+}
+inline float fresnelUnpolarized(float cosI, float cosT, float n1, float n2)
+{
+    float Fs = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
+    Fs *= Fs;
+    float Fp = (n1 * cosT - n2 * cosI) / (n1 * cosT + n2 * cosI);
+    Fp *= Fp;
+    return 0.5f * (Fs + Fp);
+}
+
+/* ---- ray.hpp:36-56, hitable.hpp:39-113 ---- */
+struct Ray {
+    V3 origin, direction;
+    float time;
+    V4 refractiveIndex;
+    V3 at(float a) const { return origin + a * direction; }
+};
+struct HitRecord {
+    bool haveHit = false;
+    float a;
+    V3 position, normal, tangent;
+    V2 texcoords;
+    bool backside;
+    uint32_t prim; /* stands for `const Hitable* hitable` */
+};
+struct RayHelper {
+    V3 invDirection;
+    int kx, ky, kz;
+    V3 S;
+    explicit RayHelper(const Ray& ray)
+    {
+        invDirection = 1.0f / ray.direction;
+        V3 absdir = V3 { std::fabs(ray.direction.x), std::fabs(ray.direction.y), std::fabs(ray.direction.z) };
+        if (absdir.z >= absdir.y && absdir.z >= absdir.x)
+            kz = 2;
+        else if (absdir.y >= absdir.x)
+            kz = 1;
+        else
+            kz = 0;
+        kx = kz + 1;
+        if (kx == 3)
+            kx = 0;
+        ky = kx + 1;
+        if (ky == 3)
+            ky = 0;
+        if (ray.direction[kz] < 0.0f) {
+            int tmp = kx;
+            kx = ky;
+            ky = tmp;
+        }
+        S.x = ray.direction[kx] * invDirection[kz];
+        S.y = ray.direction[ky] * invDirection[kz];
+        S.z = invDirection[kz];
+    }
+};
+
+/* ---- aabb.hpp:70-86 ---- */
+inline bool aabbMayHit(const float* lo, const float* hi, const Ray& ray, float amin, float amax, V3 invDir)
+{
+    V3 t0 = (v3(lo) - ray.origin) * invDir;
+    V3 t1 = (v3(hi) - ray.origin) * invDir;
+    V4 tmin = V4 { amin, fmin_(t0.x, t1.x), fmin_(t0.y, t1.y), fmin_(t0.z, t1.z) };
+    V4 tmax = V4 { amax, fmax_(t0.x, t1.x), fmax_(t0.y, t1.y), fmax_(t0.z, t1.z) };
+    return max4(tmin) <= min4(tmax);
+}
+
+struct Ctx {
+    const wpt_scene_desc* sc;
+    const wpt_params* pr;
+    wpt_counters cnt;
+};
+
+/* ---- hitable_triangle.hpp:189-325 ---- */
+inline float xorf(float a, uint32_t b)
+{
+    return wptm::bits_to_float(wptm::float_to_bits(a) ^ b);
+}
+
+inline HitRecord triangleHit(const Ctx& c, uint32_t prim, const Ray& ray, const RayHelper& rh,
+        float amin, float amax, bool fullInfo, V3* v0v1, V3* v0v2)
+{
+    const wpt_tri_geom& g = c.sc->tri_geom[prim];
+    V3 v0 = v3(g.v0), v1 = v3(g.v1), v2 = v3(g.v2); /* TRANSFORM already applied (host) */
+    const V3 A = v0 - ray.origin;
+    const V3 B = v1 - ray.origin;
+    const V3 C = v2 - ray.origin;
+    const float Ax = A[rh.kx] - rh.S.x * A[rh.kz];
+    const float Ay = A[rh.ky] - rh.S.y * A[rh.kz];
+    const float Bx = B[rh.kx] - rh.S.x * B[rh.kz];
+    const float By = B[rh.ky] - rh.S.y * B[rh.kz];
+    const float Cx = C[rh.kx] - rh.S.x * C[rh.kz];
+    const float Cy = C[rh.ky] - rh.S.y * C[rh.kz];
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    const float ldeps = float(std::numeric_limits<long double>::epsilon());
+    if (std::fabs(U) < ldeps || std::fabs(V) < ldeps || std::fabs(W) < ldeps) {
+        double CxBy = double(Cx) * double(By);
+        double CyBx = double(Cy) * double(Bx);
+        U = CxBy - CyBx;
+        double AxCy = double(Ax) * double(Cy);
+        double AyCx = double(Ay) * double(Cx);
+        V = AxCy - AyCx;
+        double BxAy = double(Bx) * double(Ay);
+        double ByAx = double(By) * double(Ax);
+        W = BxAy - ByAx;
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f))
+        return HitRecord();
+    float det = U + V + W;
+    if (det == 0.0f)
+        return HitRecord();
+    const float Az = rh.S.z * A[rh.kz];
+    const float Bz = rh.S.z * B[rh.kz];
+    const float Cz = rh.S.z * C[rh.kz];
+    const float T = U * Az + V * Bz + W * Cz;
+    uint32_t detSign = uint32_t(std::signbit(det)) << 31;
+    if (xorf(T, detSign) < amin * xorf(det, detSign) || xorf(T, detSign) > amax * xorf(det, detSign))
+        return HitRecord();
+    const float invDet = 1.0f / det;
+    const float a = invDet * T;
+
+    HitRecord hr;
+    hr.haveHit = true;
+    hr.a = a;
+    if (!fullInfo) {
+        *v0v1 = v1 - v0;
+        *v0v2 = v2 - v0;
+        return hr;
+    }
+
+    bool backfacing = (det < 0.0f);
+    const V3 bary = invDet * V3 { U, V, W };
+    V3 hitpos = ray.at(a);
+    const wpt_tri_attr& at = c.sc->tri_attr[prim];
+    const bool transform = (g.flags & WPT_TRI_TRANSFORM) != 0;
+    const float* N = c.sc->instances[g.instance].N;
+    V3 hitnrm = bary.x * v3(at.n0) + bary.y * v3(at.n1) + bary.z * v3(at.n2);
+    if (transform)
+        hitnrm = mat3_mul(N, hitnrm);
+    hitnrm = normalize(hitnrm);
+    if (backfacing)
+        hitnrm = -hitnrm;
+    V2 hittc = V2 { 0.0f, 0.0f };
+    if (g.flags & WPT_TRI_HAVE_TEXCOORDS) {
+        V2 tc0 = V2 { at.tc0[0], at.tc0[1] }, tc1 = V2 { at.tc1[0], at.tc1[1] }, tc2 = V2 { at.tc2[0], at.tc2[1] };
+        hittc = bary.x * tc0 + bary.y * tc1 + bary.z * tc2;
+    }
+    V3 hittan = v3(0.0f);
+    if (g.flags & WPT_TRI_HAVE_TANGENTS) {
+        hittan = bary.x * v3(at.t0) + bary.y * v3(at.t1) + bary.z * v3(at.t2);
+        if (dot(hittan, hittan) > 0.0f) {
+            if (transform)
+                hittan = mat3_mul(N, hittan);
+            hittan = normalize(hittan - dot(hitnrm, hittan) * hitnrm);
+        }
+    }
+    hr.position = hitpos;
+    hr.normal = hitnrm;
+    hr.tangent = hittan;
+    hr.texcoords = hittc;
+    hr.backside = backfacing;
+    hr.prim = prim;
+    return hr;
+}
+
+/* hitable_triangle.hpp:405-423 */
+inline float trianglePdfValue(Ctx& c, uint32_t prim, V3 origin, V3 direction)
+{
+    c.cnt.pdf_tests++;
+    float value = 0.0f;
+    Ray ray { origin, direction, 0.0f, v4(0.0f) };
+    V3 v0v1, v0v2;
+    HitRecord hr = triangleHit(c, prim, ray, RayHelper(ray), 0.0f, k_maxval, false, &v0v1, &v0v2);
+    if (hr.haveHit) {
+        V3 edgeCross = cross(v0v1, v0v2);
+        float edgeCrossLength = std::sqrt(dot(edgeCross, edgeCross));
+        V3 faceNormal = edgeCross / edgeCrossLength;
+        float faceArea = 0.5f * edgeCrossLength;
+        float cosine = std::fabs(dot(faceNormal, -direction));
+        float distance_squared = hr.a * hr.a;
+        value = distance_squared / (cosine * faceArea);
+    }
+    return value;
+}
+
+/* hitable_triangle.hpp:425-443 */
+inline V3 triangleDirection(const Ctx& c, uint32_t hotspot, V3 origin, Prng& prng)
+{
+    const wpt_hotspot& h = c.sc->hotspots[hotspot];
+    V3 bary = inTriangle(prng.in01x2());
+    V3 p = bary.x * v3(h.p0) + bary.y * v3(h.p1) + bary.z * v3(h.p2);
+    if (h.transform)
+        p = mat4_mul_point(h.M, p);
+    return normalize(p - origin);
+}
+
+/* ---- bvh.hpp:277-311 ---- */
+/* leafHit(prim, amin, amax) stands for the virtual `node.hitable->hit(...)` */
+template<typename LeafHit>
+inline HitRecord bvhTraverse(const wpt_bvh_node* nodes, wpt_counters& cnt, const Ray& ray, const RayHelper& rh,
+        float amin, float amax, LeafHit&& leafHit)
+{
+    cnt.rays++;
+    HitRecord hr;
+    size_t toVisitOffset = 0;
+    size_t currentNodeIndex = 0;
+    uint32_t nodesToVisit[128];
+    for (;;) {
+        const wpt_bvh_node& node = nodes[currentNodeIndex];
+        cnt.node_visits++;
+        if (aabbMayHit(node.lo, node.hi, ray, amin, amax, rh.invDirection)) {
+            if (node.kind != WPT_NODE_INNER) {
+                if (node.kind != WPT_NODE_EMPTY) {
+                    cnt.leaf_tests++;
+                    HitRecord cur = leafHit(node.link, amin, amax);
+                    if (cur.haveHit) {
+                        hr = cur;
+                        amax = hr.a;
+                    }
+                }
+                if (toVisitOffset == 0)
+                    break;
+                currentNodeIndex = nodesToVisit[--toVisitOffset];
+            } else {
+                nodesToVisit[toVisitOffset++] = node.link;
+                currentNodeIndex++;
+            }
+        } else {
+            if (toVisitOffset == 0)
+                break;
+            currentNodeIndex = nodesToVisit[--toVisitOffset];
+        }
+    }
+    return hr;
+}
+
+inline HitRecord bvhHit(Ctx& c, const Ray& ray, const RayHelper& rh, float amin, float amax)
+{
+    return bvhTraverse(c.sc->nodes, c.cnt, ray, rh, amin, amax, [&](uint32_t prim, float lo, float hi) {
+        return triangleHit(c, prim, ray, rh, lo, hi, true, nullptr, nullptr);
+    });
+}
+
+/* ---- textures: texture.hpp:160-246, texture_image.hpp:85-212, color.hpp:275-294 ---- */
+inline float srgb_to_rgb_helper(float x)
+{
+    return (x <= 0.04045f ? (x * (1.0f / 12.92f)) : m_pow((x + 0.055f) * (1.0f / 1.055f), 2.4f));
+}
+
+V4 textureValue(const Ctx& c, int tex, V2 texcoords);
+
+inline V4 imageTexel(const Ctx& c, const wpt_texture& t, size_t x, size_t y)
+{
+    if (x >= t.width)
+        x = t.width - 1;
+    if (y >= t.height)
+        y = t.height - 1;
+    const uint8_t* base = c.sc->texels + t.texel_offset;
+    size_t idx = (y * size_t(t.width) + x) * t.comps;
+    float d[4];
+    bool lin = t.linearize_srgb != 0;
+    for (uint32_t k = 0; k < t.comps; k++) {
+        float raw;
+        if (t.texel_type == WPT_TEXEL_U8)
+            raw = base[idx + k] / 255.0f;
+        else if (t.texel_type == WPT_TEXEL_U16)
+            raw = reinterpret_cast<const uint16_t*>(base)[idx + k] / 65535.0f;
+        else
+            raw = reinterpret_cast<const float*>(base)[idx + k];
+        /* colour channels are linearized, alpha (2nd of 2, 4th of 4) never */
+        bool isAlpha = (t.comps == 2 && k == 1) || (t.comps == 4 && k == 3);
+        d[k] = (lin && !isAlpha) ? srgb_to_rgb_helper(raw) : raw;
+    }
+    if (t.comps == 3)
+        return V4 { d[0], d[1], d[2], 1.0f };
+    if (t.comps == 4)
+        return V4 { d[0], d[1], d[2], d[3] };
+    if (t.comps == 1)
+        return V4 { d[0], d[0], d[0], 1.0f };
+    return V4 { d[0], d[0], d[0], d[1] };
+}
+
+V4 textureValue(const Ctx& c, int tex, V2 texcoords)
+{
+    const wpt_texture& t = c.sc->textures[tex];
+    switch (t.type) {
+    case WPT_TEX_CONSTANT:
+        return v4(t.a);
+    case WPT_TEX_CHECKER: {
+        int row = texcoords.y * int(t.height);
+        int col = texcoords.x * int(t.width);
+        return (row % 2 == col % 2 ? v4(t.a) : v4(t.b));
+    }
+    case WPT_TEX_TRANSFORMER: {
+        V2 cf = V2 { t.coord_factor[0], t.coord_factor[1] }, co = V2 { t.coord_offset[0], t.coord_offset[1] };
+        V4 val = textureValue(c, t.child, cf * texcoords + co);
+        return v4(t.a) * val + v4(t.b);
+    }
+    default: {
+        V2 cf = V2 { t.coord_factor[0], t.coord_factor[1] }, co = V2 { t.coord_offset[0], t.coord_offset[1] };
+        V2 tc = cf * texcoords + co;
+        V2 uv = V2 { tc.x - std::floor(tc.x), tc.y - std::floor(tc.y) };
+        float uvs = fmax_(0.0f, (uv.x * t.width) - 0.5f);
+        float uvt = fmax_(0.0f, (uv.y * t.height) - 0.5f);
+        size_t x0 = uvs;
+        size_t y0 = uvt;
+        size_t x1 = x0 + 1;
+        size_t y1 = y0 + 1;
+        float alpha = uvs - x0;
+        float beta = uvt - y0;
+        V4 v00 = imageTexel(c, t, x0, y0);
+        V4 v10 = imageTexel(c, t, x1, y0);
+        V4 v01 = imageTexel(c, t, x0, y1);
+        V4 v11 = imageTexel(c, t, x1, y1);
+        V4 a = mix4(v00, v10, alpha);
+        V4 b = mix4(v01, v11, alpha);
+        V4 val = mix4(a, b, beta);
+        return v4(t.a) * val + v4(t.b);
+    }
+    }
+}
+
+/* ---- envmap.hpp:55-247 ---- */
+inline V2 envM(V3 d)
+{
+    float lat = m_asin(clamp_(d.y, -1.0f, +1.0f));
+    float lon = m_atan2(-d.x, d.z);
+    float r = m_sin(0.5f * (k_pi_2 - lat));
+    float alpha = lon - k_pi_2;
+    float u, v;
+    if (alpha < -k_pi_4)
+        alpha += 2.0f * k_pi;
+    if (alpha < k_pi_4) {
+        u = r;
+        v = alpha * u / k_pi_4;
+    } else if (alpha < k_pi_2 + k_pi_4) {
+        v = r;
+        u = -(alpha - k_pi_2) * v / k_pi_4;
+    } else if (alpha < k_pi + k_pi_4) {
+        u = -r;
+        v = (alpha - k_pi) * u / k_pi_4;
+    } else {
+        v = -r;
+        u = -(alpha - (k_pi + k_pi_2)) * v / k_pi_4;
+    }
+    return V2 { 0.5f * (u + 1.0f), 0.5f * (v + 1.0f) };
+}
+inline V3 envInvM(V2 uv)
+{
+    float u = 2.0f * uv.x - 1.0f;
+    float v = 2.0f * uv.y - 1.0f;
+    float r, alpha;
+    if (u * u > v * v) {
+        r = u;
+        alpha = k_pi_4 * v / u;
+    } else {
+        r = v;
+        if (std::fabs(v) > 0.0f)
+            alpha = k_pi_2 - k_pi_4 * u / v;
+        else
+            alpha = 0.0f;
+    }
+    float lat = k_pi_2 - 2.0f * m_asin(r);
+    float lon = alpha + k_pi_2;
+    V3 d = V3 { -m_cos(lat) * m_sin(lon), m_sin(lat), m_cos(lat) * m_cos(lon) };
+    return normalize(d);
+}
+inline V4 envL(const Ctx& c, V3 direction)
+{
+    const wpt_envmap& e = c.sc->envmap;
+    float y = m_asin(clamp_(direction.y, -1.0f, 1.0f));
+    float x = m_atan2(-direction.x, direction.z);
+    if (e.compat == WPT_ENV_COMPAT_MITSUBA) {
+        x -= k_pi;
+        if (x < 0.0f)
+            x += 2.0f * k_pi;
+    }
+    x *= 0.5f * k_inv_pi;
+    y = y * k_inv_pi + 0.5f;
+    return textureValue(c, e.tex, V2 { x, y });
+}
+inline float envP(const Ctx& c, V3 direction)
+{
+    const wpt_envmap& e = c.sc->envmap;
+    int N = e.N;
+    V2 uv = envM(direction);
+    int x = uv.x * N;
+    int y = uv.y * N;
+    if (x >= N)
+        x = N - 1;
+    if (y >= N)
+        y = N - 1;
+    float q = e.M[y * N + x];
+    float invBinSizeOnSphere = (N * N) * 0.25f * k_inv_pi;
+    return q * invBinSizeOnSphere;
+}
+inline V3 envD(const Ctx& c, Prng& prng)
+{
+    const wpt_envmap& e = c.sc->envmap;
+    int N = e.N;
+    float r = prng.in01();
+    int a = 0;
+    int b = N * N - 1;
+    while (b > a + 1) {
+        int cc = (a + b) / 2;
+        if (e.Mcs[cc] < r)
+            a = cc;
+        else
+            b = cc;
+    }
+    int bin = (e.Mcs[a] >= r ? a : b);
+    bin = e.Ms[bin];
+    int x = bin % N;
+    int y = bin / N;
+    float u = (x + prng.in01()) / N;
+    float v = (y + prng.in01()) / N;
+    return envInvM(V2 { u, v });
+}
+
+/* ---- materials ---- */
+enum { ScatterNone = 0, ScatterExplicit = 1, ScatterRandom = 2 };
+struct ScatterRecord {
+    int type = ScatterNone;
+    V3 direction { 0, 0, 0 };
+    V4 attenuation { 0, 0, 0, 0 };
+    float pdf = 0.0f;
+    V4 refractiveIndex { 0, 0, 0, 0 };
+};
+inline ScatterRecord srExplicit(V3 dir, V4 att, V4 ri)
+{
+    ScatterRecord s;
+    s.type = ScatterExplicit;
+    s.direction = dir;
+    s.attenuation = att;
+    s.pdf = 0.0f;
+    s.refractiveIndex = ri;
+    return s;
+}
+inline ScatterRecord srRandom(V3 dir, V4 att, float p, V4 ri)
+{
+    ScatterRecord s;
+    s.type = ScatterRandom;
+    s.direction = dir;
+    s.attenuation = att;
+    s.pdf = p;
+    s.refractiveIndex = ri;
+    return s;
+}
+
+/* material.hpp:195-228 */
+inline V3 normalAt(const Ctx& c, const wpt_material& m, const HitRecord& hit)
+{
+    V3 n = hit.normal;
+    if (m.normal_tex >= 0) {
+        n = rgb(textureValue(c, m.normal_tex, hit.texcoords));
+        n = 2.0f * n - v3(1.0f);
+        n = normalize(TangentSpace(hit.normal, hit.tangent).toWorldSpace(n));
+    }
+    return n;
+}
+inline TangentSpace tangentSpaceAt(const Ctx& c, const wpt_material& m, const HitRecord& hit)
+{
+    TangentSpace ts;
+    if (dot(hit.tangent, hit.tangent) > k_epsilon) {
+        ts = TangentSpace(hit.normal, hit.tangent);
+        if (m.normal_tex >= 0) {
+            V3 n = rgb(textureValue(c, m.normal_tex, hit.texcoords));
+            n = 2.0f * n - v3(1.0f);
+            n = normalize(ts.toWorldSpace(n));
+            V3 t = normalize(hit.tangent - dot(n, hit.tangent) * n);
+            ts = TangentSpace(n, t);
+        }
+    } else {
+        ts = TangentSpace(hit.normal);
+    }
+    return ts;
+}
+
+/* material_lambertian.hpp:53-102 */
+inline V4 lambertianAlbedoAt(const Ctx& c, const wpt_material& m, V2 tc)
+{
+    V4 a = m.tex[0] >= 0 ? textureValue(c, m.tex[0], tc) : v4(m.v[0]);
+    if (!(m.flags & WPT_MATF_HAVE_NIR))
+        a.w = average3(rgb(a));
+    return a;
+}
+
+/* material_ggx.hpp:89-171 */
+inline float ggxLambda(V3 tsv, V2 roughness)
+{
+    V2 a2 = roughness * roughness;
+    V3 tsv2 = tsv * tsv;
+    float discriminant = 1.0f + (a2.x * tsv2.x + a2.y * tsv2.y) / tsv2.z;
+    return 0.5f * (-1.0f + std::sqrt(discriminant));
+}
+inline float ggxG1(V3 tsv, V2 r) { return 1.0f / (1.0f + ggxLambda(tsv, r)); }
+inline float ggxG2(V3 tsV, V3 tsL, V2 r) { return 1.0f / (1.0f + ggxLambda(tsV, r) + ggxLambda(tsL, r)); }
+inline float ggxD(V3 tsH, V2 roughness)
+{
+    V2 a2 = roughness * roughness;
+    V3 tsh2 = tsH * tsH;
+    float t = tsh2.x / a2.x + tsh2.y / a2.y + tsh2.z;
+    float D = 1.0f / (k_pi * roughness.x * roughness.y * t * t);
+    return D;
+}
+inline float ggxDV(V3 tsH, V3 tsV, float dotVH, V2 roughness)
+{
+    float dotVZ = tsV.z;
+    float DV = ggxG1(tsV, roughness) * dotVH * ggxD(tsH, roughness) / dotVZ;
+    return DV;
+}
+inline V3 ggxSampleVNDF(V3 Ve, V2 roughness, Prng& prng)
+{
+    float alpha_x = roughness.x;
+    float alpha_y = roughness.y;
+    float U1 = prng.in01();
+    float U2 = prng.in01();
+    V3 Vh = normalize(V3 { alpha_x * Ve.x, alpha_y * Ve.y, Ve.z });
+    float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    V3 T1 = lensq > 0.0f ? V3 { -Vh.y, Vh.x, 0.0f } * (1.0f / std::sqrt(lensq)) : V3 { 1.0f, 0.0f, 0.0f };
+    V3 T2 = cross(Vh, T1);
+    float r = std::sqrt(U1);
+    float phi = 2.0f * k_pi * U2;
+    float t1 = r * m_cos(phi);
+    float t2 = r * m_sin(phi);
+    float s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * std::sqrt(1.0f - t1 * t1) + s * t2;
+    V3 Nh = t1 * T1 + t2 * T2 + std::sqrt(fmax_(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
+    V3 Ne = normalize(V3 { alpha_x * Nh.x, alpha_y * Nh.y, fmax_(0.0f, Nh.z) });
+    return Ne;
+}
+inline V4 ggxAlbedoAt(const Ctx& c, const wpt_material& m, V2 tc)
+{
+    return m.tex[0] >= 0 ? textureValue(c, m.tex[0], tc) : v4(m.v[0]);
+}
+inline V2 ggxRoughnessAt(const Ctx& c, const wpt_material& m, V2 tc)
+{
+    V2 r = V2 { m.f[0], m.f[1] };
+    if (m.tex[1] >= 0) {
+        V4 t = textureValue(c, m.tex[1], tc);
+        r = V2 { t.x, t.y };
+    }
+    return r;
+}
+
+/* material_modphong.hpp:136-239 */
+inline float mpOpacityAt(const Ctx& c, const wpt_material& m, V2 tc)
+{
+    if (m.tex[3] >= 0)
+        return textureValue(c, m.tex[3], tc).x;
+    if (m.flags & WPT_MATF_DIFFUSE_TEX_HAS_ALPHA)
+        return textureValue(c, m.tex[0], tc).w;
+    return m.f[1];
+}
+inline V4 mpDiffuseAt(const Ctx& c, const wpt_material& m, V2 tc)
+{
+    V4 kd = m.tex[0] >= 0 ? textureValue(c, m.tex[0], tc) : v4(m.v[0]);
+    if (!(m.flags & WPT_MATF_HAVE_NIR))
+        kd.w = average3(rgb(kd));
+    return kd;
+}
+inline V4 mpSpecularAt(const Ctx& c, const wpt_material& m, V2 tc)
+{
+    V4 ks = m.tex[1] >= 0 ? textureValue(c, m.tex[1], tc) : v4(m.v[1]);
+    if (m.flags & WPT_MATF_SPECULAR_TEX_HAS_ALPHA) {
+        V3 mx = mix3(rgb(ks), rgb(v4(m.v[1])), ks.w);
+        ks = V4 { mx.x, mx.y, mx.z, ks.w };
+    }
+    if (!(m.flags & WPT_MATF_HAVE_NIR))
+        ks.w = average3(rgb(ks));
+    return ks;
+}
+inline float mpShininessAt(const Ctx& c, const wpt_material& m, V2 tc)
+{
+    float s = m.f[0];
+    if (m.tex[2] >= 0)
+        s *= textureValue(c, m.tex[2], tc).x;
+    return s;
+}
+inline V4 mpEmissiveAt(const Ctx& c, const wpt_material& m, V2 tc)
+{
+    V4 ke = m.tex[4] >= 0 ? textureValue(c, m.tex[4], tc) : v4(m.v[3]);
+    if (!(m.flags & WPT_MATF_HAVE_NIR))
+        ke.w = average3(rgb(ke));
+    return ke;
+}
+inline V4 mpAttenuation(V3 n, V3 v, V3 l, V4 kd, V4 ks, float s, float cosTheta)
+{
+    V3 r = reflect(-l, n);
+    float cosRV = fmax_(dot(r, v), 0.0f);
+    return (kd + 0.5f * ks * (s + 2.0f) * m_pow(cosRV, s)) * k_inv_pi * fmin_(cosTheta, 1.0f);
+}
+inline float mpSpecularProbability(V4 kd, V4 ks)
+{
+    float skd = kd.x + kd.y + kd.z + kd.w;
+    float sks = ks.x + ks.y + ks.z + ks.w;
+    float sum = skd + sks + 1e-4f;
+    float p = sks / sum;
+    return clamp_(p, 0.1f, 0.9f);
+}
+inline float mpPdfValue(V3 n, V3 v, V3 l, float s, float cosTheta, float specProb)
+{
+    float diffusePdfValue = cosTheta * k_inv_pi;
+    V3 r = reflect(-v, n);
+    float cosRL = fmax_(dot(r, l), 0.0f);
+    float specularPdfValue = 0.5f * k_inv_pi * (s + 1.0f) * m_pow(cosRL, s);
+    return mix_(diffusePdfValue, specularPdfValue, specProb);
+}
+
+ScatterRecord materialScatter(Ctx& c, uint32_t mat, const Ray& ray, const HitRecord& hit, Prng& prng);
+ScatterRecord materialScatterToDirection(const Ctx& c, uint32_t mat, const Ray& ray, const HitRecord& hit, V3 direction);
+V4 materialEmitted(const Ctx& c, uint32_t mat, const Ray& ray, const HitRecord& hit);
+
+inline HitRecord toFrontSide(const HitRecord& hit) /* material.hpp:279-282 */
+{
+    HitRecord h = hit;
+    h.backside = false;
+    return h;
+}
+
+ScatterRecord materialScatter(Ctx& c, uint32_t mat, const Ray& ray, const HitRecord& hit, Prng& prng)
+{
+    const wpt_material& m = c.sc->materials[mat];
+    switch (m.type) {
+    case WPT_MAT_LAMBERTIAN: { /* material_lambertian.hpp:61-84 */
+        if (hit.backside)
+            return ScatterRecord();
+        V3 cosineDir = cosineDirection(prng.in01x2());
+        float cosTheta = cosineDir.z;
+        TangentSpace ts = tangentSpaceAt(c, m, hit);
+        V3 dir = normalize(ts.toWorldSpace(cosineDir));
+        float p = cosTheta * k_inv_pi;
+        V4 att = lambertianAlbedoAt(c, m, hit.texcoords) * p;
+        return srRandom(dir, att, p, ray.refractiveIndex);
+    }
+    case WPT_MAT_MIRROR: { /* material_mirror.hpp:53-62 */
+        if (hit.backside)
+            return ScatterRecord();
+        V3 reflected = reflect(ray.direction, normalAt(c, m, hit));
+        V4 att = m.tex[0] >= 0 ? textureValue(c, m.tex[0], hit.texcoords) : v4(m.v[0]);
+        if (!(m.flags & WPT_MATF_HAVE_NIR))
+            att.w = average3(rgb(att));
+        return srExplicit(normalize(reflected), att, ray.refractiveIndex);
+    }
+    case WPT_MAT_GGX: { /* material_ggx.hpp:173-225 */
+        if (hit.backside)
+            return ScatterRecord();
+        V3 view = -ray.direction;
+        V2 roughness = ggxRoughnessAt(c, m, hit.texcoords);
+        TangentSpace ts = tangentSpaceAt(c, m, hit);
+        V3 tsV = ts.toTangentSpace(view);
+        V3 tsH = ggxSampleVNDF(tsV, roughness, prng);
+        V3 tsL = reflect(-tsV, tsH);
+        V3 light = ts.toWorldSpace(tsL);
+        float l = dot(light, light);
+        if (l < k_epsilon)
+            return ScatterRecord();
+        V3 dir = light / std::sqrt(l);
+        float dotVH = dot(tsV, tsH);
+        float p = ggxDV(tsH, tsV, dotVH, roughness) / (4.0f * dotVH);
+        if (!std::isfinite(p) || p < 0.0f)
+            return ScatterRecord();
+        V4 att = v4(0.0f);
+        float dotNL = dot(ts.normal, light);
+        float dotNV = dot(ts.normal, view);
+        if (dotNL > 0.0f && dotNV > 0.0f) {
+            float Dval = ggxD(tsH, roughness);
+            V4 albedo = ggxAlbedoAt(c, m, hit.texcoords);
+            V4 Fval = fresnelSchlick(albedo, dotVH);
+            float Gval = ggxG2(tsV, tsL, roughness);
+            att = Dval * Fval * Gval / (4.0f * dotNV);
+        }
+        return srRandom(dir, att, p, ray.refractiveIndex);
+    }
+    case WPT_MAT_GLASS: { /* material_glass.hpp:91-152 */
+        V4 att = v4(1.0f);
+        V4 ourRI = v4(m.v[1]);
+        V4 theirRI = v4(m.v[2]);
+        int riIndex = 0;
+        if (m.flags & WPT_MATF_CHROMATIC_DISPERSION) {
+            riIndex = prng.in01() * 4;
+            att = v4(0.0f);
+            att.at(riIndex) = 4.0f;
+        }
+        if (hit.backside) {
+            V4 tmp = ourRI;
+            ourRI = theirRI;
+            theirRI = tmp;
+            float distInVolume = hit.a;
+            V4 e = -v4(m.v[0]) * distInVolume;
+            att = att * V4 { m_exp(e.x), m_exp(e.y), m_exp(e.z), m_exp(e.w) };
+        }
+        V3 n = normalAt(c, m, hit);
+        V3 refracted = refract(ray.direction, n, theirRI[riIndex] / ourRI[riIndex]);
+        bool doReflection = true;
+        if (dot(refracted, refracted) > 0.0f) {
+            float cosIncident = dot(-ray.direction, n);
+            float cosTransmitted = -dot(refracted, n);
+            float fresnel = fresnelUnpolarized(cosIncident, cosTransmitted, theirRI[riIndex], ourRI[riIndex]);
+            doReflection = prng.in01() < fresnel;
+        }
+        if (doReflection) {
+            V3 reflected = reflect(ray.direction, n);
+            return srExplicit(normalize(reflected), att, theirRI);
+        } else {
+            return srExplicit(normalize(refracted), att, ourRI);
+        }
+    }
+    case WPT_MAT_MODPHONG: { /* material_modphong.hpp:241-308 */
+        float opa = mpOpacityAt(c, m, hit.texcoords);
+        bool transparent = (opa < 1.0f && opa < prng.in01());
+        if (transparent) {
+            float ourRI = m.f[2];
+            float theirRI = 1.0f;
+            if (hit.backside) {
+                float tmp = ourRI;
+                ourRI = theirRI;
+                theirRI = tmp;
+            }
+            V3 n = normalize(normalAt(c, m, hit));
+            V3 refracted = refract(ray.direction, n, theirRI / ourRI);
+            float l = dot(refracted, refracted);
+            if (l < k_epsilon)
+                return ScatterRecord();
+            refracted = refracted / std::sqrt(l);
+            V4 att = v4(m.v[2]);
+            if (!(m.flags & WPT_MATF_HAVE_NIR))
+                att.w = average3(rgb(att));
+            return srExplicit(refracted, att, v4(ourRI));
+        }
+        if (hit.backside)
+            return ScatterRecord();
+        V4 kd = mpDiffuseAt(c, m, hit.texcoords);
+        V4 ks = mpSpecularAt(c, m, hit.texcoords);
+        float s = mpShininessAt(c, m, hit.texcoords);
+        float specProb = mpSpecularProbability(kd, ks);
+        V3 dir, n;
+        float cosTheta;
+        if (prng.in01() < specProb) {
+            float r1 = prng.in01();
+            float r2 = prng.in01();
+            float cosThetaSpec = m_pow(1.0f - r1, 1.0f / (1.0f + s));
+            float discriminant = fmax_(1.0f - cosThetaSpec * cosThetaSpec, 0.0f);
+            float sinThetaSpec = std::sqrt(discriminant);
+            float phi = 2.0f * k_pi * r2;
+            float x = m_cos(phi) * sinThetaSpec;
+            float y = m_sin(phi) * sinThetaSpec;
+            float z = cosThetaSpec;
+            n = normalAt(c, m, hit);
+            TangentSpace specTS = TangentSpace(reflect(ray.direction, n));
+            dir = normalize(specTS.toWorldSpace(V3 { x, y, z }));
+            cosTheta = fmax_(dot(dir, n), 0.0f);
+        } else {
+            TangentSpace ts = tangentSpaceAt(c, m, hit);
+            n = ts.normal;
+            V3 cosineDir = cosineDirection(prng.in01x2());
+            cosTheta = cosineDir.z;
+            dir = normalize(ts.toWorldSpace(cosineDir));
+        }
+        V4 att = mpAttenuation(n, -ray.direction, dir, kd, ks, s, cosTheta);
+        float p = mpPdfValue(n, -ray.direction, dir, s, cosTheta, specProb);
+        return srRandom(dir, att, p, ray.refractiveIndex);
+    }
+    case WPT_MAT_TWOSIDED: /* material.hpp:290-296 */
+        return hit.backside ? materialScatter(c, uint32_t(m.tex[1]), ray, toFrontSide(hit), prng)
+                            : materialScatter(c, uint32_t(m.tex[0]), ray, hit, prng);
+    default: /* material.hpp:158-164: lights and the base class do not scatter */
+        return ScatterRecord();
+    }
+}
+
+ScatterRecord materialScatterToDirection(const Ctx& c, uint32_t mat, const Ray& ray, const HitRecord& hit, V3 direction)
+{
+    const wpt_material& m = c.sc->materials[mat];
+    switch (m.type) {
+    case WPT_MAT_LAMBERTIAN: { /* material_lambertian.hpp:86-102 */
+        V4 att = v4(0.0f);
+        float p = 0.0f;
+        float cosTheta = dot(normalAt(c, m, hit), direction);
+        if (cosTheta > 0.0f) {
+            p = cosTheta * k_inv_pi;
+            att = lambertianAlbedoAt(c, m, hit.texcoords) * p;
+        }
+        return srRandom(direction, att, p, ray.refractiveIndex);
+    }
+    case WPT_MAT_GGX: { /* material_ggx.hpp:227-257 */
+        V4 att = v4(0.0f);
+        float p = 0.0f;
+        V3 view = -ray.direction;
+        V3 light = direction;
+        TangentSpace ts = tangentSpaceAt(c, m, hit);
+        float dotNL = dot(ts.normal, light);
+        float dotNV = dot(ts.normal, view);
+        if (dotNL > 0.0f && dotNV > 0.0f) {
+            V2 roughness = ggxRoughnessAt(c, m, hit.texcoords);
+            V3 tsV = ts.toTangentSpace(view);
+            V3 tsL = ts.toTangentSpace(light);
+            V3 tsH = normalize(tsV + tsL);
+            float dotVH = dot(tsV, tsH);
+            if (dotVH > 0.0f) {
+                p = ggxDV(tsH, tsV, dotVH, roughness) / (4.0f * dotVH);
+                float Dval = ggxD(tsH, roughness);
+                V4 albedo = ggxAlbedoAt(c, m, hit.texcoords);
+                V4 Fval = fresnelSchlick(albedo, dotVH);
+                float Gval = ggxG2(tsV, tsL, roughness);
+                att = Dval * Fval * Gval / (4.0f * dotNV);
+            }
+        }
+        return srRandom(direction, att, p, ray.refractiveIndex);
+    }
+    case WPT_MAT_MODPHONG: { /* material_modphong.hpp:310-327 */
+        V4 att = v4(0.0f);
+        float p = 0.0f;
+        V3 n = normalAt(c, m, hit);
+        float cosTheta = dot(n, direction);
+        if (cosTheta > 0.0f) {
+            V4 kd = mpDiffuseAt(c, m, hit.texcoords);
+            V4 ks = mpSpecularAt(c, m, hit.texcoords);
+            float s = mpShininessAt(c, m, hit.texcoords);
+            float specProb = mpSpecularProbability(kd, ks);
+            att = mpAttenuation(n, -ray.direction, direction, kd, ks, s, cosTheta);
+            p = mpPdfValue(n, -ray.direction, direction, s, cosTheta, specProb);
+        }
+        return srRandom(direction, att, p, ray.refractiveIndex);
+    }
+    case WPT_MAT_TWOSIDED: /* material.hpp:298-304 */
+        return hit.backside ? materialScatterToDirection(c, uint32_t(m.tex[1]), ray, toFrontSide(hit), direction)
+                            : materialScatterToDirection(c, uint32_t(m.tex[0]), ray, hit, direction);
+    default: /* material.hpp:174-180 */
+        return ScatterRecord();
+    }
+}
+
+V4 materialEmitted(const Ctx& c, uint32_t mat, const Ray& ray, const HitRecord& hit)
+{
+    const wpt_material& m = c.sc->materials[mat];
+    switch (m.type) {
+    case WPT_MAT_LIGHT_DIFFUSE: { /* light_diffuse.hpp:50-61 */
+        V4 e = v4(0.0f);
+        if (!hit.backside) {
+            e = v4(m.v[0]);
+            if (m.tex[0] >= 0) {
+                V3 c3 = rgb(textureValue(c, m.tex[0], hit.texcoords));
+                e = e * V4 { c3.x, c3.y, c3.z, average3(c3) };
+            }
+        }
+        return e;
+    }
+    case WPT_MAT_MODPHONG: { /* material_modphong.hpp:183-190 */
+        V4 e = v4(0.0f);
+        if (!hit.backside)
+            e = mpEmissiveAt(c, m, hit.texcoords);
+        return e;
+    }
+    case WPT_MAT_TWOSIDED: /* material.hpp:306-312 */
+        return hit.backside ? materialEmitted(c, uint32_t(m.tex[1]), ray, toFrontSide(hit))
+                            : materialEmitted(c, uint32_t(m.tex[0]), ray, hit);
+    default: /* material.hpp:183-186 */
+        return v4(0.0f);
+    }
+}
+
+/* ---- sensor_rgb.hpp:63-80 ---- */
+inline void accumulateRadiance(const Ctx& c, V4 opticalPathLength, float distanceToLight, V4 radiance, float* acc)
+{
+    const wpt_params& p = *c.pr;
+    for (int i = 0; i < 3; i++) {
+        if (distanceToLight >= p.min_dist_to_light && distanceToLight <= p.max_dist_to_light
+                && opticalPathLength[i] >= p.min_path_len && opticalPathLength[i] <= p.max_path_len) {
+            acc[i] += radiance[i];
+        }
+    }
+}
+
+/* ---- wurblpt.hpp:101-106 ---- */
+inline float powerHeuristicWeight(float f, float g)
+{
+    f *= f;
+    g *= g;
+    return (f + g > 0.0f ? f / (f + g) : 0.0f);
+}
+
+/* ---- wurblpt.hpp:108-275 ---- */
+void tracePath(Ctx& c, float* sampleAccumulator, const Ray& startRay, size_t hotSpotsSize, float invHotSpotsSize, Prng& prng)
+{
+    const wpt_params& params = *c.pr;
+    const wpt_scene_desc& sc = *c.sc;
+    const bool haveEnv = sc.envmap.type != WPT_ENV_NONE;
+    V4 attenuation = v4(1.0f);
+    float pathLength = 0.0f;
+    V4 opticalPathLength = v4(0.0f);
+    Ray ray = startRay;
+
+    for (unsigned int pathComponent = 0;; pathComponent++) {
+        V4 radianceToAccumulate;
+        HitRecord hr = bvhHit(c, ray, RayHelper(ray), params.min_hit_distance, k_maxval);
+        if (!hr.haveHit) {
+            if (haveEnv) {
+                radianceToAccumulate = attenuation * envL(c, ray.direction);
+                accumulateRadiance(c, v4(k_maxval), k_maxval, radianceToAccumulate, sampleAccumulator);
+            }
+            break;
+        }
+        pathLength += hr.a;
+        opticalPathLength = opticalPathLength + hr.a * ray.refractiveIndex;
+        if (!(pathComponent + 1 < params.max_path_components))
+            break;
+
+        uint32_t mat = sc.tri_geom[hr.prim].material;
+        c.cnt.scatters++;
+        ScatterRecord sr = materialScatter(c, mat, ray, hr, prng);
+        radianceToAccumulate = attenuation * materialEmitted(c, mat, ray, hr);
+        accumulateRadiance(c, opticalPathLength, (pathComponent == 0 ? 0.0f : hr.a), radianceToAccumulate, sampleAccumulator);
+        if (sr.type == ScatterNone)
+            break;
+
+        V4 nextAttenuation = attenuation * sr.attenuation;
+        if (sr.type == ScatterRandom) {
+            if (sr.pdf > 0.0f)
+                nextAttenuation = nextAttenuation / sr.pdf;
+            else
+                nextAttenuation = v4(0.0f);
+        }
+
+        if (sr.type == ScatterRandom && hotSpotsSize > 0) {
+            float hotSpotsPdf = 0.0f;
+            for (size_t i = 0; i < hotSpotsSize; i++)
+                hotSpotsPdf += trianglePdfValue(c, sc.hotspots[i].prim, hr.position, sr.direction);
+            hotSpotsPdf *= invHotSpotsSize;
+            nextAttenuation = nextAttenuation * powerHeuristicWeight(sr.pdf, hotSpotsPdf);
+            size_t hotSpotIndex = prng.in01() * hotSpotsSize;
+            hotSpotIndex = hotSpotIndex < hotSpotsSize - 1 ? hotSpotIndex : hotSpotsSize - 1;
+            V3 directDir = triangleDirection(c, uint32_t(hotSpotIndex), hr.position, prng);
+            float directPdf = 0.0f;
+            for (size_t i = 0; i < hotSpotsSize; i++)
+                directPdf += trianglePdfValue(c, sc.hotspots[i].prim, hr.position, directDir);
+            directPdf *= invHotSpotsSize;
+            if (directPdf > 0.0f) {
+                ScatterRecord directSR = materialScatterToDirection(c, mat, ray, hr, directDir);
+                if (directSR.pdf > 0.0f) {
+                    Ray directRay { hr.position, directDir, ray.time, directSR.refractiveIndex };
+                    HitRecord directHR = bvhHit(c, directRay, RayHelper(directRay), params.min_hit_distance, k_maxval);
+                    if (directHR.haveHit && directHR.prim == sc.hotspots[hotSpotIndex].prim) {
+                        float weight = powerHeuristicWeight(directPdf, directSR.pdf);
+                        uint32_t lmat = sc.tri_geom[directHR.prim].material;
+                        radianceToAccumulate = attenuation * directSR.attenuation / directPdf * weight
+                            * materialEmitted(c, lmat, directRay, directHR);
+                        V4 opticalPathLengthToAccumulate = opticalPathLength + directHR.a * directRay.refractiveIndex;
+                        accumulateRadiance(c, opticalPathLengthToAccumulate, directHR.a, radianceToAccumulate, sampleAccumulator);
+                    }
+                }
+            }
+        } else if (sr.type == ScatterRandom && haveEnv && sc.envmap.N > 0) {
+            float lightsP = envP(c, sr.direction);
+            nextAttenuation = nextAttenuation * powerHeuristicWeight(sr.pdf, lightsP);
+            V3 lightDir = envD(c, prng);
+            float lightDirP = envP(c, lightDir);
+            ScatterRecord lightSR = materialScatterToDirection(c, mat, ray, hr, lightDir);
+            if (lightSR.pdf > 0.0f) {
+                Ray lightRay { hr.position, lightDir, ray.time, lightSR.refractiveIndex };
+                HitRecord lightHR = bvhHit(c, lightRay, RayHelper(lightRay), params.min_hit_distance, k_maxval);
+                if (!lightHR.haveHit) {
+                    float weight = powerHeuristicWeight(lightDirP, lightSR.pdf);
+                    radianceToAccumulate = attenuation * lightSR.attenuation / lightDirP * weight * envL(c, lightDir);
+                    accumulateRadiance(c, v4(k_maxval), k_maxval, radianceToAccumulate, sampleAccumulator);
+                }
+            }
+        }
+
+        attenuation = nextAttenuation;
+        ray = Ray { hr.position, sr.direction, ray.time, sr.refractiveIndex };
+
+        if (max4(attenuation) < params.rr_threshold && pathComponent >= 5) {
+            float q = clamp_(1.0f - max4(attenuation), 0.0f, 0.95f);
+            if (prng.in01() < q)
+                break;
+            float rrWeight = 1.0f / (1.0f - q);
+            attenuation = attenuation * rrWeight;
+        }
+    }
+}
+
+/* ---- camera.hpp:123-185 (Surround_Off, no lens distortion, no stereo, t0 == t1) ---- */
+inline Ray cameraGetRay(const wpt_camera& cam, float p, float q, Prng& prng)
+{
+    V3 P = V3 { mix_(cam.l, cam.r, p), mix_(cam.b, cam.t, q), -1.0f };
+    V3 O = v3(0.0f);
+    if (cam.lens_radius > 0.0f) { /* optics.hpp:326-334 */
+        P = P * v3(cam.focus_dist);
+        V2 d = cam.lens_radius * inUnitDisk(prng.in01x2());
+        O = V3 { d.x, d.y, 0.0f };
+    }
+    V3 D = P - O;
+    O = O + V3 { 0.0f, 0.0f, 0.0f };
+    V3 origin = v3(cam.translation) + quat_rotate(cam.rotation, O * v3(cam.scaling)); /* transformation.hpp:80-83 */
+    V3 direction = quat_rotate(cam.rotation, D);
+    return Ray { origin, normalize(direction), 0.0f, v4(1.0f) };
+}
+
+} /* namespace */
+
+extern "C" {
+
+/* wurblpt.hpp:279-436, the pixel loop :335-381; counters are summed over threads */
+int wpt_oracle_render(const wpt_scene_desc* scene, const wpt_camera* camera, const wpt_params* params,
+        uint32_t width, uint32_t height, uint32_t samples_sqrt, uint32_t block_start, uint32_t block_size,
+        float* frame, wpt_counters* counters, int num_threads)
+{
+    if (!scene || !camera || !params || !frame || width == 0 || height == 0 || samples_sqrt == 0)
+        return 1;
+    if (uint64_t(block_start) + block_size > uint64_t(width) * height)
+        return 1;
+    unsigned int samples = samples_sqrt * samples_sqrt;
+    float invSamples = 1.0f / samples;
+    float invSamplesSqrt = 1.0f / samples_sqrt;
+    V2 invSize = V2 { 1.0f / width, 1.0f / height };
+    size_t hotSpotsSize = scene->hotspot_count;
+    float invHotSpotsSize = 1.0f / scene->hotspot_count;
+    wpt_counters total;
+    memset(&total, 0, sizeof(total));
+    if (num_threads <= 0)
+        num_threads = omp_get_max_threads();
+#pragma omp parallel num_threads(num_threads)
+    {
+        Ctx c;
+        c.sc = scene;
+        c.pr = params;
+        memset(&c.cnt, 0, sizeof(c.cnt));
+#pragma omp for schedule(dynamic)
+        for (unsigned int blockPixel = 0; blockPixel < block_size; blockPixel++) {
+            unsigned int pixel = block_start + blockPixel;
+            unsigned int y = pixel / width;
+            unsigned int x = pixel % width;
+            Prng prng(pixel);
+            float sampleAccumulator[3] = { 0.0f, 0.0f, 0.0f };
+            for (unsigned int sampleIndex = 0; sampleIndex < samples; sampleIndex++) {
+                V2 uv = V2 { float(x), float(y) };
+                if (params->randomize_ray_over_pixel) {
+                    unsigned int j = sampleIndex / samples_sqrt;
+                    unsigned int i = sampleIndex % samples_sqrt;
+                    /* wurblpt.hpp:355: g++ evaluates `j + in01()` first */
+                    float fj = j + prng.in01();
+                    float fi = i + prng.in01();
+                    uv = uv + V2 { fi, fj } * invSamplesSqrt;
+                } else {
+                    uv = uv + V2 { 0.5f, 0.5f };
+                }
+                uv = uv * invSize;
+                Ray r = cameraGetRay(*camera, uv.x, uv.y, prng);
+                c.cnt.samples++;
+                tracePath(c, sampleAccumulator, r, hotSpotsSize, invHotSpotsSize, prng);
+            }
+            frame[size_t(pixel) * 3 + 0] = invSamples * sampleAccumulator[0];
+            frame[size_t(pixel) * 3 + 1] = invSamples * sampleAccumulator[1];
+            frame[size_t(pixel) * 3 + 2] = invSamples * sampleAccumulator[2];
+        }
+#pragma omp critical
+        {
+            total.samples += c.cnt.samples;
+            total.rays += c.cnt.rays;
+            total.node_visits += c.cnt.node_visits;
+            total.leaf_tests += c.cnt.leaf_tests;
+            total.pdf_tests += c.cnt.pdf_tests;
+            total.scatters += c.cnt.scatters;
+        }
+    }
+    if (counters)
+        *counters = total;
+    return 0;
+}
+
+/* ---- per-function probes (used by tests/ to compare with the reference's golden vectors) ---- */
+
+void wpt_oracle_prng(uint32_t pixel, int n, float* out)
+{
+    Prng prng(pixel);
+    for (int i = 0; i < n; i++)
+        out[i] = prng.in01();
+}
+
+void wpt_oracle_prng_x2(uint32_t pixel, int n, float* out_xy)
+{
+    Prng prng(pixel);
+    for (int i = 0; i < n; i++) {
+        V2 v = prng.in01x2();
+        out_xy[2 * i] = v.x;
+        out_xy[2 * i + 1] = v.y;
+    }
+}
+
+/* which: 0 inUnitDisk (2 out), 1 inTriangle (3 out), 2 cosineDirection (3 out) */
+void wpt_oracle_sampler(int which, int n, const float* u_xy, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        V2 u = V2 { u_xy[2 * i], u_xy[2 * i + 1] };
+        if (which == 0) {
+            V2 r = inUnitDisk(u);
+            out[2 * i] = r.x;
+            out[2 * i + 1] = r.y;
+        } else {
+            V3 r = which == 1 ? inTriangle(u) : cosineDirection(u);
+            out[3 * i] = r.x;
+            out[3 * i + 1] = r.y;
+            out[3 * i + 2] = r.z;
+        }
+    }
+}
+
+/* TangentSpace(n) (Duff) -> tangent, bitangent, then toWorldSpace(v), toTangentSpace(v): 12 floats */
+void wpt_oracle_tangentspace(int n, const float* normals, const float* vecs, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        TangentSpace ts(v3(normals + 3 * i));
+        V3 w = ts.toWorldSpace(v3(vecs + 3 * i));
+        V3 t = ts.toTangentSpace(v3(vecs + 3 * i));
+        float* o = out + 12 * i;
+        o[0] = ts.tangent.x; o[1] = ts.tangent.y; o[2] = ts.tangent.z;
+        o[3] = ts.bitangent.x; o[4] = ts.bitangent.y; o[5] = ts.bitangent.z;
+        o[6] = w.x; o[7] = w.y; o[8] = w.z;
+        o[9] = t.x; o[10] = t.y; o[11] = t.z;
+    }
+}
+
+/* rays: origin(3) direction(3); out: invDir(3) k(3 as float) S(3) */
+void wpt_oracle_rayhelper(int n, const float* rays, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        Ray r { v3(rays + 6 * i), v3(rays + 6 * i + 3), 0.0f, v4(1.0f) };
+        RayHelper h(r);
+        float* o = out + 9 * i;
+        o[0] = h.invDirection.x; o[1] = h.invDirection.y; o[2] = h.invDirection.z;
+        o[3] = float(h.kx); o[4] = float(h.ky); o[5] = float(h.kz);
+        o[6] = h.S.x; o[7] = h.S.y; o[8] = h.S.z;
+    }
+}
+
+/* boxes: lo(3) hi(3); rays: origin(3) dir(3) amin amax (8 floats) */
+void wpt_oracle_aabb(int n, const float* boxes, const float* rays, int32_t* out)
+{
+    for (int i = 0; i < n; i++) {
+        Ray r { v3(rays + 8 * i), v3(rays + 8 * i + 3), 0.0f, v4(1.0f) };
+        RayHelper h(r);
+        out[i] = aabbMayHit(boxes + 6 * i, boxes + 6 * i + 3, r, rays[8 * i + 6], rays[8 * i + 7], h.invDirection) ? 1 : 0;
+    }
+}
+
+/* fresnelUnpolarized(cosI, cosT, n1, n2) and fresnelSchlick(vec4 r0 = a, cos) -> 5 floats */
+void wpt_oracle_fresnel(int n, const float* in4, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        const float* p = in4 + 4 * i;
+        out[5 * i] = fresnelUnpolarized(p[0], p[1], p[2], p[3]);
+        V4 s = fresnelSchlick(V4 { p[0], p[1], p[2], p[3] }, p[1]);
+        out[5 * i + 1] = s.x; out[5 * i + 2] = s.y; out[5 * i + 3] = s.z; out[5 * i + 4] = s.w;
+    }
+}
+
+/* reflect(i, n), refract(i, n, eta): in 7 floats, out 6 */
+void wpt_oracle_reflect_refract(int n, const float* in7, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        const float* p = in7 + 7 * i;
+        V3 a = reflect(v3(p), v3(p + 3));
+        V3 b = refract(v3(p), v3(p + 3), p[6]);
+        float* o = out + 6 * i;
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = b.x; o[4] = b.y; o[5] = b.z;
+    }
+}
+
+/* Camera::getRay for n (p, q) pairs; out origin(3) direction(3); Prng(pixel 0) for DOF */
+void wpt_oracle_camera_rays(const wpt_camera* cam, int n, const float* pq, float* out)
+{
+    Prng prng(0);
+    for (int i = 0; i < n; i++) {
+        Ray r = cameraGetRay(*cam, pq[2 * i], pq[2 * i + 1], prng);
+        float* o = out + 6 * i;
+        o[0] = r.origin.x; o[1] = r.origin.y; o[2] = r.origin.z;
+        o[3] = r.direction.x; o[4] = r.direction.y; o[5] = r.direction.z;
+    }
+}
+
+/* BVH::hit against the scene for n rays (origin, dir, amin, amax = 8 floats).
+ * out per ray: haveHit, prim, a, position(3), normal(3), tangent(3), texcoords(2), backside = 15 floats */
+void wpt_oracle_bvh_hits(const wpt_scene_desc* scene, int n, const float* rays, float* out, wpt_counters* counters)
+{
+    wpt_params pr;
+    memset(&pr, 0, sizeof(pr));
+    Ctx c;
+    c.sc = scene;
+    c.pr = &pr;
+    memset(&c.cnt, 0, sizeof(c.cnt));
+    for (int i = 0; i < n; i++) {
+        Ray r { v3(rays + 8 * i), v3(rays + 8 * i + 3), 0.0f, v4(1.0f) };
+        HitRecord hr = bvhHit(c, r, RayHelper(r), rays[8 * i + 6], rays[8 * i + 7]);
+        float* o = out + 15 * i;
+        memset(o, 0, 15 * sizeof(float));
+        o[0] = hr.haveHit ? 1.0f : 0.0f;
+        if (hr.haveHit) {
+            o[1] = float(hr.prim);
+            o[2] = hr.a;
+            o[3] = hr.position.x; o[4] = hr.position.y; o[5] = hr.position.z;
+            o[6] = hr.normal.x; o[7] = hr.normal.y; o[8] = hr.normal.z;
+            o[9] = hr.tangent.x; o[10] = hr.tangent.y; o[11] = hr.tangent.z;
+            o[12] = hr.texcoords.x; o[13] = hr.texcoords.y;
+            o[14] = hr.backside ? 1.0f : 0.0f;
+        }
+    }
+    if (counters)
+        *counters = c.cnt;
+}
+
+/* BVH::hit over caller-given nodes whose leaves are "probe hitables": leaf `prim` reports a
+ * hit at distance leaf_a[prim] iff that lies in [amin, amax] (oracle/ref_probe.cpp ProbeHitable).
+ * Writes the leaf visiting order (up to max_log entries) and the final hit. */
+void wpt_oracle_bvh_walk(const wpt_bvh_node* nodes, const float* ray8, const float* leaf_a,
+        int64_t* log, int64_t max_log, int64_t* log_len, int64_t* final_prim, float* final_a)
+{
+    wpt_counters cnt;
+    memset(&cnt, 0, sizeof(cnt));
+    Ray r { v3(ray8), v3(ray8 + 3), 0.0f, v4(1.0f) };
+    int64_t n = 0;
+    HitRecord hr = bvhTraverse(nodes, cnt, r, RayHelper(r), ray8[6], ray8[7], [&](uint32_t prim, float lo, float hi) {
+        if (n < max_log)
+            log[n] = prim;
+        n++;
+        HitRecord h;
+        float a = leaf_a[prim];
+        if (a >= lo && a <= hi) {
+            h.haveHit = true;
+            h.a = a;
+            h.prim = prim;
+        }
+        return h;
+    });
+    *log_len = n;
+    *final_prim = hr.haveHit ? int64_t(hr.prim) : -1;
+    *final_a = hr.haveHit ? hr.a : 0.0f;
+}
+
+/* math back end probe: op 0 sin, 1 cos, 2 exp, 3 pow(a,b), 4 asin, 5 atan2(a,b) */
+void wpt_oracle_math(int op, int n, const float* a, const float* b, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        switch (op) {
+        case 0: out[i] = m_sin(a[i]); break;
+        case 1: out[i] = m_cos(a[i]); break;
+        case 2: out[i] = m_exp(a[i]); break;
+        case 3: out[i] = m_pow(a[i], b[i]); break;
+        case 4: out[i] = m_asin(a[i]); break;
+        default: out[i] = m_atan2(a[i], b[i]); break;
+        }
+    }
+}
+
+const char* wpt_oracle_backend(void)
+{
+#ifdef WPT_ORACLE_LIBM
+    return "libm";
+#else
+    return "portable";
+#endif
+}
+
+} /* extern "C" */

@@ -1,0 +1,96 @@
+"""Host side of the framework for Python callers (tests, bench): scene construction and
+flattening through libwurblpt_host.so, which is compiled from the C++ API under
+include/wurblpt/ (the mirror of the reference's Scene / Mesh / Material / Camera classes).
+CPU only; no HIP dependency."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libwurblpt_host.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        L = C.CDLL(path)
+        L.wpt_host_cornell.restype = C.c_void_p
+        L.wpt_host_cornell.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint]
+        L.wpt_host_random_triangles.restype = C.c_void_p
+        L.wpt_host_random_triangles.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint, C.c_float]
+        L.wpt_host_scene_desc.restype = C.POINTER(_abi.SceneDesc)
+        L.wpt_host_scene_desc.argtypes = [C.c_void_p]
+        L.wpt_host_scene_camera.restype = C.POINTER(_abi.Camera)
+        L.wpt_host_scene_camera.argtypes = [C.c_void_p]
+        L.wpt_host_scene_bvh_levels.restype = C.c_uint
+        L.wpt_host_scene_bvh_levels.argtypes = [C.c_void_p]
+        L.wpt_host_scene_free.argtypes = [C.c_void_p]
+        L.wpt_host_default_params.argtypes = [C.POINTER(_abi.Params)]
+        L.wpt_host_bvh_build.restype = C.c_uint
+        L.wpt_host_bvh_build.argtypes = [C.c_uint, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint)]
+        _LIB = L
+    return _LIB
+
+
+def default_params():
+    """Parameters() of the reference (wurblpt.hpp:89-95) plus the default SensorRGB gates."""
+    p = _abi.Params()
+    lib().wpt_host_default_params(C.byref(p))
+    return p
+
+
+class HostScene:
+    """A built and flattened scene with its camera; owns the host buffers."""
+
+    def __init__(self, handle, width, height, name):
+        if not handle:
+            raise RuntimeError("scene construction failed: %s" % name)
+        self._handle = handle
+        self.width, self.height, self.name = width, height, name
+        self.desc = lib().wpt_host_scene_desc(handle)
+        self.camera = lib().wpt_host_scene_camera(handle)
+        self.bvh_levels = lib().wpt_host_scene_bvh_levels(handle)
+
+    def __del__(self):
+        if getattr(self, "_handle", None):
+            lib().wpt_host_scene_free(self._handle)
+            self._handle = None
+
+    @property
+    def d(self):
+        return self.desc.contents
+
+    def nodes_array(self):
+        n = self.d.node_count
+        return np.ctypeslib.as_array(C.cast(self.d.nodes, C.POINTER(C.c_uint32)), shape=(n, 8)).copy()
+
+
+def cornell(width, height, tall_box_material=0, short_object_material=0):
+    """Cornell box of wurblpt-cornellbox.cpp: tall box 0 = white / 1 = GGX metal,
+    short box 0 = white / 2 = glass."""
+    h = lib().wpt_host_cornell(tall_box_material, 0, short_object_material, width, height)
+    return HostScene(h, width, height, "cornell(tall=%d,short=%d)" % (tall_box_material, short_object_material))
+
+
+def random_triangles(n, seed, width, height, with_texcoords=True, aperture=0.0):
+    h = lib().wpt_host_random_triangles(n, seed, 1 if with_texcoords else 0, width, height, aperture)
+    return HostScene(h, width, height, "random_triangles(%d,%d)" % (n, seed))
+
+
+def bvh_build(boxes):
+    """boxes: float32 [n, 6] (lo, hi) -> (uint32 [nodes, 8] raw node words, levels)."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    n = boxes.shape[0]
+    out = np.zeros((max(2 * n - 1, 1), 8), dtype=np.uint32)
+    levels = C.c_uint(0)
+    cnt = lib().wpt_host_bvh_build(n, boxes.ctypes.data, out.ctypes.data, C.byref(levels))
+    return out[:cnt], levels.value
