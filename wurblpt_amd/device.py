@@ -1,0 +1,129 @@
+"""Python binding of the C ABI in include/wurblpt_hip.h (libwurblpt_hip.so).
+
+torch supplies device memory (frame buffers are torch tensors whose data_ptr() crosses the
+C ABI) and streams; nothing here computes.  There is no CPU fallback: loading fails loudly
+when the HIP library is missing, and rendering fails when no GPU is present."""
+import ctypes as C
+import os
+
+from . import _abi
+
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libwurblpt_hip.so")
+
+
+EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_scene_upload", "wpt_scene_free",
+           "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_kernel_name",
+           "wpt_last_error"]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing: the HIP extension must be built (python -c 'import __graft_entry__ as g; g.build()'); "
+                               "there is no CPU fallback" % path)
+        L = C.CDLL(path)
+        L.wpt_device_count.restype = C.c_int
+        L.wpt_select_device.argtypes = [C.c_int]
+        L.wpt_scene_upload.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(C.c_void_p)]
+        L.wpt_scene_free.argtypes = [C.c_void_p]
+        L.wpt_render_block_device.argtypes = [C.c_void_p, C.POINTER(_abi.Camera), C.POINTER(_abi.Params),
+                                              C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wpt_render_block.argtypes = [C.c_void_p, C.POINTER(_abi.Camera), C.POINTER(_abi.Params),
+                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.wpt_set_launch_config.argtypes = [C.c_uint32, C.c_uint32]
+        L.wpt_kernel_name.restype = C.c_char_p
+        L.wpt_last_error.restype = C.c_char_p
+        L.wpt_selftest_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wpt_scene_get_envmap_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _check(status):
+    if status != _abi.WPT_OK:
+        raise RuntimeError("wurblpt_hip: %s (status %d)" % (lib().wpt_last_error().decode(), status))
+
+
+def device_count():
+    return lib().wpt_device_count()
+
+
+class DeviceScene:
+    """A flattened scene resident in HBM on the current device."""
+
+    def __init__(self, host_scene):
+        self._handle = C.c_void_p()
+        _check(lib().wpt_scene_upload(host_scene.desc, C.byref(self._handle)))
+        self.host = host_scene
+
+    def close(self):
+        if self._handle:
+            lib().wpt_scene_free(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_block_into(self, frame, samples_sqrt, block=None, params=None, counters=None, stream=None,
+                          width=None, height=None):
+        """Asynchronously renders pixels [start, start+size) into `frame`, a CUDA float32 tensor
+        [h, w, 3] (full frame).  `counters`: optional CUDA int64 tensor [6] that is added to."""
+        from . import host
+        w = width or self.host.width
+        h = height or self.host.height
+        assert frame.is_cuda and frame.is_contiguous() and frame.numel() == w * h * 3
+        p = params if params is not None else host.default_params()
+        start, size = block if block is not None else (0, w * h)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        cptr = C.c_void_p(counters.data_ptr()) if counters is not None else None
+        _check(lib().wpt_render_block_device(self._handle, self.host.camera, C.byref(p), w, h, samples_sqrt,
+                                              start, size, C.c_void_p(frame.data_ptr()), cptr, sptr))
+
+    def render(self, samples_sqrt, block=None, params=None, with_counters=False, width=None, height=None):
+        """Synchronous convenience: returns (frame as numpy [h, w, 3], counters dict or None)."""
+        import torch
+        w = width or self.host.width
+        h = height or self.host.height
+        frame = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+        counters = torch.zeros(6, dtype=torch.int64, device="cuda") if with_counters else None
+        stream = torch.cuda.current_stream()
+        self.render_block_into(frame, samples_sqrt, block, params, counters, stream, w, h)
+        torch.cuda.synchronize()
+        cnt = None
+        if with_counters:
+            names = ("samples", "rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")
+            cnt = dict(zip(names, [int(x) for x in counters.cpu().tolist()]))
+        return frame.cpu().numpy(), cnt
+
+    def render_block_host(self, samples_sqrt, block, params=None, width=None, height=None):
+        """wpt_render_block: MPICoordinator::submitBlock semantics, host buffer of size*3 floats."""
+        import numpy as np
+        from . import host
+        w = width or self.host.width
+        h = height or self.host.height
+        p = params if params is not None else host.default_params()
+        start, size = block
+        out = np.zeros((size, 3), dtype=np.float32)
+        _check(lib().wpt_render_block(self._handle, self.host.camera, C.byref(p), w, h, samples_sqrt, start, size,
+                                       C.c_void_p(out.ctypes.data)))
+        return out
+
+
+def selftest_math(op, a, b=None):
+    """Evaluates one arithmetic primitive of the kernel on the GPU (see wpt_selftest_kernel)."""
+    import torch
+    ta = torch.as_tensor(a, dtype=torch.float32, device="cuda").contiguous()
+    tb = torch.as_tensor(b if b is not None else a, dtype=torch.float32, device="cuda").contiguous()
+    out = torch.empty_like(ta)
+    _check(lib().wpt_selftest_math(op, ta.numel(), C.c_void_p(ta.data_ptr()), C.c_void_p(tb.data_ptr()), C.c_void_p(out.data_ptr())))
+    return out.cpu().numpy()
