@@ -1,0 +1,262 @@
+#!/usr/bin/env python
+"""bench.py -- Msamples/s of the path-tracing hot path on N MI355X of one node.
+
+One "step" = one render of the whole frame of the workload (BASELINE.json configs[1] by
+default: Cornell box 1024x1024, 1024 spp, GGX tall box + glass short box) with the scene
+already resident in HBM.  N = 1: one launch covers the frame (the reference's single-process
+path hands out the whole frame as one block, mpi.hpp:241-254).  N > 1: one process per GPU
+(torch.distributed over RCCL); ranks pull pixel blocks from a shared counter in the c10d store
+(MPICoordinator::getBlock semantics, mpi.hpp:125-134), render them into a zero-initialised
+full frame on their GPU and the frames are summed onto rank 0 with one RCCL reduce
+(blocks are disjoint, so the sum is exact).  The frame is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline      HBM roofline of the path-tracing kernel from ALGORITHMIC bytes
+  cpu_baseline  the CPU restatement (oracle/, "port") timed on this box's host cores
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (builder kwargs, width, height, samples_sqrt)
+    "cornell_1024x1024_1024spp_ggx_glass": dict(kind="cornell", tall=1, short=2, width=1024, height=1024, samples_sqrt=32),
+    "cornell_256x256_64spp_lambertian": dict(kind="cornell", tall=0, short=0, width=256, height=256, samples_sqrt=8),
+}
+
+
+def build_scene(w):
+    from wurblpt_amd import host
+    if w["kind"] == "cornell":
+        return host.cornell(w["width"], w["height"], w["tall"], w["short"])
+    raise ValueError(w["kind"])
+
+
+def bytes_per_sample(counters, scene, spp):
+    """nodes*32 B + (leaf tests + hot-spot pdf tests) * (32 B + 3 vertices * 4 B *
+    vertexFloats) + 12 B / spp, with the reference's record sizes."""
+    import numpy as np
+    d = scene.d
+    flags = np.array([d.tri_geom[i].flags for i in range(min(d.tri_count, 100000))], dtype=np.uint32)
+    vf = np.where((flags & 1) != 0, np.where((flags & 2) != 0, 11, 8), 6)
+    tri_bytes = 32.0 + 12.0 * float(vf.mean())
+    n = float(counters["samples"])
+    return (counters["node_visits"] / n) * 32.0 + ((counters["leaf_tests"] + counters["pdf_tests"]) / n) * tri_bytes + 12.0 / spp, tri_bytes
+
+
+def host_cores():
+    """threads the CPU baseline may use: the affinity mask, capped by the cgroup CPU quota"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return cores
+
+
+def cpu_baseline(scene, w, target_seconds):
+    """The CPU restatement on the host cores, on a bounded block of the same workload: a short
+    probe sizes the block so that the timed run takes about target_seconds."""
+    from tests import oracle_loader
+    orc = oracle_loader.load("portable")
+    width, height = w["width"], w["height"]
+    cores = host_cores()
+
+    def run(pixels):
+        pixels = max(width, min(pixels - pixels % width, width * height))
+        start = max(0, (width * height - pixels) // 2)
+        start -= start % width
+        t0 = time.time()
+        _, cnt = orc.render(scene, w["samples_sqrt"], block=(start, pixels), threads=cores)
+        return cnt["samples"], time.time() - t0, start, pixels
+
+    n, dt, _, _ = run(4 * width)
+    rate = n / max(dt, 1e-3)
+    want = int(rate * target_seconds / (w["samples_sqrt"] ** 2))
+    n, dt, start, pixels = run(max(4 * width, want))
+    return {
+        "value": n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": "%d pixels (rows %d-%d) x %d spp of the same frame, %.1f s" % (
+            pixels, start // width, (start + pixels - 1) // width, w["samples_sqrt"] ** 2, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell_1024x1024_1024spp_ggx_glass", choices=sorted(WORKLOADS))
+    ap.add_argument("--samples-sqrt", type=int, default=0, help="override spp (debug only; changes the workload name)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--streams", type=int, default=4, help="concurrent block launches per GPU when N > 1")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from wurblpt_amd import device, host
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the path tracer has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w = dict(WORKLOADS[args.workload])
+    name = args.workload
+    if args.samples_sqrt:
+        w["samples_sqrt"] = args.samples_sqrt
+        name += "_override%dspp" % (args.samples_sqrt ** 2)
+    width, height, ssqrt = w["width"], w["height"], w["samples_sqrt"]
+    spp = ssqrt * ssqrt
+    pixels = width * height
+    scene = build_scene(w)
+    dscene = device.DeviceScene(scene)
+    params = host.default_params()
+    frame = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
+    main_stream = torch.cuda.current_stream()
+
+    # ---- counted pass (untimed): work per sample for the roofline's algorithmic bytes ----
+    count_sqrt = min(ssqrt, 4)
+    counters = torch.zeros(6, dtype=torch.int64, device="cuda")
+    dscene.render_block_into(frame, count_sqrt, None, params, counters, main_stream)
+    torch.cuda.synchronize()
+    cnt = dict(zip(("samples", "rays", "node_visits", "leaf_tests", "pdf_tests", "scatters"), [int(x) for x in counters.cpu().tolist()]))
+    bps, tri_bytes = bytes_per_sample(cnt, scene, spp)
+
+    # ---- the step ----
+    kernel_ms = []  # (milliseconds, samples) per launch on this rank, timed steps only
+    store = dist.distributed_c10d._get_default_store() if world > 1 else None
+    streams = [torch.cuda.Stream() for _ in range(args.streams)] if world > 1 else []
+    block_size = 0
+    if world > 1:
+        # about two blocks per stream and GPU, whole rows, never less than the reference's 4096
+        block_size = max(4096, -(-pixels // (world * args.streams * 2)))
+        block_size = -(-block_size // width) * width
+    n_blocks = -(-pixels // block_size) if world > 1 else 1
+
+    def step(index, timed):
+        if world == 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main_stream)
+            dscene.render_block_into(frame, ssqrt, None, params, None, main_stream)
+            e1.record(main_stream)
+            if timed:
+                kernel_ms.append((e0, e1, pixels * spp))
+            return
+        frame.zero_()
+        torch.cuda.synchronize()
+        key = "wpt_block_counter_%d" % index
+        errors = []
+
+        def worker(stream):
+            try:
+                torch.cuda.set_device(local_rank)
+                while True:
+                    b = store.add(key, 1) - 1  # MPICoordinator::getBlock
+                    if b >= n_blocks:
+                        break
+                    start = b * block_size
+                    size = min(block_size, pixels - start)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    dscene.render_block_into(frame, ssqrt, (start, size), params, None, stream)
+                    e1.record(stream)
+                    stream.synchronize()  # submitBlock: the block is in this rank's frame
+                    if timed:
+                        kernel_ms.append((e0, e1, size * spp))
+            except Exception as exc:  # surface worker failures on the main thread
+                errors.append(exc)
+
+        threads = [threading.Thread(target=worker, args=(s,)) for s in streams]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        torch.cuda.synchronize()
+        dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)  # final framebuffer reduce over xGMI
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ok = bool(torch.isfinite(frame).all().item()) if rank == 0 else True
+    launches = [(a.elapsed_time(b), s) for a, b, s in kernel_ms]
+    if rank == 0:
+        total_samples = float(pixels) * spp * args.steps
+        avg_ms = sum(m for m, _ in launches) / max(1, len(launches))
+        avg_samples = sum(s for _, s in launches) / max(1, len(launches))
+        achieved = bps * avg_samples / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == name and world == 1:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/s", "value": total_samples / elapsed / 1e6, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "width": width, "height": height, "spp": spp,
+                       "triangles": int(scene.d.tri_count), "bvh_nodes": int(scene.d.node_count),
+                       "parallelism": "1 launch" if world == 1 else "pixel blocks of %d over %d GPUs (%d streams each) + RCCL reduce" % (block_size, world, args.streams)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": device.lib().wpt_kernel_name().decode(), "avg_launch_ms": avg_ms,
+                         "launches": len(launches), "bytes_per_sample": bps,
+                         "per_sample": {k: cnt[k] / float(cnt["samples"]) for k in ("rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")},
+                         "counted_on": "%dx%d x %d spp" % (width, height, count_sqrt ** 2)},
+            "frame_finite": ok,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, w, args.cpu_seconds)
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
