@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--streams", type=int, default=4, help="concurrent block launches per GPU when N > 1")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant / scheduler tuning word for wpt_set_launch_config (experiments)")
     args = ap.parse_args()
 
     import numpy as np
@@ -131,6 +132,8 @@ def main():
     spp = ssqrt * ssqrt
     pixels = width * height
     scene = build_scene(w)
+    if args.variant:
+        device.lib().wpt_set_launch_config(0, args.variant)
     dscene = device.DeviceScene(scene)
     params = host.default_params()
     frame = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")

@@ -1,0 +1,23 @@
+"""Prints the wave scheduler's statistics for the Cornell GGX+glass frame (GPU box)."""
+import ctypes as C, sys
+import torch
+from wurblpt_amd import device, host
+var = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+if var:
+    device.lib().wpt_set_launch_config(0, var)
+sc = host.cornell(1024, 1024, 1, 2)
+ds = device.DeviceScene(sc)
+stats = torch.zeros(11, dtype=torch.int64, device="cuda")
+device.lib().wpt_set_scheduler_stats.argtypes = [C.c_void_p]
+device.lib().wpt_set_scheduler_stats(C.c_void_p(stats.data_ptr()))
+frame, cnt = ds.render(4, with_counters=True)
+s = [int(x) for x in stats.cpu().tolist()]
+n = cnt["samples"]
+print("per sample:", {k: round(v / n, 3) for k, v in cnt.items()})
+names = ["NODE", "LEAF", "SHADE", "NEEEND", "NEW"]
+print("NODE: rounds/sample-lane %.3f iters/round %.2f avg active lanes %.1f  (lane-steps %.1f/sample)" % (s[0] * 64 / n, s[1] / max(1, s[0]), s[2] / max(1, s[1]), s[2] / n))
+for i, nm in enumerate(names[1:]):
+    r, l = s[3 + 2 * i], s[4 + 2 * i]
+    print("%s: rounds per 64 samples %.3f avg lanes %.1f (lane-execs %.3f/sample)" % (nm, r * 64 / n, l / max(1, r), l / n))
+tot_rounds = s[0] + s[3] + s[5] + s[7] + s[9]
+print("scheduler rounds per 64 samples: %.2f" % (tot_rounds * 64 / n))

@@ -1,18 +1,7 @@
 /*
- * wpt_capi.hip -- C ABI of include/wurblpt_hip.h over the gfx950 path-tracing kernel (wpt_pathtrace.inc.h).
- *
- * Kernel shape (MI355X first):
- *  - one lane = one pixel, because the reference consumes ONE Prng per pixel serially over
- *    all of that pixel's samples (wurblpt.hpp:342-366): the only parallel axis is pixels.
- *  - a lane never idles between samples or path segments: the loop below is a per-lane state
- *    machine (NEW -> PATH ray -> optional NEE ray -> advance) with ONE traversal site, so
- *    the 64 lanes of a wave always meet again at the BVH traversal no matter how long each
- *    lane's path is.  Path rays and next-event rays share that traversal code.
- *  - BVH nodes are fetched as two dwordx4 per lane, triangles as three; the traversal stack
- *    is an LDS column per lane (conflict-free: one dword per lane per level), spilling to
- *    scratch only below level 32.
- *  - shading data (96 B per triangle) is read once per ray, after traversal.
- *  - no MFMA anywhere: there is no dense contraction on this path.
+ * wpt_capi.hip -- the C ABI of include/wurblpt_hip.h: scene upload (validation, conversion of
+ * the BVH to the device's stackless node form, environment importance tables), kernel
+ * selection and launch.  The kernel itself is in wpt_pathtrace.inc.h.
  */
 #include <hip/hip_runtime.h>
 
@@ -99,6 +88,9 @@ namespace {
 
 uint32_t g_threadsPerGroup = WG;
 uint32_t g_variant = 0;
+uint32_t g_leaveEighths = 2;
+uint32_t g_heavyMin = 24;
+unsigned long long* g_schedStats = nullptr;
 
 template<typename T> wpt_status uploadArray(wpt_scene* s, const T* src, size_t count, const T** dst)
 {
@@ -156,7 +148,7 @@ wpt_status validate(const wpt_scene_desc* d)
             if (n.link >= d->node_count || n.link <= i || i + 1 >= d->node_count)
                 return fail(WPT_ERR_INVALID_ARGUMENT, "BVH inner node links outside the node array");
         } else if (n.kind == WPT_NODE_TRIANGLE) {
-            if (n.link >= d->tri_count)
+            if (n.link >= d->tri_count || n.link >= NODE_EMPTY)
                 return fail(WPT_ERR_INVALID_ARGUMENT, "BVH leaf references a triangle outside the array");
         } else if (n.kind != WPT_NODE_EMPTY) {
             return fail(WPT_ERR_UNSUPPORTED, "BVH node kind is not known to the kernel");
@@ -252,7 +244,32 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
             return st;            \
         }                         \
     } while (0)
-    UP(uploadArray(s, reinterpret_cast<const float4*>(desc->nodes), size_t(desc->node_count) * 2, &nodes));
+    {
+        /* Device node form: the reference pops a stack to find the next node after a subtree
+         * (bvh.hpp:296,305); in its depth-first array that node is the first one behind the
+         * subtree, so it is stored per node ("skip") and the kernel needs no stack.
+         * skip(root) = node_count; for an inner node i: skip(i + 1) = link(i), skip(link(i)) = skip(i). */
+        const uint32_t n = desc->node_count;
+        std::vector<uint32_t> skip(n, n);
+        for (uint32_t i = 0; i < n; i++) {
+            const wpt_bvh_node& nd = desc->nodes[i];
+            if (nd.kind == WPT_NODE_INNER) {
+                skip[i + 1] = nd.link;
+                skip[nd.link] = skip[i];
+            }
+        }
+        std::vector<float4> dev(size_t(n) * 2);
+        for (uint32_t i = 0; i < n; i++) {
+            const wpt_bvh_node& nd = desc->nodes[i];
+            const uint32_t prim = nd.kind == WPT_NODE_INNER ? NODE_INNER : nd.kind == WPT_NODE_TRIANGLE ? nd.link : NODE_EMPTY;
+            float sk, pr;
+            memcpy(&sk, &skip[i], 4);
+            memcpy(&pr, &prim, 4);
+            dev[2 * size_t(i)] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0]);
+            dev[2 * size_t(i) + 1] = make_float4(nd.hi[1], nd.hi[2], sk, pr);
+        }
+        UP(uploadArray(s, dev.data(), dev.size(), &nodes));
+    }
     UP(uploadArray(s, reinterpret_cast<const float4*>(desc->tri_geom), size_t(desc->tri_count) * 3, &geom));
     UP(uploadArray(s, reinterpret_cast<const float4*>(desc->tri_attr), size_t(desc->tri_count) * 6, &attr));
     s->view.nodes = nodes;
@@ -263,6 +280,8 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     UP(uploadArray(s, desc->textures, desc->texture_count, &s->view.textures));
     UP(uploadArray(s, desc->texels, desc->texel_bytes, &s->view.texels));
     UP(uploadArray(s, desc->hotspots, desc->hotspot_count, &s->view.hotspots));
+    s->view.nodeCount = desc->node_count;
+    s->view.triCount = desc->tri_count;
     s->view.hotspotCount = desc->hotspot_count;
     s->view.envType = desc->envmap.type;
     s->view.envCompat = desc->envmap.compat;
@@ -364,13 +383,21 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     args.blockSize = block_size;
     args.frame = frame_device;
     args.counters = counters_device;
+    args.schedStats = g_schedStats;
+    /* a wave covers an 8x8 pixel tile when the block consists of whole groups of 8 rows */
+    args.leaveEighths = g_leaveEighths;
+    args.heavyMin = g_heavyMin;
+    args.tiled = (width % 8 == 0 && block_start % width == 0 && block_size % (8 * width) == 0) ? 1u : 0u;
     uint32_t need = scene->features | (camera->lens_radius > 0.0f ? FEAT_LENS : 0u);
     dim3 grid((block_size + WG - 1) / WG);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const bool count = counters_device != nullptr;
+    const size_t ldsBytes = size_t(scene->nodeCount) * 32 + size_t(scene->triCount) * 48;
     if ((need & ~FEAT_BASIC) == 0 && g_variant != 2) {
         if (count)
             launchBasicCount(args, grid, stream);
+        else if (ldsBytes <= LDS_SCENE_MAX_BYTES && g_variant != 1)
+            launchBasicLds(args, grid, ldsBytes, stream);
         else
             launchBasic(args, grid, stream);
     } else {
@@ -411,7 +438,19 @@ wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant)
     if (threads_per_group != 0 && threads_per_group != WG)
         return fail(WPT_ERR_UNSUPPORTED, "this build uses 256 threads per workgroup");
     g_threadsPerGroup = WG;
-    g_variant = variant;
+    g_variant = variant & 0xffu;
+    if ((variant >> 8) & 0xffu)
+        g_leaveEighths = ((variant >> 8) & 0xffu) - 1; /* byte 1: leave threshold in eighths, plus one */
+    if ((variant >> 16) & 0xffu)
+        g_heavyMin = ((variant >> 16) & 0xffu) - 1;     /* byte 2: lanes a long block needs, plus one */
+    return WPT_OK;
+}
+
+/* profiling hook: device buffer of 11 uint64 that counted launches add their wave-scheduler
+ * statistics to (rounds, loop iterations and lane counts per state); NULL switches it off */
+wpt_status wpt_set_scheduler_stats(unsigned long long* stats_device)
+{
+    g_schedStats = stats_device;
     return WPT_OK;
 }
 

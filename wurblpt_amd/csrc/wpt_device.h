@@ -368,7 +368,7 @@ struct Hit {
 };
 
 struct SceneView {
-    const float4* nodes;     /* 2 x float4 per node */
+    const float4* nodes;     /* 2 x float4 per node: lo.xyz hi.x | hi.yz skip prim (device form) */
     const float4* triGeom;   /* 3 x float4 per triangle */
     const float4* triAttr;   /* 6 x float4 per triangle */
     const wpt_instance* instances;
@@ -379,6 +379,7 @@ struct SceneView {
     const float* envM;
     const int32_t* envMs;
     const float* envMcs;
+    uint32_t nodeCount, triCount;
     uint32_t hotspotCount;
     uint32_t envType, envCompat;
     int32_t envTex, envN;

@@ -1,11 +1,11 @@
-/* wpt_k_basic.hip -- instantiates wpt_pathtrace<FEAT_BASIC, false> (one variant per file: parallel builds) */
+/* wpt_k_basic.hip -- instantiates wpt_pathtrace<FEAT_BASIC, false, false> (one variant per file: parallel builds) */
 #include "wpt_pathtrace.inc.h"
 
 namespace wptk {
 
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false>), grid, dim3(WG), 0, stream, args);
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false, false, 3>), grid, dim3(WG), 0, stream, args);
 }
 
 }

@@ -1,11 +1,11 @@
-/* wpt_k_basic_count.hip -- instantiates wpt_pathtrace<FEAT_BASIC, true> (one variant per file: parallel builds) */
+/* wpt_k_basic_count.hip -- instantiates wpt_pathtrace<FEAT_BASIC, true, false> (one variant per file: parallel builds) */
 #include "wpt_pathtrace.inc.h"
 
 namespace wptk {
 
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, true>), grid, dim3(WG), 0, stream, args);
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, true, false, 2>), grid, dim3(WG), 0, stream, args);
 }
 
 }

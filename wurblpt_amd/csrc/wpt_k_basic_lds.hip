@@ -1,0 +1,11 @@
+/* wpt_k_basic_lds.hip -- instantiates wpt_pathtrace<FEAT_BASIC, false, true> (one variant per file: parallel builds) */
+#include "wpt_pathtrace.inc.h"
+
+namespace wptk {
+
+void launchBasicLds(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false, true, 3>), grid, dim3(WG), ldsBytes, stream, args);
+}
+
+}

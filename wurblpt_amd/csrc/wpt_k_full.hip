@@ -1,11 +1,11 @@
-/* wpt_k_full.hip -- instantiates wpt_pathtrace<FEAT_ALL, false> (one variant per file: parallel builds) */
+/* wpt_k_full.hip -- instantiates wpt_pathtrace<FEAT_ALL, false, false> (one variant per file: parallel builds) */
 #include "wpt_pathtrace.inc.h"
 
 namespace wptk {
 
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL, false>), grid, dim3(WG), 0, stream, args);
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL, false, false, 2>), grid, dim3(WG), 0, stream, args);
 }
 
 }

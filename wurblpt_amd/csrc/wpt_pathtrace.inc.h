@@ -1,7 +1,33 @@
 /*
- * wpt_pathtrace.inc.h -- the path-tracing kernel template (see wpt_capi.hip for the design
- * notes).  Included by one translation unit per instantiation (wpt_k_*.hip) so that the
- * variants compile in parallel.
+ * wpt_pathtrace.inc.h -- the gfx950 path-tracing kernel (template; one translation unit per
+ * instantiation, wpt_k_*.hip, so that the variants compile in parallel).
+ *
+ * Shape of the kernel, MI355X first:
+ *
+ *  - One lane owns one pixel and walks that pixel's whole sample sequence, because the
+ *    reference seeds ONE Prng per pixel and consumes it serially over all samples
+ *    (wurblpt.hpp:342-366).  Pixels are the only parallel axis; a wave is an 8x8 pixel tile.
+ *
+ *  - Every lane is a small state machine (NEW ray -> NODE steps <-> LEAF tests -> SHADE or
+ *    NEE-END -> ...).  The 64 lanes of a wave are in different states at any time, so the wave
+ *    runs its own scheduler: each round it counts the lanes per state with ballots, runs the
+ *    code of the most populated state for exactly those lanes, and leaves the hot NODE loop
+ *    as soon as too few lanes remain in it.  Lanes in other states simply wait for their turn.
+ *    Each lane still executes its own operations in the reference's order, so results do not
+ *    change; only SIMD utilisation does (v0 without the scheduler: 18 % active lanes).
+ *
+ *  - BVH traversal is stackless.  The reference walks its depth-first node array with a stack,
+ *    left child first (bvh.hpp:277-311); in that layout the node a pop returns to is always
+ *    the first node after the current subtree, so each device node carries that index
+ *    ("skip") and the walk is: box hit & inner -> next node; otherwise -> skip.  Same visiting
+ *    order, no stack, no LDS or scratch traffic for it.
+ *
+ *  - Small scenes (nodes + triangle positions up to 48 KiB, e.g. the Cornell box: 4 KiB) are
+ *    copied into LDS once per workgroup and traversed from there; larger scenes are fetched
+ *    from HBM/L2 as two dwordx4 per node and three per triangle.
+ *
+ *  - Shading data (96 B per triangle) is read once per ray, after traversal.
+ *  - No MFMA: there is no dense contraction anywhere on this path.
  */
 #ifndef WPT_PATHTRACE_INC_H
 #define WPT_PATHTRACE_INC_H
@@ -15,10 +41,11 @@ namespace wptk {
 
 using namespace wptd;
 
-constexpr int WG = 256;            /* threads per workgroup: 4 waves, one per SIMD */
-constexpr int LDS_STACK_DEPTH = 32; /* levels kept in LDS; deeper levels spill to scratch */
-constexpr int SPILL_DEPTH = 96;     /* 32 + 96 = the reference's 128-entry stack (bvh.hpp:230) */
+constexpr int WG = 256; /* threads per workgroup: 4 waves, one per SIMD */
 constexpr uint32_t NO_HIT = 0xffffffffu;
+constexpr uint32_t NODE_INNER = 0xffffffffu; /* device node: marker in the primitive slot */
+constexpr uint32_t NODE_EMPTY = 0xfffffffeu;
+constexpr uint32_t LDS_SCENE_MAX_BYTES = 48 * 1024;
 
 struct KernelArgs {
     SceneView sv;
@@ -26,79 +53,25 @@ struct KernelArgs {
     wpt_params par;
     uint32_t width, height, samplesSqrt;
     uint32_t blockStart, blockSize;
+    uint32_t tiled; /* 1: a wave covers an 8x8 pixel tile (block is whole rows, multiple of 8) */
+    uint32_t leaveEighths; /* scheduler: leave the NODE loop when fewer than this many eighths of the entering lanes remain */
+    uint32_t heavyMin;     /* scheduler: lanes a long block needs before it runs (0: most-populated-state policy) */
     float* frame;
     wpt_counters* counters;
+    unsigned long long* schedStats; /* COUNT builds: 11 scheduler statistics, or NULL */
 };
 
 struct LaneCounters {
     uint32_t rays, nodes, leaves, pdfs, scatters;
 };
 
-/* BVH::hit (bvh.hpp:277-311): unordered depth-first walk, left child first, closest hit wins,
- * a later candidate at equal distance replaces an earlier one. */
-template<bool COUNT>
-__device__ __forceinline__ Candidate traverse(const SceneView& sv, f3 org, f3 dir, float amin, float amax,
-        uint32_t (*stack)[WG], LaneCounters& lc)
-{
-    const RayAux h = rayAux(dir);
-    Candidate best;
-    best.prim = NO_HIT;
-    best.a = 0.0f;
-    best.invDet = 0.0f;
-    best.U = best.V = best.W = best.det = 0.0f;
-    uint32_t spill[SPILL_DEPTH];
-    uint32_t node = 0;
-    int sp = 0;
-    const int tid = threadIdx.x;
-    if (COUNT)
-        lc.rays++;
-    for (;;) {
-        const float4 n0 = sv.nodes[2 * (size_t)node];
-        const float4 n1 = sv.nodes[2 * (size_t)node + 1];
-        if (COUNT)
-            lc.nodes++;
-        bool descend = false;
-        if (boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), org, h.inv, amin, amax)) {
-            const uint32_t link = __float_as_uint(n1.z);
-            const uint32_t kind = __float_as_uint(n1.w);
-            if (kind == WPT_NODE_INNER) {
-                if (sp < LDS_STACK_DEPTH)
-                    stack[sp][tid] = link;
-                else
-                    spill[sp - LDS_STACK_DEPTH] = link;
-                sp++;
-                node++;
-                descend = true;
-            } else if (kind == WPT_NODE_TRIANGLE) {
-                if (COUNT)
-                    lc.leaves++;
-                const float4 g0 = sv.triGeom[3 * (size_t)link + 0];
-                const float4 g1 = sv.triGeom[3 * (size_t)link + 1];
-                const float4 g2 = sv.triGeom[3 * (size_t)link + 2];
-                Candidate c;
-                if (triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), org, h, amin, amax, c)) {
-                    c.prim = link;
-                    best = c;
-                    amax = c.a;
-                }
-            }
-        }
-        if (!descend) {
-            if (sp == 0)
-                break;
-            sp--;
-            node = sp < LDS_STACK_DEPTH ? stack[sp][tid] : spill[sp - LDS_STACK_DEPTH];
-        }
-    }
-    return best;
-}
+/* lane states, in scheduling priority order for ties */
+enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5 };
+enum { RAY_PATH = 0, RAY_NEE_LIGHT = 1, RAY_NEE_ENV = 2 };
 
 /* HitableTriangle::pdfValue (hitable_triangle.hpp:405-423) for one hot spot */
-__device__ __forceinline__ float hotSpotPdf(const SceneView& sv, uint32_t prim, f3 org, f3 dir, const RayAux& h)
+__device__ __forceinline__ float hotSpotPdf(float4 g0, float4 g1, float4 g2, f3 org, f3 dir, const RayAux& h)
 {
-    const float4 g0 = sv.triGeom[3 * (size_t)prim + 0];
-    const float4 g1 = sv.triGeom[3 * (size_t)prim + 1];
-    const float4 g2 = sv.triGeom[3 * (size_t)prim + 2];
     const f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
     Candidate c;
     float value = 0.0f;
@@ -114,21 +87,8 @@ __device__ __forceinline__ float hotSpotPdf(const SceneView& sv, uint32_t prim, 
     return value;
 }
 
-__device__ __forceinline__ float hotSpotsMeanPdf(const SceneView& sv, f3 org, f3 dir, float invCount, LaneCounters& lc, bool count)
-{
-    const RayAux h = rayAux(dir);
-    float sum = 0.0f;
-    for (uint32_t i = 0; i < sv.hotspotCount; i++) {
-        sum += hotSpotPdf(sv, sv.hotspots[i].prim, org, dir, h);
-        if (count)
-            lc.pdfs++;
-    }
-    sum *= invCount;
-    return sum;
-}
-
 /* SensorRGB::accumulateRadiance (sensor_rgb.hpp:63-80) */
-__device__ __forceinline__ void accumulate(const wpt_params& par, f4 opl, float distanceToLight, f4 radiance, float& a0, float& a1, float& a2)
+__device__ __forceinline__ void accumulate(const wpt_params& par, f3 opl, float distanceToLight, f4 radiance, float& a0, float& a1, float& a2)
 {
     const bool dOk = distanceToLight >= par.min_dist_to_light && distanceToLight <= par.max_dist_to_light;
     if (dOk && opl.x >= par.min_path_len && opl.x <= par.max_path_len)
@@ -139,22 +99,54 @@ __device__ __forceinline__ void accumulate(const wpt_params& par, f4 opl, float 
         a2 += radiance.z;
 }
 
-enum { ST_NEW = 0, ST_PATH = 1, ST_NEE_LIGHT = 2, ST_NEE_ENV = 3 };
-
-template<uint32_t F, bool COUNT>
-__global__ __launch_bounds__(WG) void wpt_pathtrace(const KernelArgs args)
+template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC>
+__global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 {
-    __shared__ uint32_t stack[LDS_STACK_DEPTH][WG];
+    extern __shared__ float4 ldsScene[];
 
     const SceneView& sv = args.sv;
     const wpt_params& par = args.par;
+    const uint32_t nodeCount = sv.nodeCount;
+
+    if (LDSSCENE) {
+        /* nodes (2 x float4 each) followed by the triangle positions (3 x float4 each) */
+        const uint32_t n4 = 2 * nodeCount, t4 = 3 * sv.triCount;
+        for (uint32_t i = threadIdx.x; i < n4; i += WG)
+            ldsScene[i] = sv.nodes[i];
+        for (uint32_t i = threadIdx.x; i < t4; i += WG)
+            ldsScene[n4 + i] = sv.triGeom[i];
+        __syncthreads();
+    }
+    auto node4 = [&](uint32_t i) -> float4 {
+        if constexpr (LDSSCENE)
+            return ldsScene[i];
+        else
+            return sv.nodes[i];
+    };
+    auto tri4 = [&](uint32_t i) -> float4 {
+        if constexpr (LDSSCENE)
+            return ldsScene[2 * nodeCount + i];
+        else
+            return sv.triGeom[i];
+    };
+
+    /* lane -> pixel */
     const uint32_t gid = blockIdx.x * WG + threadIdx.x;
-    /* lanes beyond the block still run the loop zero times; no early return before LDS use */
     const bool inBlock = gid < args.blockSize;
-    const uint32_t pixel = args.blockStart + (inBlock ? gid : 0);
+    uint32_t pixel;
+    if (args.tiled) {
+        const uint32_t tilesPerRow = args.width >> 3;
+        const uint32_t tile = gid >> 6, lane = gid & 63u;
+        const uint32_t tx = tile % tilesPerRow, ty = tile / tilesPerRow;
+        pixel = args.blockStart + ((ty << 3) + (lane >> 3)) * args.width + (tx << 3) + (lane & 7u);
+    } else {
+        pixel = args.blockStart + gid;
+    }
+    if (!inBlock)
+        pixel = args.blockStart;
     const uint32_t px = pixel % args.width;
     const uint32_t py = pixel / args.width;
-    const uint32_t samples = inBlock ? args.samplesSqrt * args.samplesSqrt : 0;
+    const uint32_t samples = args.samplesSqrt * args.samplesSqrt;
     const float invSamplesSqrt = 1.0f / (float)args.samplesSqrt;
     const float invW = 1.0f / (float)args.width;
     const float invH = 1.0f / (float)args.height;
@@ -165,195 +157,338 @@ __global__ __launch_bounds__(WG) void wpt_pathtrace(const KernelArgs args)
     prngSeed(prng, pixel);
     float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
     LaneCounters lc = { 0, 0, 0, 0, 0 };
+    /* wave-level scheduler statistics (COUNT builds): rounds and lane counts per state */
+    unsigned long long sched[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 
-    /* per-lane path state */
+    /* ---- per-lane state ---- */
+    int state = inBlock ? S_NEW : S_DONE;
     uint32_t sampleIndex = 0;
-    int state = ST_NEW;
     uint32_t pathComponent = 0;
+    int rayKind = RAY_PATH;
     Ray ray;
-    f4 att = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-    f4 opl = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-    /* pending next-event state */
-    f4 nextAtt = att, directAtt = att, srRi = att;
-    f3 srDir = mk3(0.0f, 0.0f, 1.0f);
-    float directPdf = 0.0f, neeWeight = 0.0f;
-    uint32_t chosenPrim = NO_HIT;
     ray.o = mk3(0.0f, 0.0f, 0.0f);
     ray.d = mk3(0.0f, 0.0f, 1.0f);
-    ray.ri = att;
+    ray.ri = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+    f4 att = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+    f3 opl = mk3(0.0f, 0.0f, 0.0f); /* opticalPathLength; SensorRGB reads channels 0..2 only */
+    /* traversal registers */
+    RayAux aux = rayAux(ray.d);
+    uint32_t node = 0, leafPrim = 0;
+    float amax = k_maxval;
+    Candidate best;
+    best.prim = NO_HIT;
+    best.a = best.invDet = best.U = best.V = best.W = best.det = 0.0f;
+    /* pending continuation of the path while a next-event ray is in flight */
+    f4 nextAtt = att, directAtt = att, srRi = att;
+    f3 srDir = ray.d;
+    float directPdf = 0.0f, neeWeight = 0.0f;
+    uint32_t chosenPrim = NO_HIT;
+
+    auto beginRay = [&](int kind) {
+        aux = rayAux(ray.d);
+        node = 0;
+        amax = k_maxval;
+        best.prim = NO_HIT;
+        rayKind = kind;
+        state = S_NODE;
+        if (COUNT)
+            lc.rays++;
+    };
+    auto endOfRayState = [&]() { return rayKind == RAY_PATH ? S_SHADE : S_NEEEND; };
+
+    /* mean pdf over all hot spots of hitting them from org along dir (wurblpt.hpp:181-184) */
+    auto hotSpotsMeanPdf = [&](f3 org, f3 dir) {
+        const RayAux h = rayAux(dir);
+        float sum = 0.0f;
+        for (uint32_t i = 0; i < sv.hotspotCount; i++) {
+            const uint32_t p = sv.hotspots[i].prim;
+            sum += hotSpotPdf(tri4(3 * p), tri4(3 * p + 1), tri4(3 * p + 2), org, dir, h);
+            if (COUNT)
+                lc.pdfs++;
+        }
+        sum *= invHotSpots;
+        return sum;
+    };
+
+    /* wurblpt.hpp:254-273: continue the path along the scattered direction (ray.o already is
+     * the hit position), Russian roulette */
+    auto advancePath = [&]() {
+        att = nextAtt;
+        ray.d = srDir;
+        ray.ri = srRi;
+        const float mx = max4(att);
+        if (mx < par.rr_threshold && pathComponent >= 5) {
+            const float q = clampr(1.0f - mx, 0.0f, 0.95f);
+            if (in01(prng) < q) {
+                state = S_NEW;
+                return;
+            }
+            const float rrWeight = 1.0f / (1.0f - q);
+            att = sclr(att, rrWeight);
+        }
+        pathComponent++;
+        beginRay(RAY_PATH);
+    };
 
     for (;;) {
-        if (state == ST_NEW) {
-            if (sampleIndex >= samples)
-                break;
-            /* wurblpt.hpp:349-360: stratified jitter, the vertical stratum is drawn first */
-            float u = (float)px, v = (float)py;
-            if (par.randomize_ray_over_pixel) {
-                const uint32_t j = sampleIndex / args.samplesSqrt;
-                const uint32_t i = sampleIndex % args.samplesSqrt;
-                const float fj = (float)j + in01(prng);
-                const float fi = (float)i + in01(prng);
-                u += fi * invSamplesSqrt;
-                v += fj * invSamplesSqrt;
+        /* ---- the wave's scheduler: run the most populated state ---- */
+        const int cNode = __popcll(__ballot(state == S_NODE));
+        const int cLeaf = __popcll(__ballot(state == S_LEAF));
+        const int cShade = __popcll(__ballot(state == S_SHADE));
+        const int cNee = __popcll(__ballot(state == S_NEEEND));
+        const int cNew = __popcll(__ballot(state == S_NEW));
+        if ((cNode | cLeaf | cShade | cNee | cNew) == 0)
+            break;
+        int pick;
+        if (args.heavyMin == 0) {
+            /* policy 0: the most populated state */
+            int most = cNode;
+            pick = S_NODE;
+            if (cLeaf > most) { pick = S_LEAF; most = cLeaf; }
+            if (cShade > most) { pick = S_SHADE; most = cShade; }
+            if (cNee > most) { pick = S_NEEEND; most = cNee; }
+            if (cNew > most) { pick = S_NEW; most = cNew; }
+        } else {
+            /* policy 1: the long blocks (SHADE, NEE-END, NEW) run only when they are well
+             * filled, or when no traversal work is left in the wave; the short traversal
+             * blocks take whatever lanes they have */
+            const int heavyMin = (int)args.heavyMin;
+            if (cShade >= heavyMin) {
+                pick = S_SHADE;
+            } else if (cNee >= heavyMin) {
+                pick = S_NEEEND;
+            } else if (cNew >= heavyMin) {
+                pick = S_NEW;
+            } else if ((cNode | cLeaf) != 0) {
+                pick = cLeaf > cNode ? S_LEAF : S_NODE;
             } else {
-                u += 0.5f;
-                v += 0.5f;
+                int most = cShade;
+                pick = S_SHADE;
+                if (cNee > most) { pick = S_NEEEND; most = cNee; }
+                if (cNew > most) { pick = S_NEW; most = cNew; }
             }
-            u *= invW;
-            v *= invH;
-            /* Camera::getRay (camera.hpp:123-185), pinhole or thin lens */
-            f3 P = mk3(mixr(args.cam.l, args.cam.r, u), mixr(args.cam.b, args.cam.t, v), -1.0f);
-            f3 O = mk3(0.0f, 0.0f, 0.0f);
-            if ((F & FEAT_LENS) && args.cam.lens_radius > 0.0f) {
-                P = sclr(P, args.cam.focus_dist);
-                f2 d = inUnitDisk(in01x2(prng));
-                O = mk3(args.cam.lens_radius * d.x, args.cam.lens_radius * d.y, 0.0f);
-            }
-            f3 D = sub(P, O);
-            O = add(O, mk3(0.0f, 0.0f, 0.0f));
-            ray.o = add(ld3(args.cam.translation), quatRotate(args.cam.rotation, mul(O, ld3(args.cam.scaling))));
-            ray.d = normalize(quatRotate(args.cam.rotation, D));
-            ray.ri = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-            att = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-            opl = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-            pathComponent = 0;
-            sampleIndex++;
-            state = ST_PATH;
         }
 
-        /* the one traversal site: path rays and next-event rays */
-        const Candidate cand = traverse<COUNT>(sv, ray.o, ray.d, par.min_hit_distance, k_maxval, stack, lc);
-
-        bool advance = false;
-        if (state == ST_PATH) {
-            if (cand.prim == NO_HIT) {
-                if (haveEnv) {
-                    f4 rad = mul(att, envL(sv, ray.d));
-                    accumulate(par, mk4(k_maxval, k_maxval, k_maxval, k_maxval), k_maxval, rad, acc0, acc1, acc2);
+        if (pick == S_NODE) {
+            /* AABB::mayHit + the stackless form of BVH::hit's walk.  Stay while at least half
+             * of the lanes that entered are still walking. */
+            /* never below 1: the loop must end when no lane is left in it */
+            int leaveBelow = (cNode * (int)args.leaveEighths + 7) >> 3;
+            leaveBelow = leaveBelow < 1 ? 1 : leaveBelow;
+            if (COUNT) {
+                sched[0]++;
+            }
+            do {
+                if (COUNT) {
+                    sched[1]++;
+                    sched[2] += __popcll(__ballot(state == S_NODE));
                 }
-                state = ST_NEW;
-                continue;
+                if (state == S_NODE) {
+                    const float4 n0 = node4(2 * node);
+                    const float4 n1 = node4(2 * node + 1);
+                    if (COUNT)
+                        lc.nodes++;
+                    const uint32_t skip = __float_as_uint(n1.z);
+                    const uint32_t prim = __float_as_uint(n1.w);
+                    const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray.o, aux.inv, par.min_hit_distance, amax);
+                    /* select form of: hit & inner -> next node; hit & leaf -> test it; else -> skip */
+                    const bool toLeaf = hit && prim < NODE_EMPTY;
+                    const uint32_t next = (hit && prim == NODE_INNER) ? node + 1 : skip;
+                    leafPrim = toLeaf ? prim : leafPrim;
+                    node = toLeaf ? node : next;
+                    const int after = node >= nodeCount ? (rayKind == RAY_PATH ? S_SHADE : S_NEEEND) : S_NODE;
+                    state = toLeaf ? S_LEAF : after;
+                }
+            } while (__popcll(__ballot(state == S_NODE)) >= leaveBelow);
+        } else if (pick == S_LEAF) {
+            if (COUNT) {
+                sched[3]++;
+                sched[4] += cLeaf;
             }
-            opl = add(opl, scl(cand.a, ray.ri));
-            if (!(pathComponent + 1 < par.max_path_components)) {
-                state = ST_NEW;
-                continue;
+            if (state == S_LEAF) {
+                /* HitableTriangle::hit, candidate part (hitable_triangle.hpp:189-271) */
+                if (COUNT)
+                    lc.leaves++;
+                const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
+                Candidate c;
+                if (triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), ray.o, aux,
+                            par.min_hit_distance, amax, c)) {
+                    c.prim = leafPrim;
+                    best = c;
+                    amax = c.a;
+                }
+                node = node + 1; /* a leaf's subtree is the leaf itself */
+                state = node >= nodeCount ? endOfRayState() : S_NODE;
             }
-            Hit h = finishHit(sv, cand, ray.o, ray.d);
-            const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
-            if (COUNT)
-                lc.scatters++;
-            const Scatter sr = materialScatter<F>(sv, m, ray, h, prng);
-            {
-                f4 rad = mul(att, materialEmitted<F>(sv, m, h));
-                accumulate(par, opl, (pathComponent == 0 ? 0.0f : h.a), rad, acc0, acc1, acc2);
+        } else if (pick == S_SHADE) {
+            if (COUNT) {
+                sched[5]++;
+                sched[6] += cShade;
             }
-            if (sr.type == SCATTER_NONE) {
-                state = ST_NEW;
-                continue;
-            }
-            nextAtt = mul(att, sr.att);
-            if (sr.type == SCATTER_RANDOM) {
-                if (sr.pdf > 0.0f)
-                    nextAtt = divs(nextAtt, sr.pdf);
-                else
-                    nextAtt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-            srDir = sr.dir;
-            srRi = sr.ri;
-            advance = true;
-            if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
-                /* light sampling with MIS (wurblpt.hpp:179-220) */
-                const float hotSpotsPdf = hotSpotsMeanPdf(sv, h.p, sr.dir, invHotSpots, lc, COUNT);
-                nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
-                uint32_t idx = (uint32_t)(in01(prng) * (float)sv.hotspotCount);
-                idx = idx < sv.hotspotCount - 1 ? idx : sv.hotspotCount - 1;
-                const wpt_hotspot& hs = sv.hotspots[idx];
-                /* HitableTriangle::direction (hitable_triangle.hpp:425-443) */
-                const f3 bary = inTriangle(in01x2(prng));
-                f3 p = add(add(scl(bary.x, ld3(hs.p0)), scl(bary.y, ld3(hs.p1))), scl(bary.z, ld3(hs.p2)));
-                if (hs.transform)
-                    p = mat4mulPoint(hs.M, p);
-                const f3 directDir = normalize(sub(p, h.p));
-                directPdf = hotSpotsMeanPdf(sv, h.p, directDir, invHotSpots, lc, COUNT);
-                if (directPdf > 0.0f) {
-                    float dpdf;
-                    materialEval<F>(sv, m, ray, h, directDir, directAtt, dpdf);
-                    if (dpdf > 0.0f) {
-                        neeWeight = powerHeuristicWeight(directPdf, dpdf);
-                        chosenPrim = hs.prim;
-                        ray.o = h.p;
-                        ray.d = directDir;
-                        state = ST_NEE_LIGHT;
-                        advance = false;
+            if (state == S_SHADE) {
+                /* tracePath, one path component (wurblpt.hpp:131-252) */
+                if (best.prim == NO_HIT) {
+                    if (haveEnv) {
+                        f4 rad = mul(att, envL(sv, ray.d));
+                        accumulate(par, mk3(k_maxval, k_maxval, k_maxval), k_maxval, rad, acc0, acc1, acc2);
+                    }
+                    state = S_NEW;
+                } else {
+                    opl = add(opl, scl(best.a, mk3(ray.ri.x, ray.ri.y, ray.ri.z)));
+                    if (!(pathComponent + 1 < par.max_path_components)) {
+                        state = S_NEW;
+                    } else {
+                        Hit h = finishHit(sv, best, ray.o, ray.d);
+                        const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
+                        if (COUNT)
+                            lc.scatters++;
+                        const Scatter sr = materialScatter<F>(sv, m, ray, h, prng);
+                        {
+                            f4 rad = mul(att, materialEmitted<F>(sv, m, h));
+                            accumulate(par, opl, (pathComponent == 0 ? 0.0f : h.a), rad, acc0, acc1, acc2);
+                        }
+                        if (sr.type == SCATTER_NONE) {
+                            state = S_NEW;
+                        } else {
+                            nextAtt = mul(att, sr.att);
+                            if (sr.type == SCATTER_RANDOM) {
+                                if (sr.pdf > 0.0f)
+                                    nextAtt = divs(nextAtt, sr.pdf);
+                                else
+                                    nextAtt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+                            }
+                            srDir = sr.dir;
+                            srRi = sr.ri;
+                            bool shootNee = false;
+                            if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
+                                /* light sampling with MIS (wurblpt.hpp:179-220) */
+                                const float hotSpotsPdf = hotSpotsMeanPdf(h.p, sr.dir);
+                                nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
+                                uint32_t idx = (uint32_t)(in01(prng) * (float)sv.hotspotCount);
+                                idx = idx < sv.hotspotCount - 1 ? idx : sv.hotspotCount - 1;
+                                const wpt_hotspot& hs = sv.hotspots[idx];
+                                /* HitableTriangle::direction (hitable_triangle.hpp:425-443) */
+                                const f3 bary = inTriangle(in01x2(prng));
+                                f3 p = add(add(scl(bary.x, ld3(hs.p0)), scl(bary.y, ld3(hs.p1))), scl(bary.z, ld3(hs.p2)));
+                                if (hs.transform)
+                                    p = mat4mulPoint(hs.M, p);
+                                const f3 directDir = normalize(sub(p, h.p));
+                                directPdf = hotSpotsMeanPdf(h.p, directDir);
+                                if (directPdf > 0.0f) {
+                                    float dpdf;
+                                    materialEval<F>(sv, m, ray, h, directDir, directAtt, dpdf);
+                                    if (dpdf > 0.0f) {
+                                        neeWeight = powerHeuristicWeight(directPdf, dpdf);
+                                        chosenPrim = hs.prim;
+                                        ray.o = h.p;
+                                        ray.d = directDir;
+                                        shootNee = true;
+                                        beginRay(RAY_NEE_LIGHT);
+                                    }
+                                }
+                            } else if ((F & FEAT_ENVMAP) && sr.type == SCATTER_RANDOM && haveEnv && sv.envN > 0) {
+                                /* environment sampling with MIS (wurblpt.hpp:221-252) */
+                                const float lightsP = envP(sv, sr.dir);
+                                nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, lightsP));
+                                const f3 lightDir = envD(sv, prng);
+                                directPdf = envP(sv, lightDir);
+                                float dpdf;
+                                materialEval<F>(sv, m, ray, h, lightDir, directAtt, dpdf);
+                                if (dpdf > 0.0f) {
+                                    neeWeight = powerHeuristicWeight(directPdf, dpdf);
+                                    ray.o = h.p;
+                                    ray.d = lightDir;
+                                    shootNee = true;
+                                    beginRay(RAY_NEE_ENV);
+                                }
+                            }
+                            if (!shootNee) {
+                                ray.o = h.p;
+                                advancePath();
+                            }
+                        }
                     }
                 }
-            } else if ((F & FEAT_ENVMAP) && sr.type == SCATTER_RANDOM && haveEnv && sv.envN > 0) {
-                /* environment sampling with MIS (wurblpt.hpp:221-252) */
-                const float lightsP = envP(sv, sr.dir);
-                nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, lightsP));
-                const f3 lightDir = envD(sv, prng);
-                directPdf = envP(sv, lightDir);
-                float dpdf;
-                materialEval<F>(sv, m, ray, h, lightDir, directAtt, dpdf);
-                if (dpdf > 0.0f) {
-                    neeWeight = powerHeuristicWeight(directPdf, dpdf);
-                    ray.o = h.p;
-                    ray.d = lightDir;
-                    state = ST_NEE_ENV;
-                    advance = false;
+            }
+        } else if (pick == S_NEEEND) {
+            if (COUNT) {
+                sched[7]++;
+                sched[8] += cNee;
+            }
+            if (state == S_NEEEND) {
+                if (rayKind == RAY_NEE_LIGHT) {
+                    /* wurblpt.hpp:208-218: only the CHOSEN hot spot as nearest hit counts */
+                    if (best.prim == chosenPrim) {
+                        Hit lh = finishHit(sv, best, ray.o, ray.d);
+                        const wpt_material& lm = resolveMaterial<F>(sv, lh.material, lh);
+                        f4 rad = mul(sclr(divs(mul(att, directAtt), directPdf), neeWeight), materialEmitted<F>(sv, lm, lh));
+                        f3 oplLight = add(opl, scl(lh.a, mk3(ray.ri.x, ray.ri.y, ray.ri.z)));
+                        accumulate(par, oplLight, lh.a, rad, acc0, acc1, acc2);
+                    }
+                } else if (F & FEAT_ENVMAP) {
+                    if (best.prim == NO_HIT) {
+                        f4 rad = mul(sclr(divs(mul(att, directAtt), directPdf), neeWeight), envL(sv, ray.d));
+                        accumulate(par, mk3(k_maxval, k_maxval, k_maxval), k_maxval, rad, acc0, acc1, acc2);
+                    }
+                }
+                advancePath();
+            }
+        } else { /* S_NEW */
+            if (COUNT) {
+                sched[9]++;
+                sched[10] += cNew;
+            }
+            if (state == S_NEW) {
+                if (sampleIndex >= samples) {
+                    state = S_DONE;
+                } else {
+                    /* wurblpt.hpp:349-360: stratified jitter, the vertical stratum is drawn first */
+                    float u = (float)px, v = (float)py;
+                    if (par.randomize_ray_over_pixel) {
+                        const uint32_t j = sampleIndex / args.samplesSqrt;
+                        const uint32_t i = sampleIndex % args.samplesSqrt;
+                        const float fj = (float)j + in01(prng);
+                        const float fi = (float)i + in01(prng);
+                        u += fi * invSamplesSqrt;
+                        v += fj * invSamplesSqrt;
+                    } else {
+                        u += 0.5f;
+                        v += 0.5f;
+                    }
+                    u *= invW;
+                    v *= invH;
+                    /* Camera::getRay (camera.hpp:123-185), pinhole or thin lens */
+                    f3 P = mk3(mixr(args.cam.l, args.cam.r, u), mixr(args.cam.b, args.cam.t, v), -1.0f);
+                    f3 O = mk3(0.0f, 0.0f, 0.0f);
+                    if ((F & FEAT_LENS) && args.cam.lens_radius > 0.0f) {
+                        P = sclr(P, args.cam.focus_dist);
+                        f2 d = inUnitDisk(in01x2(prng));
+                        O = mk3(args.cam.lens_radius * d.x, args.cam.lens_radius * d.y, 0.0f);
+                    }
+                    f3 D = sub(P, O);
+                    O = add(O, mk3(0.0f, 0.0f, 0.0f));
+                    ray.o = add(ld3(args.cam.translation), quatRotate(args.cam.rotation, mul(O, ld3(args.cam.scaling))));
+                    ray.d = normalize(quatRotate(args.cam.rotation, D));
+                    ray.ri = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+                    att = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+                    opl = mk3(0.0f, 0.0f, 0.0f);
+                    pathComponent = 0;
+                    sampleIndex++;
+                    beginRay(RAY_PATH);
                 }
             }
-            if (advance)
-                ray.o = h.p;
-        } else if (state == ST_NEE_LIGHT) {
-            /* wurblpt.hpp:208-218: only the CHOSEN hot spot as nearest hit counts */
-            if (cand.prim == chosenPrim) {
-                Hit lh = finishHit(sv, cand, ray.o, ray.d);
-                const wpt_material& lm = resolveMaterial<F>(sv, lh.material, lh);
-                f4 rad = mul(sclr(divs(mul(att, directAtt), directPdf), neeWeight), materialEmitted<F>(sv, lm, lh));
-                f4 oplLight = add(opl, scl(lh.a, ray.ri));
-                accumulate(par, oplLight, lh.a, rad, acc0, acc1, acc2);
-            }
-            state = ST_PATH;
-            advance = true;
-        } else { /* ST_NEE_ENV */
-            if (cand.prim == NO_HIT) {
-                f4 rad = mul(sclr(divs(mul(att, directAtt), directPdf), neeWeight), envL(sv, ray.d));
-                accumulate(par, mk4(k_maxval, k_maxval, k_maxval, k_maxval), k_maxval, rad, acc0, acc1, acc2);
-            }
-            state = ST_PATH;
-            advance = true;
-        }
-
-        if (advance) {
-            /* wurblpt.hpp:254-273 (ray.o already is the hit position) */
-            att = nextAtt;
-            ray.d = srDir;
-            ray.ri = srRi;
-            const float mx = max4(att);
-            if (mx < par.rr_threshold && pathComponent >= 5) {
-                const float q = clampr(1.0f - mx, 0.0f, 0.95f);
-                if (in01(prng) < q) {
-                    state = ST_NEW;
-                    continue;
-                }
-                const float rrWeight = 1.0f / (1.0f - q);
-                att = sclr(att, rrWeight);
-            }
-            pathComponent++;
         }
     }
 
     if (inBlock) {
         /* SensorRGB::finishPixel (sensor_rgb.hpp:82-87) */
-        const float invSamples = 1.0f / (float)(args.samplesSqrt * args.samplesSqrt);
+        const float invSamples = 1.0f / (float)samples;
         float* out = args.frame + 3 * (size_t)pixel;
         out[0] = invSamples * acc0;
         out[1] = invSamples * acc1;
         out[2] = invSamples * acc2;
     }
-    if (COUNT && args.counters) {
+    if (COUNT && args.counters && inBlock) {
         atomicAdd((unsigned long long*)&args.counters->samples, (unsigned long long)samples);
         atomicAdd((unsigned long long*)&args.counters->rays, (unsigned long long)lc.rays);
         atomicAdd((unsigned long long*)&args.counters->node_visits, (unsigned long long)lc.nodes);
@@ -361,13 +496,18 @@ __global__ __launch_bounds__(WG) void wpt_pathtrace(const KernelArgs args)
         atomicAdd((unsigned long long*)&args.counters->pdf_tests, (unsigned long long)lc.pdfs);
         atomicAdd((unsigned long long*)&args.counters->scatters, (unsigned long long)lc.scatters);
     }
+    if (COUNT && args.schedStats && (threadIdx.x & 63) == 0) {
+        for (int i = 0; i < 11; i++)
+            atomicAdd(args.schedStats + i, sched[i]);
+    }
 }
-
 
 constexpr uint32_t FEAT_BASIC = FEAT_GGX | FEAT_GLASS;
 constexpr uint32_t FEAT_ALL = FEAT_TEXTURES | FEAT_MODPHONG | FEAT_ENVMAP | FEAT_LENS | FEAT_TWOSIDED | FEAT_GGX | FEAT_GLASS;
 
-/* one launcher per instantiation, each defined in its own translation unit */
+/* one launcher per instantiation, each defined in its own translation unit;
+ * ldsBytes is the dynamic LDS size (0 for the HBM variants) */
+void launchBasicLds(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream);
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream);
