@@ -19,7 +19,6 @@ import ctypes as C
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -149,14 +148,10 @@ def main():
 
     # ---- the step ----
     kernel_ms = []  # (milliseconds, samples) per launch on this rank, timed steps only
+    from wurblpt_amd import blocks
     store = dist.distributed_c10d._get_default_store() if world > 1 else None
     streams = [torch.cuda.Stream() for _ in range(args.streams)] if world > 1 else []
-    block_size = 0
-    if world > 1:
-        # about two blocks per stream and GPU, whole rows, never less than the reference's 4096
-        block_size = max(4096, -(-pixels // (world * args.streams * 2)))
-        block_size = -(-block_size // width) * width
-    n_blocks = -(-pixels // block_size) if world > 1 else 1
+    block_size = blocks.plan_block_size(pixels, width, world, args.streams) if world > 1 else pixels
 
     def step(index, timed):
         if world == 1:
@@ -169,37 +164,22 @@ def main():
             return
         frame.zero_()
         torch.cuda.synchronize()
-        key = "wpt_block_counter_%d" % index
-        errors = []
+        queue = blocks.BlockQueue(pixels, block_size, store, "wpt_block_counter_%d" % index)
 
-        def worker(stream):
-            try:
-                torch.cuda.set_device(local_rank)
-                while True:
-                    b = store.add(key, 1) - 1  # MPICoordinator::getBlock
-                    if b >= n_blocks:
-                        break
-                    start = b * block_size
-                    size = min(block_size, pixels - start)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(stream)
-                    dscene.render_block_into(frame, ssqrt, (start, size), params, None, stream)
-                    e1.record(stream)
-                    stream.synchronize()  # submitBlock: the block is in this rank's frame
-                    if timed:
-                        kernel_ms.append((e0, e1, size * spp))
-            except Exception as exc:  # surface worker failures on the main thread
-                errors.append(exc)
+        def render_block(worker, start, size):
+            stream = streams[worker]
+            torch.cuda.set_device(local_rank)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            dscene.render_block_into(frame, ssqrt, (start, size), params, None, stream)
+            e1.record(stream)
+            stream.synchronize()  # submitBlock: the block is in this rank's frame
+            if timed:
+                kernel_ms.append((e0, e1, size * spp))
 
-        threads = [threading.Thread(target=worker, args=(s,)) for s in streams]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
+        blocks.render_sharded(queue, render_block, len(streams))
         torch.cuda.synchronize()
-        dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)  # final framebuffer reduce over xGMI
+        blocks.reduce_frame(frame, dst=0)  # final framebuffer reduce over xGMI
 
     def barrier():
         if world > 1:

@@ -1,0 +1,90 @@
+"""The N > 1 path on CPU: two gloo ranks pull pixel blocks from the shared counter
+(MPICoordinator::getBlock semantics), render them with the CPU restatement into
+zero-initialised full frames, and one reduce sums them onto rank 0.  The result must be
+bit-identical to the single-process frame (blocks are disjoint; the rest is exactly 0)."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+from wurblpt_amd import blocks, host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from wurblpt_amd import blocks, host
+from tests import oracle_loader
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+W, H, S = 48, 40, 3
+sc = host.cornell(W, H, 1, 2)
+orc = oracle_loader.load("portable")
+frame = torch.zeros((H, W, 3), dtype=torch.float32)
+store = dist.distributed_c10d._get_default_store()
+bs = blocks.plan_block_size(W * H, W, world, 2, min_block=96)
+queue = blocks.BlockQueue(W * H, bs, store, "q0")
+def render_block(worker, start, size):
+    part, _ = orc.render(sc, S, block=(start, size), threads=1)
+    flat = frame.view(-1, 3)
+    flat[start:start + size] = torch.from_numpy(part.reshape(-1, 3)[start:start + size])
+mine = blocks.render_sharded(queue, render_block, 2)
+counts = torch.tensor([len(mine), sum(s for _, s in mine)], dtype=torch.int64)
+dist.all_reduce(counts)
+blocks.reduce_frame(frame, dst=0)
+if rank == 0:
+    np.save(sys.argv[1], frame.numpy())
+    np.save(sys.argv[1] + ".counts.npy", counts.numpy())
+    np.save(sys.argv[1] + ".bs.npy", np.array([bs, queue.n_blocks]))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_plan_block_size():
+    assert blocks.plan_block_size(1024 * 1024, 1024, 1, 1) == 1024 * 1024 // 2
+    bs = blocks.plan_block_size(1024 * 1024, 1024, 8, 4)
+    assert bs % (8 * 1024) == 0 and 4096 <= bs <= 1024 * 1024 // 32
+    assert blocks.plan_block_size(100, 10, 8, 4) == 100  # never below the reference's 4096 -> whole frame
+
+
+def test_block_queue_covers_the_frame_exactly_once():
+    q = blocks.BlockQueue(1000, 96)
+    seen = np.zeros(1000, np.int32)
+    while True:
+        b = q.get_block()
+        if b is None:
+            break
+        seen[b[0]:b[0] + b[1]] += 1
+    assert (seen == 1).all() and q.get_block() is None
+
+
+def test_two_ranks_gloo_match_single_process(oracle):
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "worker.py")
+        open(script, "w").write(WORKER % {"root": ROOT})
+        out = os.path.join(d, "frame.npy")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, out]
+        subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        got = np.load(out)
+        counts = np.load(out + ".counts.npy")
+        bs, nb = np.load(out + ".bs.npy")
+    sc = host.cornell(48, 40, 1, 2)
+    ref, _ = oracle.render(sc, 3)
+    assert counts[0] == nb and counts[1] == 48 * 40  # every block rendered exactly once over both ranks
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

@@ -1,0 +1,90 @@
+"""Pixel-block distribution over the GPUs of one node.
+
+Mirror of the reference's MPICoordinator (mpi.hpp:152-289): the frame is cut into blocks of
+consecutive pixel indices, workers pull the next block index from one shared counter
+(getBlock), render it into their own zero-initialised full frame (submitBlock), and the frames
+are summed onto rank 0 at the end.  Here the counter lives in the c10d store of
+torch.distributed (an atomic fetch-add, so no coordinator thread is needed), one process
+drives one GPU, and the final gather is ONE reduce over RCCL/xGMI.  Blocks are disjoint and the
+rest of every frame is exactly 0.0f, so the sum is exact in any reduction order.
+
+Backend agnostic: tests run it with gloo on CPU tensors and the CPU restatement as renderer."""
+import threading
+
+
+def plan_block_size(pixels, width, world, workers_per_rank, min_block=4096, blocks_per_worker=2):
+    """Whole rows, about `blocks_per_worker` blocks per worker, never below the reference's
+    default block of 4096 pixels (mpi.hpp:178), and a multiple of 8 rows where possible so that
+    the kernel can map waves to 8x8 pixel tiles."""
+    size = max(min_block, -(-pixels // max(1, world * workers_per_rank * blocks_per_worker)))
+    rows = -(-size // width)
+    if rows > 8:
+        rows -= rows % 8
+    return min(pixels, rows * width)
+
+
+class BlockQueue:
+    """MPICoordinator::getBlock over a shared counter."""
+
+    def __init__(self, pixels, block_size, store=None, key="wpt_blocks"):
+        self.pixels = pixels
+        self.block_size = block_size
+        self.n_blocks = -(-pixels // block_size)
+        self._store = store
+        self._key = key
+        self._local = 0
+        self._lock = threading.Lock()
+
+    def get_block(self):
+        """Returns (start, size) or None when the frame is handed out (blockSize == 0 in the reference)."""
+        if self._store is not None:
+            index = self._store.add(self._key, 1) - 1
+        else:
+            with self._lock:
+                index = self._local
+                self._local += 1
+        if index >= self.n_blocks:
+            return None
+        start = index * self.block_size
+        return start, min(self.block_size, self.pixels - start)
+
+
+def render_sharded(queue, render_block, workers):
+    """Each worker (e.g. one per HIP stream) pulls blocks until the queue is empty.
+    render_block(worker_index, start, size) must return after the block is in this rank's frame.
+    Returns the list of (start, size) this rank rendered."""
+    done = []
+    errors = []
+    lock = threading.Lock()
+
+    def run(w):
+        try:
+            while True:
+                b = queue.get_block()
+                if b is None:
+                    break
+                render_block(w, b[0], b[1])
+                with lock:
+                    done.append(b)
+        except Exception as exc:  # surfaced on the calling thread
+            errors.append(exc)
+
+    if workers == 1:
+        run(0)
+    else:
+        threads = [threading.Thread(target=run, args=(w,)) for w in range(workers)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+    return done
+
+
+def reduce_frame(frame, dst=0):
+    """Final gather: sum of the per-rank frames onto rank `dst` (RCCL over xGMI for CUDA tensors)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
+    return frame
