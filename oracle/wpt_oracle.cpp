@@ -27,6 +27,7 @@
 #include <math.h>
 #include <cmath>
 #include <limits>
+#include <algorithm>
 #include <vector>
 #include <omp.h>
 
@@ -1375,6 +1376,42 @@ int wpt_oracle_render(const wpt_scene_desc* scene, const wpt_camera* camera, con
     }
     if (counters)
         *counters = total;
+    return 0;
+}
+
+/* EnvironmentMap::initializeImportanceSampling (envmap.hpp:121-158): M (normalized importance
+ * per bin), Ms (bin ids sorted by descending importance), Mcs (cumulative importance) */
+int wpt_oracle_envmap_tables(const wpt_scene_desc* scene, int N, float* M, int32_t* Ms, float* Mcs)
+{
+    if (!scene || scene->envmap.type == WPT_ENV_NONE || N <= 0)
+        return 1;
+    wpt_params pr;
+    memset(&pr, 0, sizeof(pr));
+    Ctx c;
+    c.sc = scene;
+    c.pr = &pr;
+    float totalImportance = 0.0f;
+    for (int y = 0; y < N; y++) {
+        float v = (y + 0.5f) / N;
+        for (int x = 0; x < N; x++) {
+            float u = (x + 0.5f) / N;
+            V3 d = envInvM(V2 { u, v });
+            V4 L = envL(c, d);
+            float importance = L.x + L.y + L.z + L.w;
+            totalImportance += importance;
+            M[y * N + x] = importance;
+        }
+    }
+    for (int i = 0; i < N * N; i++)
+        M[i] /= totalImportance;
+    for (int i = 0; i < N * N; i++)
+        Ms[i] = i;
+    std::sort(Ms, Ms + N * N, [M](unsigned int i, unsigned int j) { return M[i] > M[j]; });
+    float sum = 0.0f;
+    for (int i = 0; i < N * N; i++) {
+        sum += M[Ms[i]];
+        Mcs[i] = sum;
+    }
     return 0;
 }
 

@@ -50,6 +50,16 @@ class Oracle:
             raise RuntimeError("oracle render failed: %d" % rc)
         return frame, cnt.as_dict()
 
+    def envmap_tables(self, scene, n=None):
+        """Importance tables of the scene's environment map (M, Ms, Mcs) as numpy arrays."""
+        n = n or scene.d.envmap.N
+        M = np.zeros(n * n, np.float32)
+        Ms = np.zeros(n * n, np.int32)
+        Mcs = np.zeros(n * n, np.float32)
+        rc = self.L.wpt_oracle_envmap_tables(scene.desc, C.c_int(n), C.c_void_p(M.ctypes.data), C.c_void_p(Ms.ctypes.data), C.c_void_p(Mcs.ctypes.data))
+        assert rc == 0
+        return M, Ms, Mcs
+
     # -- per-function probes ---------------------------------------------
     def _call(self, fn, *args):
         getattr(self.L, fn)(*args)

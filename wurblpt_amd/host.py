@@ -27,6 +27,8 @@ def lib():
         L.wpt_host_cornell.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint]
         L.wpt_host_random_triangles.restype = C.c_void_p
         L.wpt_host_random_triangles.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint, C.c_float]
+        L.wpt_host_sponza_like.restype = C.c_void_p
+        L.wpt_host_sponza_like.argtypes = [C.c_uint, C.c_float, C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint]
         L.wpt_host_scene_desc.restype = C.POINTER(_abi.SceneDesc)
         L.wpt_host_scene_desc.argtypes = [C.c_void_p]
         L.wpt_host_scene_camera.restype = C.POINTER(_abi.Camera)
@@ -69,6 +71,13 @@ class HostScene:
     def d(self):
         return self.desc.contents
 
+    def set_envmap_tables(self, M, Ms, Mcs):
+        """Attaches importance tables (numpy arrays, kept alive here) to the scene description;
+        without them wpt_scene_upload builds them on the device."""
+        self._env_tables = (M, Ms, Mcs)
+        e = self.d.envmap
+        e.M, e.Ms, e.Mcs = M.ctypes.data, Ms.ctypes.data, Mcs.ctypes.data
+
     def nodes_array(self):
         n = self.d.node_count
         return np.ctypeslib.as_array(C.cast(self.d.nodes, C.POINTER(C.c_uint32)), shape=(n, 8)).copy()
@@ -84,6 +93,14 @@ def cornell(width, height, tall_box_material=0, short_object_material=0):
 def random_triangles(n, seed, width, height, with_texcoords=True, aperture=0.0):
     h = lib().wpt_host_random_triangles(n, seed, 1 if with_texcoords else 0, width, height, aperture)
     return HostScene(h, width, height, "random_triangles(%d,%d)" % (n, seed))
+
+
+def sponza_like(width, height, seed=1, detail=1.0, tex_size=1024, env_width=2048, importance_n=512):
+    """BASELINE config 3 stand-in: seeded Sponza-class courtyard (about 262 k triangles at
+    detail 1.0), textured Lambertian / ModPhong / two-sided / GGX / mirror materials, normal
+    maps, procedural sun + sky environment map with importance sampling."""
+    h = lib().wpt_host_sponza_like(seed, detail, tex_size, env_width, importance_n, width, height)
+    return HostScene(h, width, height, "sponza_like(seed=%d,detail=%g)" % (seed, detail))
 
 
 def bvh_build(boxes):

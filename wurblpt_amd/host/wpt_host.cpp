@@ -8,6 +8,7 @@
  */
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <random>
 #include <string>
 #include <vector>
@@ -20,7 +21,8 @@
 using namespace WurblPT;
 
 struct wpt_host_scene {
-    Scene scene;
+    std::unique_ptr<Scene> scenePtr { new Scene };
+    Scene& scene = *scenePtr;
     FlatScene flat;
     wpt_scene_desc desc;
     wpt_camera camera;
@@ -186,11 +188,11 @@ void buildRandomTriangles(Scene& scene, unsigned int n, unsigned int seed, bool 
     scene.take(new MeshInstance(scene.take(generateQuad()), light, T), HotSpot);
 }
 
-wpt_host_scene* finishScene(wpt_host_scene* hs, unsigned int width, unsigned int height, float vfovRadians,
-        const vec3& from, const vec3& at, float aperture = 0.0f, float focusDist = 1.0f)
+wpt_host_scene* finishSceneOf(wpt_host_scene* hs, Scene& scene, unsigned int width, unsigned int height, float vfovRadians,
+        const vec3& from, const vec3& at, float aperture, float focusDist)
 {
-    hs->scene.updateBVH();
-    if (!hs->scene.flatten(hs->flat, &hs->error)) {
+    scene.updateBVH();
+    if (!scene.flatten(hs->flat, &hs->error)) {
         fprintf(stderr, "wpt_host: %s\n", hs->error.c_str());
         delete hs;
         return nullptr;
@@ -202,6 +204,21 @@ wpt_host_scene* finishScene(wpt_host_scene* hs, unsigned int width, unsigned int
     return hs;
 }
 
+wpt_host_scene* finishScene(wpt_host_scene* hs, unsigned int width, unsigned int height, float vfovRadians,
+        const vec3& from, const vec3& at, float aperture = 0.0f, float focusDist = 1.0f)
+{
+    return finishSceneOf(hs, hs->scene, width, height, vfovRadians, from, at, aperture, focusDist);
+}
+
+}
+
+/* used by the other scene files of this library: takes ownership of `scene` */
+wpt_host_scene* wptHostFinish(Scene* scene, unsigned int width, unsigned int height, float vfovRadians, const vec3& from,
+        const vec3& at, float aperture, float focusDist)
+{
+    wpt_host_scene* hs = new wpt_host_scene;
+    hs->scenePtr.reset(scene);
+    return finishSceneOf(hs, *scene, width, height, vfovRadians, from, at, aperture, focusDist);
 }
 
 extern "C" {

@@ -1,0 +1,266 @@
+/*
+ * wpt_host_sponza.cpp -- the Sponza-class procedural stand-in of BASELINE config 3.
+ *
+ * The real Crytek Sponza OBJ, its textures and the HDR environment map are not available
+ * offline, so this builds a seeded scene of the same class with the generator
+ * functions: a colonnaded courtyard (subdivided floor and walls, two rows of cylinder columns
+ * with bases and capitals, beams, hanging curtains, vases) with what the OBJ importer would
+ * produce (reference import.hpp:288-398): textured Lambertian and ModPhong materials, normal
+ * maps on some of them, an alpha-textured two-sided curtain, plus a GGX and a mirror object.
+ * Geometry is authored in "OBJ units" and baked through the transformation of
+ * wurblpt-sponza.cpp:49-53 (rotate 90 degrees about Y, scale 0.01); camera of :145-148;
+ * procedural sun + sky equirectangular float32 environment map with importance sampling.
+ * `detail` scales the tessellation: 1.0 gives about 262 k triangles, tests use small values.
+ */
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/wurblpt/camera.hpp"
+#include "../../include/wurblpt/generator.hpp"
+#include "../../include/wurblpt/scene.hpp"
+#include "../../include/wurblpt/sensor.hpp"
+
+using namespace WurblPT;
+
+struct wpt_host_scene;
+wpt_host_scene* wptHostFinish(Scene* scene, unsigned int width, unsigned int height, float vfovRadians, const vec3& from,
+        const vec3& at, float aperture, float focusDist);
+
+namespace {
+
+struct Rng {
+    std::mt19937 g;
+    explicit Rng(unsigned int seed) : g(seed) {}
+    float u01() { return float(g() >> 8) * (1.0f / 16777216.0f); }
+};
+
+/* seeded value noise, bilinear over a lattice, a few octaves */
+struct ValueNoise {
+    int n;
+    std::vector<float> lattice;
+    ValueNoise(Rng& rng, int n_) : n(n_), lattice(size_t(n_) * n_)
+    {
+        for (float& v : lattice)
+            v = rng.u01();
+    }
+    float at(float x, float y) const
+    {
+        x -= std::floor(x);
+        y -= std::floor(y);
+        float fx = x * n, fy = y * n;
+        int x0 = int(fx) % n, y0 = int(fy) % n, x1 = (x0 + 1) % n, y1 = (y0 + 1) % n;
+        float ax = fx - std::floor(fx), ay = fy - std::floor(fy);
+        float a = lattice[y0 * n + x0] * (1.0f - ax) + lattice[y0 * n + x1] * ax;
+        float b = lattice[y1 * n + x0] * (1.0f - ax) + lattice[y1 * n + x1] * ax;
+        return a * (1.0f - ay) + b * ay;
+    }
+    float fbm(float x, float y) const { return 0.5f * at(x, y) + 0.3f * at(2.0f * x + 0.37f, 2.0f * y + 0.11f) + 0.2f * at(4.0f * x + 0.71f, 4.0f * y + 0.53f); }
+};
+
+unsigned char toByte(float v)
+{
+    v = v < 0.0f ? 0.0f : v > 1.0f ? 1.0f : v;
+    return (unsigned char)(v * 255.0f + 0.5f);
+}
+
+/* sRGB colour texture: two base colours blended by noise, with a brick / tile pattern */
+Texture* makeColorTexture(Scene& scene, Rng& rng, int size, const vec3& c0, const vec3& c1, int tilesX, int tilesY, bool withAlpha)
+{
+    ValueNoise noise(rng, 16);
+    Array<uint8_t> img(size, size, withAlpha ? 4 : 3);
+    for (int y = 0; y < size; y++)
+        for (int x = 0; x < size; x++) {
+            float u = (x + 0.5f) / size, v = (y + 0.5f) / size;
+            float t = noise.fbm(u, v);
+            float gu = u * tilesX - std::floor(u * tilesX), gv = v * tilesY - std::floor(v * tilesY);
+            float mortar = (gu < 0.06f || gv < 0.08f) ? 0.55f : 1.0f;
+            uint8_t* p = img.at(x, y);
+            for (int k = 0; k < 3; k++)
+                p[k] = toByte((c0[k] * (1.0f - t) + c1[k] * t) * mortar);
+            if (withAlpha) {
+                /* curtain with holes: a soft dot pattern in the alpha channel */
+                float du = gu - 0.5f, dv = gv - 0.5f;
+                p[3] = toByte((du * du + dv * dv < 0.06f) ? 0.15f + 0.5f * t : 1.0f);
+            }
+        }
+    return scene.take(createTextureImage(img));
+}
+
+/* normal map (linear uint8): derivative of a noise height field */
+Texture* makeNormalMap(Scene& scene, Rng& rng, int size, float strength)
+{
+    ValueNoise noise(rng, 24);
+    Array<uint8_t> img(size, size, 3);
+    float e = 1.0f / size;
+    for (int y = 0; y < size; y++)
+        for (int x = 0; x < size; x++) {
+            float u = (x + 0.5f) / size, v = (y + 0.5f) / size;
+            float dx = (noise.fbm(u + e, v) - noise.fbm(u - e, v)) * strength;
+            float dy = (noise.fbm(u, v + e) - noise.fbm(u, v - e)) * strength;
+            vec3 n = normalize(vec3(-dx, -dy, 1.0f));
+            uint8_t* p = img.at(x, y);
+            for (int k = 0; k < 3; k++)
+                p[k] = toByte(0.5f * n[k] + 0.5f);
+        }
+    return scene.take(createTextureImage(img, LinearizeSRGB_Off));
+}
+
+/* single-channel linear texture (shininess / opacity modulation) */
+Texture* makeGreyTexture(Scene& scene, Rng& rng, int size, float lo, float hi)
+{
+    ValueNoise noise(rng, 12);
+    Array<uint8_t> img(size, size, 1);
+    for (int y = 0; y < size; y++)
+        for (int x = 0; x < size; x++)
+            img.at(x, y)[0] = toByte(lo + (hi - lo) * noise.fbm((x + 0.5f) / size, (y + 0.5f) / size));
+    return scene.take(createTextureImage(img, LinearizeSRGB_Off));
+}
+
+/* procedural sky: horizon-to-zenith gradient, ground, and a small bright sun; float32 RGB,
+ * equirectangular, row 0 = v 0 = straight down */
+Texture* makeSky(Scene& scene, int width, int height)
+{
+    Array<float> img(width, height, 3);
+    const vec3 sunDir = normalize(vec3(0.35f, 0.8f, -0.45f));
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            float lat = ((y + 0.5f) / height - 0.5f) * pi;
+            float lon = ((x + 0.5f) / width) * 2.0f * pi;
+            vec3 d(-std::cos(lat) * std::sin(lon), std::sin(lat), std::cos(lat) * std::cos(lon));
+            float up = d.y();
+            vec3 c = up > 0.0f ? mix(vec3(0.9f, 0.95f, 1.0f), vec3(0.25f, 0.45f, 0.9f), std::sqrt(up)) : vec3(0.2f, 0.18f, 0.15f);
+            float s = dot(d, sunDir);
+            if (s > 0.9995f)
+                c = c + vec3(800.0f, 760.0f, 700.0f);
+            else if (s > 0.99f)
+                c = c + vec3(4.0f, 3.6f, 3.0f) * ((s - 0.99f) / 0.0095f);
+            float* p = img.at(x, y);
+            p[0] = c.x();
+            p[1] = c.y();
+            p[2] = c.z();
+        }
+    return scene.take(createTextureImage(img));
+}
+
+int scaled(float detail, int full, int least)
+{
+    int v = int(full * detail + 0.5f);
+    return v < least ? least : v;
+}
+
+}
+
+extern "C" wpt_host_scene* wpt_host_sponza_like(unsigned int seed, float detail, unsigned int texSize, unsigned int envWidth,
+        int importanceN, unsigned int width, unsigned int height)
+{
+    Scene* scenePtr = new Scene;
+    Scene& scene = *scenePtr;
+    Rng rng(seed);
+    /* wurblpt-sponza.cpp:49-53: OBJ space -> world */
+    const Transformation objToWorld(vec3(0.0f), toQuat(radians(90.0f), vec3(0.0f, 1.0f, 0.0f)), vec3(0.01f));
+    const int ts = int(texSize);
+
+    Texture* floorTex = makeColorTexture(scene, rng, ts, vec3(0.55f, 0.5f, 0.42f), vec3(0.8f, 0.76f, 0.68f), 8, 8, false);
+    Texture* floorNrm = makeNormalMap(scene, rng, ts, 6.0f);
+    Texture* wallTex = makeColorTexture(scene, rng, ts, vec3(0.62f, 0.45f, 0.33f), vec3(0.78f, 0.62f, 0.5f), 12, 24, false);
+    Texture* wallNrm = makeNormalMap(scene, rng, ts, 10.0f);
+    Texture* columnTex = makeColorTexture(scene, rng, ts, vec3(0.7f, 0.68f, 0.62f), vec3(0.86f, 0.84f, 0.8f), 1, 6, false);
+    Texture* columnShi = makeGreyTexture(scene, rng, ts / 2 > 4 ? ts / 2 : 4, 0.2f, 1.0f);
+    Texture* curtainTex[3] = {
+        makeColorTexture(scene, rng, ts, vec3(0.7f, 0.08f, 0.08f), vec3(0.9f, 0.2f, 0.15f), 10, 10, true),
+        makeColorTexture(scene, rng, ts, vec3(0.1f, 0.3f, 0.7f), vec3(0.2f, 0.5f, 0.9f), 10, 10, true),
+        makeColorTexture(scene, rng, ts, vec3(0.1f, 0.5f, 0.15f), vec3(0.3f, 0.75f, 0.3f), 10, 10, true) };
+    Texture* specTex = makeColorTexture(scene, rng, ts / 2 > 4 ? ts / 2 : 4, vec3(0.05f), vec3(0.35f), 4, 4, false);
+
+    /* what the importer produces (import.hpp:328-386) */
+    MaterialLambertian* floorMat = new MaterialLambertian(vec3(0.7f), floorTex);
+    floorMat->normalTex = floorNrm;
+    scene.take(floorMat, "floor");
+    MaterialLambertian* wallMat = new MaterialLambertian(vec3(0.7f), wallTex);
+    wallMat->normalTex = wallNrm;
+    scene.take(wallMat, "bricks");
+    MaterialModPhong* columnMat = new MaterialModPhong;
+    columnMat->haveNIR = false;
+    columnMat->diffuse = vec4(0.6f, 0.6f, 0.6f, 0.0f);
+    columnMat->diffuseTex = columnTex;
+    columnMat->specular = vec4(0.25f, 0.25f, 0.25f, 0.0f);
+    columnMat->specularTex = specTex;
+    columnMat->shininess = 60.0f;
+    columnMat->shininessTex = columnShi;
+    columnMat->opacity = 1.0f;
+    scene.take(columnMat, "column");
+    Material* curtainMat[3];
+    for (int i = 0; i < 3; i++) {
+        MaterialModPhong* m = new MaterialModPhong;
+        m->haveNIR = false;
+        m->diffuse = vec4(0.6f, 0.6f, 0.6f, 0.0f);
+        m->diffuseTex = curtainTex[i];
+        m->diffuseTexHasAlpha = true;
+        m->specular = vec4(0.04f, 0.04f, 0.04f, 0.0f);
+        m->shininess = 12.0f;
+        m->opacity = 1.0f;
+        m->transmissive = vec4(0.3f, 0.3f, 0.3f, 0.0f);
+        scene.take(m, "fabric");
+        curtainMat[i] = scene.take(new MaterialTwoSided(m, m), "fabric-two-sided");
+    }
+    Material* beamMat = scene.take(new MaterialModPhong(vec3(0.45f, 0.3f, 0.2f), vec3(0.1f), 30.0f), "wood");
+    Material* vaseMat = scene.take(new MaterialGGX(vec3(0.95f, 0.75f, 0.4f), vec2(0.15f, 0.25f)), "brass");
+    Material* mirrorMat = scene.take(new MaterialMirror(vec3(0.9f)), "mirror");
+
+    auto T = [&](const vec3& t, const vec3& s, const quat& r = quat::null()) { return objToWorld * Transformation(t, r, s); };
+    const quat layFlat = toQuat(radians(-90.0f), vec3(1.0f, 0.0f, 0.0f)); /* quad (XY) -> floor (XZ), facing up */
+    const float halfL = 1400.0f, halfW = 600.0f, wallH = 1100.0f;
+
+    /* floor: the largest share of the triangles, like Sponza's tiled floor */
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f), vec3(halfL, halfW, 1.0f), layFlat), scaled(detail, 300, 2))), floorMat));
+    /* four walls */
+    const int ws = scaled(detail, 64, 1);
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH * 0.5f, -halfW), vec3(halfL, wallH * 0.5f, 1.0f)), ws)), wallMat));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH * 0.5f, halfW), vec3(halfL, wallH * 0.5f, 1.0f), toQuat(radians(180.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), wallMat));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(-halfL, wallH * 0.5f, 0.0f), vec3(halfW, wallH * 0.5f, 1.0f), toQuat(radians(90.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), wallMat));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(halfL, wallH * 0.5f, 0.0f), vec3(halfW, wallH * 0.5f, 1.0f), toQuat(radians(-90.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), wallMat));
+    /* a partial roof: two side strips, the middle is open to the sky */
+    const quat faceDown = toQuat(radians(90.0f), vec3(1.0f, 0.0f, 0.0f));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH, -halfW * 0.7f), vec3(halfL, halfW * 0.3f, 1.0f), faceDown), scaled(detail, 24, 1))), wallMat));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH, halfW * 0.7f), vec3(halfL, halfW * 0.3f, 1.0f), faceDown), scaled(detail, 24, 1))), wallMat));
+    /* two rows of columns with base and capital, beams on top */
+    const int columns = 12;
+    const int cylSlices = scaled(detail, 96, 6);
+    for (int row = 0; row < 2; row++) {
+        float z = (row == 0 ? -1.0f : 1.0f) * halfW * 0.45f;
+        for (int i = 0; i < columns; i++) {
+            float x = -halfL * 0.85f + i * (2.0f * halfL * 0.85f / (columns - 1));
+            scene.take(new MeshInstance(scene.take(generateClosedCylinder(T(vec3(x, 330.0f, z), vec3(42.0f, 300.0f, 42.0f)), cylSlices)), columnMat));
+            scene.take(new MeshInstance(scene.take(generateCube(T(vec3(x, 15.0f, z), vec3(60.0f, 15.0f, 60.0f)), scaled(detail, 4, 1))), columnMat));
+            scene.take(new MeshInstance(scene.take(generateCube(T(vec3(x, 645.0f, z), vec3(58.0f, 15.0f, 58.0f)), scaled(detail, 4, 1))), columnMat));
+        }
+        scene.take(new MeshInstance(scene.take(generateCube(T(vec3(0.0f, 690.0f, z), vec3(halfL * 0.9f, 30.0f, 40.0f)), scaled(detail, 8, 1))), beamMat));
+    }
+    /* curtains between columns */
+    for (int i = 0; i < 9; i++) {
+        float x = -halfL * 0.7f + i * (2.0f * halfL * 0.7f / 8.0f);
+        float z = (i % 2 == 0 ? -1.0f : 1.0f) * halfW * 0.45f;
+        scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(x, 430.0f, z), vec3(95.0f, 190.0f, 1.0f), toQuat(radians(6.0f * (rng.u01() - 0.5f)), vec3(0.0f, 1.0f, 0.0f))),
+                            scaled(detail, 20, 1))), curtainMat[i % 3]));
+    }
+    /* vases and a mirror sphere on the floor */
+    const int sphSlices = scaled(detail, 128, 8), sphStacks = scaled(detail, 64, 4);
+    for (int i = 0; i < 6; i++) {
+        float x = -halfL * 0.6f + i * (2.0f * halfL * 0.6f / 5.0f) + 40.0f * (rng.u01() - 0.5f);
+        float z = (i % 2 == 0 ? -170.0f : 170.0f) + 60.0f * (rng.u01() - 0.5f);
+        float r = 35.0f + 25.0f * rng.u01();
+        scene.take(new MeshInstance(scene.take(generateSphere(T(vec3(x, r * 1.4f, z), vec3(r, r * 1.4f, r)), sphSlices, sphStacks)), i == 2 ? mirrorMat : vaseMat));
+    }
+
+    /* environment map with importance sampling */
+    Texture* sky = makeSky(scene, int(envWidth), int(envWidth / 2));
+    EnvironmentMap* env = scene.take(new EnvironmentMapEquiRect(sky));
+    if (importanceN > 0)
+        env->initializeImportanceSampling(importanceN);
+
+    /* camera of wurblpt-sponza.cpp:145-148 */
+    return wptHostFinish(scenePtr, width, height, radians(70.0f), vec3(0.0f, 1.7f, 0.0f), vec3(0.0f, 1.7f, -1.0f), 0.0f, 1.0f);
+}
