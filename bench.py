@@ -31,6 +31,8 @@ WORKLOADS = {
     # name: (builder kwargs, width, height, samples_sqrt)
     "cornell_1024x1024_1024spp_ggx_glass": dict(kind="cornell", tall=1, short=2, width=1024, height=1024, samples_sqrt=32),
     "cornell_256x256_64spp_lambertian": dict(kind="cornell", tall=0, short=0, width=256, height=256, samples_sqrt=8),
+    # BASELINE configs[2]: procedural Sponza-class stand-in (the real OBJ is not available offline)
+    "sponza_like_1920x1080_256spp_envmap_is": dict(kind="sponza", width=1920, height=1080, samples_sqrt=16),
 }
 
 
@@ -38,6 +40,8 @@ def build_scene(w):
     from wurblpt_amd import host
     if w["kind"] == "cornell":
         return host.cornell(w["width"], w["height"], w["tall"], w["short"])
+    if w["kind"] == "sponza":
+        return host.sponza_like(w["width"], w["height"], seed=1, detail=w.get("detail", 1.0))
     raise ValueError(w["kind"])
 
 

@@ -91,7 +91,7 @@ def test_scheduler_tuning_never_changes_results(dev, oracle, leave, heavy):
     try:
         got, _ = dev.DeviceScene(sc).render(4)
     finally:
-        dev.lib().wpt_set_launch_config(0, (3 << 8) | (25 << 16))
+        dev.lib().wpt_set_launch_config(0, (3 << 8) | (17 << 16) | (16 << 24))
     assert bits_equal(got, ref)
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <outdir-suffix> <bench args...>   (runs on the GPU box; separate --pmc passes)
+# usage: tools/pmc_sq.sh <outdir-suffix> <bench args...>   (runs on the GPU box; separate --pmc passes)
 export TMPDIR=/tmp
 SUF=$1; shift
 B="python3 bench.py $@ --no-cpu-baseline"

@@ -1,16 +1,21 @@
-"""Prints the wave scheduler's statistics for the Cornell GGX+glass frame (GPU box)."""
-import ctypes as C, sys
+"""usage: python tools/sched_stats.py [variant-word] [sponza]
+Prints the wave scheduler's statistics for the Cornell GGX+glass frame (GPU box)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wurblpt_amd import device, host
 var = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 if var:
     device.lib().wpt_set_launch_config(0, var)
-sc = host.cornell(1024, 1024, 1, 2)
+sc = host.sponza_like(1920, 1080) if (len(sys.argv) > 2 and sys.argv[2] == "sponza") else host.cornell(1024, 1024, 1, 2)
 ds = device.DeviceScene(sc)
 stats = torch.zeros(11, dtype=torch.int64, device="cuda")
 device.lib().wpt_set_scheduler_stats.argtypes = [C.c_void_p]
 device.lib().wpt_set_scheduler_stats(C.c_void_p(stats.data_ptr()))
-frame, cnt = ds.render(4, with_counters=True)
+frame, cnt = ds.render(2 if len(sys.argv) > 2 else 4, with_counters=True)
 s = [int(x) for x in stats.cpu().tolist()]
 n = cnt["samples"]
 print("per sample:", {k: round(v / n, 3) for k, v in cnt.items()})

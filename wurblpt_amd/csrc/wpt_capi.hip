@@ -89,7 +89,8 @@ namespace {
 uint32_t g_threadsPerGroup = WG;
 uint32_t g_variant = 0;
 uint32_t g_leaveEighths = 2;
-uint32_t g_heavyMin = 24;
+uint32_t g_heavyMin = 0; /* 0 = chosen per scene size at launch */
+uint32_t g_leafBias = 0;
 unsigned long long* g_schedStats = nullptr;
 
 template<typename T> wpt_status uploadArray(wpt_scene* s, const T* src, size_t count, const T** dst)
@@ -245,28 +246,55 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
         }                         \
     } while (0)
     {
-        /* Device node form: the reference pops a stack to find the next node after a subtree
-         * (bvh.hpp:296,305); in its depth-first array that node is the first one behind the
+        /* Device node form.  The reference pops a stack to find the next node after a subtree
+         * (bvh.hpp:296,305); in a depth-first array that node is the first one behind the
          * subtree, so it is stored per node ("skip") and the kernel needs no stack.
-         * skip(root) = node_count; for an inner node i: skip(i + 1) = link(i), skip(link(i)) = skip(i). */
+         * Eight copies of the tree are stored, one per sign octant of the ray direction: copy k
+         * lists at every inner node first the child that is nearer for such rays along the
+         * node's split axis (the builder sorts by centre along the longest axis of the node's
+         * box, bvh.hpp:110-113, and the left child takes the low side).  Copy 0 (all signs
+         * positive) is the reference's own order: left child first everywhere. */
         const uint32_t n = desc->node_count;
-        std::vector<uint32_t> skip(n, n);
-        for (uint32_t i = 0; i < n; i++) {
-            const wpt_bvh_node& nd = desc->nodes[i];
-            if (nd.kind == WPT_NODE_INNER) {
-                skip[i + 1] = nd.link;
-                skip[nd.link] = skip[i];
+        std::vector<float4> dev(size_t(n) * 2 * 8);
+        struct Item { uint32_t src; uint32_t pos; bool done; };
+        for (uint32_t oct = 0; oct < 8; oct++) {
+            float4* out = dev.data() + size_t(oct) * n * 2;
+            uint32_t cursor = 0;
+            std::vector<Item> stack;
+            stack.push_back(Item { 0, 0, false });
+            while (!stack.empty()) {
+                Item it = stack.back();
+                stack.pop_back();
+                const wpt_bvh_node& nd = desc->nodes[it.src];
+                if (it.done) {
+                    /* subtree emitted: its skip link is the next free position */
+                    float sk;
+                    memcpy(&sk, &cursor, 4);
+                    out[2 * size_t(it.pos) + 1].z = sk;
+                    continue;
+                }
+                const uint32_t pos = cursor++;
+                const uint32_t prim = nd.kind == WPT_NODE_INNER ? NODE_INNER : nd.kind == WPT_NODE_TRIANGLE ? nd.link : NODE_EMPTY;
+                float pr;
+                memcpy(&pr, &prim, 4);
+                out[2 * size_t(pos)] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0]);
+                out[2 * size_t(pos) + 1] = make_float4(nd.hi[1], nd.hi[2], 0.0f, pr);
+                stack.push_back(Item { it.src, pos, true });
+                if (nd.kind == WPT_NODE_INNER) {
+                    /* AABB::longestAxis (aabb.hpp:52-62) */
+                    const float l0 = nd.hi[0] - nd.lo[0], l1 = nd.hi[1] - nd.lo[1], l2 = nd.hi[2] - nd.lo[2];
+                    int axis = 2;
+                    if (l0 > l1 && l0 > l2)
+                        axis = 0;
+                    else if (l1 > l2)
+                        axis = 1;
+                    const bool leftFirst = ((oct >> axis) & 1u) == 0;
+                    const uint32_t first = leftFirst ? it.src + 1 : nd.link;
+                    const uint32_t second = leftFirst ? nd.link : it.src + 1;
+                    stack.push_back(Item { second, 0, false }); /* popped after the first subtree */
+                    stack.push_back(Item { first, 0, false });
+                }
             }
-        }
-        std::vector<float4> dev(size_t(n) * 2);
-        for (uint32_t i = 0; i < n; i++) {
-            const wpt_bvh_node& nd = desc->nodes[i];
-            const uint32_t prim = nd.kind == WPT_NODE_INNER ? NODE_INNER : nd.kind == WPT_NODE_TRIANGLE ? nd.link : NODE_EMPTY;
-            float sk, pr;
-            memcpy(&sk, &skip[i], 4);
-            memcpy(&pr, &prim, 4);
-            dev[2 * size_t(i)] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0]);
-            dev[2 * size_t(i) + 1] = make_float4(nd.hi[1], nd.hi[2], sk, pr);
         }
         UP(uploadArray(s, dev.data(), dev.size(), &nodes));
     }
@@ -386,13 +414,19 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     args.schedStats = g_schedStats;
     /* a wave covers an 8x8 pixel tile when the block consists of whole groups of 8 rows */
     args.leaveEighths = g_leaveEighths;
-    args.heavyMin = g_heavyMin;
+
     args.tiled = (width % 8 == 0 && block_start % width == 0 && block_size % (8 * width) == 0) ? 1u : 0u;
     uint32_t need = scene->features | (camera->lens_radius > 0.0f ? FEAT_LENS : 0u);
     dim3 grid((block_size + WG - 1) / WG);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const bool count = counters_device != nullptr;
-    const size_t ldsBytes = size_t(scene->nodeCount) * 32 + size_t(scene->triCount) * 48;
+    const size_t ldsBytes = size_t(scene->nodeCount) * 32 * (ORDERED_KERNELS ? 8 : 1) + size_t(scene->triCount) * 48;
+    /* scheduler defaults from sweeps on the Cornell box (scene in LDS, short walks) and on the
+     * Sponza-class scene (deep tree in HBM: traversal dominates, so long blocks may run with fewer
+     * lanes and leaf tests earlier) */
+    const bool smallScene = ldsBytes <= LDS_SCENE_MAX_BYTES;
+    args.heavyMin = g_heavyMin ? g_heavyMin : (smallScene ? 16u : 8u);
+    args.leafBias = g_leafBias ? g_leafBias : (smallScene ? 16u : 32u);
     if ((need & ~FEAT_BASIC) == 0 && g_variant != 2) {
         if (count)
             launchBasicCount(args, grid, stream);
@@ -443,6 +477,8 @@ wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant)
         g_leaveEighths = ((variant >> 8) & 0xffu) - 1; /* byte 1: leave threshold in eighths, plus one */
     if ((variant >> 16) & 0xffu)
         g_heavyMin = ((variant >> 16) & 0xffu) - 1;     /* byte 2: lanes a long block needs, plus one */
+    if ((variant >> 24) & 0xffu)
+        g_leafBias = (variant >> 24) & 0xffu;           /* byte 3: leaf bias */
     return WPT_OK;
 }
 

@@ -248,44 +248,50 @@ struct Ray {
     f4 ri; /* refractiveIndex */
 };
 /* RayIntersectionHelper (hitable.hpp:66-113) */
+/* Kept per ray in registers while it traverses, so it is small: the axis permutation is
+ * packed into one word (kx | ky << 2 | kz << 4) and S.z, which equals inv[kz], is not stored. */
 struct RayAux {
     f3 inv;
-    int kx, ky, kz;
-    f3 S;
+    int k;
+    float Sx, Sy;
 };
+WPT_D int auxKx(const RayAux& h) { return h.k & 3; }
+WPT_D int auxKy(const RayAux& h) { return (h.k >> 2) & 3; }
+WPT_D int auxKz(const RayAux& h) { return (h.k >> 4) & 3; }
 WPT_D RayAux rayAux(f3 dir)
 {
     RayAux h;
     h.inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     float ax = __builtin_fabsf(dir.x), ay = __builtin_fabsf(dir.y), az = __builtin_fabsf(dir.z);
+    int kx, ky, kz;
     if (az >= ay && az >= ax)
-        h.kz = 2;
+        kz = 2;
     else if (ay >= ax)
-        h.kz = 1;
+        kz = 1;
     else
-        h.kz = 0;
-    h.kx = h.kz + 1;
-    if (h.kx == 3)
-        h.kx = 0;
-    h.ky = h.kx + 1;
-    if (h.ky == 3)
-        h.ky = 0;
-    if (comp(dir, h.kz) < 0.0f) {
-        int tmp = h.kx;
-        h.kx = h.ky;
-        h.ky = tmp;
+        kz = 0;
+    kx = kz + 1;
+    if (kx == 3)
+        kx = 0;
+    ky = kx + 1;
+    if (ky == 3)
+        ky = 0;
+    if (comp(dir, kz) < 0.0f) {
+        int tmp = kx;
+        kx = ky;
+        ky = tmp;
     }
-    float invz = comp(h.inv, h.kz);
-    h.S.x = comp(dir, h.kx) * invz;
-    h.S.y = comp(dir, h.ky) * invz;
-    h.S.z = invz;
+    float invz = comp(h.inv, kz);
+    h.Sx = comp(dir, kx) * invz;
+    h.Sy = comp(dir, ky) * invz;
+    h.k = kx | (ky << 2) | (kz << 4);
     return h;
 }
 
 /* what survives of a triangle candidate: enough to rebuild the HitRecord later */
 struct Candidate {
     uint32_t prim; /* 0xffffffff = no hit */
-    float a, invDet, U, V, W, det;
+    float a, invDet, U, V, W; /* det itself is not kept: its sign is the sign of invDet */
 };
 
 /* Watertight test (hitable_triangle.hpp:189-271).  Returns true and fills c when accepted. */
@@ -294,13 +300,15 @@ WPT_D bool triangleTest(f3 v0, f3 v1, f3 v2, f3 org, const RayAux& h, float amin
     const f3 A = sub(v0, org);
     const f3 B = sub(v1, org);
     const f3 C = sub(v2, org);
-    const float Akz = comp(A, h.kz), Bkz = comp(B, h.kz), Ckz = comp(C, h.kz);
-    const float Ax = comp(A, h.kx) - h.S.x * Akz;
-    const float Ay = comp(A, h.ky) - h.S.y * Akz;
-    const float Bx = comp(B, h.kx) - h.S.x * Bkz;
-    const float By = comp(B, h.ky) - h.S.y * Bkz;
-    const float Cx = comp(C, h.kx) - h.S.x * Ckz;
-    const float Cy = comp(C, h.ky) - h.S.y * Ckz;
+    const int kx = auxKx(h), ky = auxKy(h), kz = auxKz(h);
+    const float Sz = comp(h.inv, kz);
+    const float Akz = comp(A, kz), Bkz = comp(B, kz), Ckz = comp(C, kz);
+    const float Ax = comp(A, kx) - h.Sx * Akz;
+    const float Ay = comp(A, ky) - h.Sy * Akz;
+    const float Bx = comp(B, kx) - h.Sx * Bkz;
+    const float By = comp(B, ky) - h.Sy * Bkz;
+    const float Cx = comp(C, kx) - h.Sx * Ckz;
+    const float Cy = comp(C, ky) - h.Sy * Ckz;
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;
     float W = Bx * Ay - By * Ax;
@@ -320,9 +328,9 @@ WPT_D bool triangleTest(f3 v0, f3 v1, f3 v2, f3 org, const RayAux& h, float amin
     float det = U + V + W;
     if (det == 0.0f)
         return false;
-    const float Az = h.S.z * Akz;
-    const float Bz = h.S.z * Bkz;
-    const float Cz = h.S.z * Ckz;
+    const float Az = Sz * Akz;
+    const float Bz = Sz * Bkz;
+    const float Cz = Sz * Ckz;
     const float T = U * Az + V * Bz + W * Cz;
     const uint32_t sgn = wptm::float_to_bits(det) & 0x80000000u;
     const float Ts = wptm::bits_to_float(wptm::float_to_bits(T) ^ sgn);
@@ -335,7 +343,6 @@ WPT_D bool triangleTest(f3 v0, f3 v1, f3 v2, f3 org, const RayAux& h, float amin
     c.U = U;
     c.V = V;
     c.W = W;
-    c.det = det;
     return true;
 }
 
@@ -397,7 +404,7 @@ WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir)
     const uint32_t instance = __float_as_uint(g0.w);
     h.material = __float_as_uint(g1.w);
     const uint32_t flags = __float_as_uint(g2.w);
-    const bool backfacing = c.det < 0.0f;
+    const bool backfacing = c.invDet < 0.0f; /* det < 0 (hitable_triangle.hpp:274) */
     const float bx = c.invDet * c.U, by = c.invDet * c.V, bz = c.invDet * c.W;
     h.p = add(org, scl(c.a, dir));
     const float4* at = sv.triAttr + 6 * (size_t)c.prim;

@@ -46,6 +46,11 @@ constexpr uint32_t NO_HIT = 0xffffffffu;
 constexpr uint32_t NODE_INNER = 0xffffffffu; /* device node: marker in the primitive slot */
 constexpr uint32_t NODE_EMPTY = 0xfffffffeu;
 constexpr uint32_t LDS_SCENE_MAX_BYTES = 48 * 1024;
+/* Near-first walk over the octant copies of the BVH (template parameter ORDERED).  Measured on
+ * the Sponza-class scene: only 10 % fewer node visits (1112 vs 1243 per sample; the reference's
+ * tree is 50 levels deep, so most visits are the two boxes per level on the way down) for 4 more
+ * registers per lane, which costs more than it saves.  Kept as an option, switched off. */
+constexpr bool ORDERED_KERNELS = false;
 
 struct KernelArgs {
     SceneView sv;
@@ -55,7 +60,8 @@ struct KernelArgs {
     uint32_t blockStart, blockSize;
     uint32_t tiled; /* 1: a wave covers an 8x8 pixel tile (block is whole rows, multiple of 8) */
     uint32_t leaveEighths; /* scheduler: leave the NODE loop when fewer than this many eighths of the entering lanes remain */
-    uint32_t heavyMin;     /* scheduler: lanes a long block needs before it runs (0: most-populated-state policy) */
+    uint32_t heavyMin;     /* scheduler: lanes a long block needs before it runs */
+    uint32_t leafBias;     /* scheduler: leaf tests run when waiting lanes * leafBias >= walking lanes * 8 */
     float* frame;
     wpt_counters* counters;
     unsigned long long* schedStats; /* COUNT builds: 11 scheduler statistics, or NULL */
@@ -99,7 +105,7 @@ __device__ __forceinline__ void accumulate(const wpt_params& par, f3 opl, float 
         a2 += radiance.z;
 }
 
-template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC>
+template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, bool ORDERED>
 __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 {
     extern __shared__ float4 ldsScene[];
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 
     if (LDSSCENE) {
         /* nodes (2 x float4 each) followed by the triangle positions (3 x float4 each) */
-        const uint32_t n4 = 2 * nodeCount, t4 = 3 * sv.triCount;
+        const uint32_t n4 = 2 * nodeCount * (ORDERED ? 8u : 1u), t4 = 3 * sv.triCount;
         for (uint32_t i = threadIdx.x; i < n4; i += WG)
             ldsScene[i] = sv.nodes[i];
         for (uint32_t i = threadIdx.x; i < t4; i += WG)
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     };
     auto tri4 = [&](uint32_t i) -> float4 {
         if constexpr (LDSSCENE)
-            return ldsScene[2 * nodeCount + i];
+            return ldsScene[2 * nodeCount * (ORDERED ? 8u : 1u) + i];
         else
             return sv.triGeom[i];
     };
@@ -174,14 +180,17 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     /* traversal registers */
     RayAux aux = rayAux(ray.d);
     uint32_t node = 0, leafPrim = 0;
+    uint32_t nodeBase = 0; /* ORDERED: first node of the ray's octant copy of the BVH */
+    bool exact = !ORDERED; /* true: the reference's own walk (copy 0, exact bounds) */
     float amax = k_maxval;
+    float amaxCull = k_maxval, second = k_maxval; /* ORDERED: widened bound, 2nd closest candidate */
     Candidate best;
     best.prim = NO_HIT;
-    best.a = best.invDet = best.U = best.V = best.W = best.det = 0.0f;
+    best.a = best.invDet = best.U = best.V = best.W = 0.0f;
     /* pending continuation of the path while a next-event ray is in flight */
-    f4 nextAtt = att, directAtt = att, srRi = att;
+    f4 nextAtt = att;
+    f4 neeFactor = att; /* attenuation * directSR.attenuation / directPdf * weight (wurblpt.hpp:211,243), complete except for the emitted radiance */
     f3 srDir = ray.d;
-    float directPdf = 0.0f, neeWeight = 0.0f;
     uint32_t chosenPrim = NO_HIT;
 
     auto beginRay = [&](int kind) {
@@ -189,12 +198,36 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         node = 0;
         amax = k_maxval;
         best.prim = NO_HIT;
+        if (ORDERED) {
+            const uint32_t octant = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
+            nodeBase = octant * nodeCount;
+            exact = false;
+            amaxCull = k_maxval;
+            second = k_maxval;
+        }
         rayKind = kind;
         state = S_NODE;
         if (COUNT)
             lc.rays++;
     };
-    auto endOfRayState = [&]() { return rayKind == RAY_PATH ? S_SHADE : S_NEEEND; };
+    /* State after the walk has left the tree.  ORDERED: the near-first walk found the closest
+     * candidate `best` and the runner-up distance `second`; if no other candidate lies within
+     * (1 + 2^-13) of it, the reference's unordered walk must end with the same candidate (it
+     * accepts it whenever it reaches it, and nothing can replace it).  Otherwise candidates
+     * tie and the winner depends on the reference's visiting order, so the ray walks again in
+     * exactly that order (copy 0, exact bounds) starting from amax = best.a * (1 + 2^-13),
+     * which gives the reference's result: everything farther is superseded in its walk anyway. */
+    auto endOfRayState = [&]() {
+        if (ORDERED && !exact && best.prim != NO_HIT && !(second > best.a * 1.0001220703125f)) {
+            exact = true;
+            nodeBase = 0;
+            node = 0;
+            amax = best.a * 1.0001220703125f;
+            best.prim = NO_HIT;
+            return (int)S_NODE;
+        }
+        return rayKind == RAY_PATH ? (int)S_SHADE : (int)S_NEEEND;
+    };
 
     /* mean pdf over all hot spots of hitting them from org along dir (wurblpt.hpp:181-184) */
     auto hotSpotsMeanPdf = [&](f3 org, f3 dir) {
@@ -215,7 +248,6 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     auto advancePath = [&]() {
         att = nextAtt;
         ray.d = srDir;
-        ray.ri = srRi;
         const float mx = max4(att);
         if (mx < par.rr_threshold && pathComponent >= 5) {
             const float q = clampr(1.0f - mx, 0.0f, 0.95f);
@@ -231,36 +263,29 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     };
 
     for (;;) {
-        /* ---- the wave's scheduler: run the most populated state ---- */
-        const int cNode = __popcll(__ballot(state == S_NODE));
-        const int cLeaf = __popcll(__ballot(state == S_LEAF));
+        /* ---- the wave's scheduler ----
+         * Traversal (NODE steps and LEAF tests) is one block with its own inner policy; the long
+         * blocks (SHADE, NEE-END, NEW) run when they are well filled, or when no traversal work
+         * is left in the wave.  Waiting lanes lose nothing but time: every lane still executes
+         * its own operations in order. */
+        const int cTrav = __popcll(__ballot(state == S_NODE || state == S_LEAF));
         const int cShade = __popcll(__ballot(state == S_SHADE));
         const int cNee = __popcll(__ballot(state == S_NEEEND));
         const int cNew = __popcll(__ballot(state == S_NEW));
-        if ((cNode | cLeaf | cShade | cNee | cNew) == 0)
+        if ((cTrav | cShade | cNee | cNew) == 0)
             break;
         int pick;
-        if (args.heavyMin == 0) {
-            /* policy 0: the most populated state */
-            int most = cNode;
-            pick = S_NODE;
-            if (cLeaf > most) { pick = S_LEAF; most = cLeaf; }
-            if (cShade > most) { pick = S_SHADE; most = cShade; }
-            if (cNee > most) { pick = S_NEEEND; most = cNee; }
-            if (cNew > most) { pick = S_NEW; most = cNew; }
-        } else {
-            /* policy 1: the long blocks (SHADE, NEE-END, NEW) run only when they are well
-             * filled, or when no traversal work is left in the wave; the short traversal
-             * blocks take whatever lanes they have */
-            const int heavyMin = (int)args.heavyMin;
+        {
+            /* at least 1: a block must never be picked with no lane in it */
+            const int heavyMin = (int)args.heavyMin < 1 ? 1 : (int)args.heavyMin;
             if (cShade >= heavyMin) {
                 pick = S_SHADE;
             } else if (cNee >= heavyMin) {
                 pick = S_NEEEND;
             } else if (cNew >= heavyMin) {
                 pick = S_NEW;
-            } else if ((cNode | cLeaf) != 0) {
-                pick = cLeaf > cNode ? S_LEAF : S_NODE;
+            } else if (cTrav != 0) {
+                pick = S_NODE;
             } else {
                 int most = cShade;
                 pick = S_SHADE;
@@ -270,55 +295,77 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         }
 
         if (pick == S_NODE) {
-            /* AABB::mayHit + the stackless form of BVH::hit's walk.  Stay while at least half
-             * of the lanes that entered are still walking. */
-            /* never below 1: the loop must end when no lane is left in it */
-            int leaveBelow = (cNode * (int)args.leaveEighths + 7) >> 3;
+            /* Leave when fewer than leaveEighths/8 of the entering lanes are still traversing
+             * (never below 1: the loop must end when no lane is left in it). */
+            int leaveBelow = (cTrav * (int)args.leaveEighths + 7) >> 3;
             leaveBelow = leaveBelow < 1 ? 1 : leaveBelow;
-            if (COUNT) {
+            if (COUNT)
                 sched[0]++;
-            }
-            do {
-                if (COUNT) {
-                    sched[1]++;
-                    sched[2] += __popcll(__ballot(state == S_NODE));
+            for (;;) {
+                const int nNode = __popcll(__ballot(state == S_NODE));
+                const int nLeaf = __popcll(__ballot(state == S_LEAF));
+                if (nNode + nLeaf < leaveBelow)
+                    break;
+                /* a leaf test is ~3 node steps long; it runs once enough lanes wait for it
+                 * (leafBias/8 of the walking lanes), because waiting lanes thin out the walk */
+                if (nLeaf * (int)args.leafBias >= nNode * 8 && nLeaf > 0) {
+                    if (COUNT) {
+                        sched[3]++;
+                        sched[4] += nLeaf;
+                    }
+                    if (state == S_LEAF) {
+                        /* HitableTriangle::hit, candidate part (hitable_triangle.hpp:189-271) */
+                        if (COUNT)
+                            lc.leaves++;
+                        const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
+                        Candidate c;
+                        const float bound = (ORDERED && !exact) ? amaxCull : amax;
+                        if (triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), ray.o, aux,
+                                    par.min_hit_distance, bound, c)) {
+                            c.prim = leafPrim;
+                            if (ORDERED && !exact) {
+                                /* keep the closest; remember how close the runner-up came */
+                                if (best.prim == NO_HIT || c.a < best.a) {
+                                    second = best.prim != NO_HIT && best.a < second ? best.a : second;
+                                    best = c;
+                                    amax = c.a;
+                                    amaxCull = amax * 1.000244140625f; /* 1 + 2^-12 */
+                                } else {
+                                    second = c.a < second ? c.a : second;
+                                }
+                            } else {
+                                best = c;
+                                amax = c.a;
+                            }
+                        }
+                        node = node + 1; /* a leaf's subtree is the leaf itself */
+                        state = node >= nodeCount ? endOfRayState() : S_NODE;
+                    }
+                } else {
+                    if (COUNT) {
+                        sched[1]++;
+                        sched[2] += nNode;
+                    }
+                    if (state == S_NODE) {
+                        /* AABB::mayHit + the stackless form of BVH::hit's walk */
+                        const float4 n0 = node4(2 * (nodeBase + node));
+                        const float4 n1 = node4(2 * (nodeBase + node) + 1);
+                        if (COUNT)
+                            lc.nodes++;
+                        const uint32_t skip = __float_as_uint(n1.z);
+                        const uint32_t prim = __float_as_uint(n1.w);
+                        const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray.o, aux.inv, par.min_hit_distance,
+                                (ORDERED && !exact) ? amaxCull : amax);
+                        /* select form of: hit & inner -> next node; hit & leaf -> test it; else -> skip */
+                        const bool toLeaf = hit && prim < NODE_EMPTY;
+                        const uint32_t next = (hit && prim == NODE_INNER) ? node + 1 : skip;
+                        leafPrim = toLeaf ? prim : leafPrim;
+                        node = toLeaf ? node : next;
+                        state = toLeaf ? (int)S_LEAF : (int)S_NODE;
+                        if (!toLeaf && node >= nodeCount)
+                            state = endOfRayState();
+                    }
                 }
-                if (state == S_NODE) {
-                    const float4 n0 = node4(2 * node);
-                    const float4 n1 = node4(2 * node + 1);
-                    if (COUNT)
-                        lc.nodes++;
-                    const uint32_t skip = __float_as_uint(n1.z);
-                    const uint32_t prim = __float_as_uint(n1.w);
-                    const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray.o, aux.inv, par.min_hit_distance, amax);
-                    /* select form of: hit & inner -> next node; hit & leaf -> test it; else -> skip */
-                    const bool toLeaf = hit && prim < NODE_EMPTY;
-                    const uint32_t next = (hit && prim == NODE_INNER) ? node + 1 : skip;
-                    leafPrim = toLeaf ? prim : leafPrim;
-                    node = toLeaf ? node : next;
-                    const int after = node >= nodeCount ? (rayKind == RAY_PATH ? S_SHADE : S_NEEEND) : S_NODE;
-                    state = toLeaf ? S_LEAF : after;
-                }
-            } while (__popcll(__ballot(state == S_NODE)) >= leaveBelow);
-        } else if (pick == S_LEAF) {
-            if (COUNT) {
-                sched[3]++;
-                sched[4] += cLeaf;
-            }
-            if (state == S_LEAF) {
-                /* HitableTriangle::hit, candidate part (hitable_triangle.hpp:189-271) */
-                if (COUNT)
-                    lc.leaves++;
-                const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
-                Candidate c;
-                if (triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), ray.o, aux,
-                            par.min_hit_distance, amax, c)) {
-                    c.prim = leafPrim;
-                    best = c;
-                    amax = c.a;
-                }
-                node = node + 1; /* a leaf's subtree is the leaf itself */
-                state = node >= nodeCount ? endOfRayState() : S_NODE;
             }
         } else if (pick == S_SHADE) {
             if (COUNT) {
@@ -358,7 +405,6 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                                     nextAtt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
                             }
                             srDir = sr.dir;
-                            srRi = sr.ri;
                             bool shootNee = false;
                             if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
                                 /* light sampling with MIS (wurblpt.hpp:179-220) */
@@ -373,12 +419,13 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                                 if (hs.transform)
                                     p = mat4mulPoint(hs.M, p);
                                 const f3 directDir = normalize(sub(p, h.p));
-                                directPdf = hotSpotsMeanPdf(h.p, directDir);
+                                const float directPdf = hotSpotsMeanPdf(h.p, directDir);
                                 if (directPdf > 0.0f) {
                                     float dpdf;
+                                    f4 directAtt;
                                     materialEval<F>(sv, m, ray, h, directDir, directAtt, dpdf);
                                     if (dpdf > 0.0f) {
-                                        neeWeight = powerHeuristicWeight(directPdf, dpdf);
+                                        neeFactor = sclr(divs(mul(att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
                                         chosenPrim = hs.prim;
                                         ray.o = h.p;
                                         ray.d = directDir;
@@ -391,19 +438,26 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                                 const float lightsP = envP(sv, sr.dir);
                                 nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, lightsP));
                                 const f3 lightDir = envD(sv, prng);
-                                directPdf = envP(sv, lightDir);
+                                const float directPdf = envP(sv, lightDir);
                                 float dpdf;
+                                f4 directAtt;
                                 materialEval<F>(sv, m, ray, h, lightDir, directAtt, dpdf);
                                 if (dpdf > 0.0f) {
-                                    neeWeight = powerHeuristicWeight(directPdf, dpdf);
+                                    neeFactor = sclr(divs(mul(att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
                                     ray.o = h.p;
                                     ray.d = lightDir;
                                     shootNee = true;
                                     beginRay(RAY_NEE_ENV);
                                 }
                             }
+                            /* The scattered ray's refractive index: every ScatterRandom record
+                             * carries the incoming ray's index unchanged (material_lambertian.hpp:83,
+                             * material_ggx.hpp:224, material_modphong.hpp:307), so while a next-event
+                             * ray is in flight ray.ri already is the value to continue with; only
+                             * explicit scattering (glass, transparent ModPhong) changes it. */
                             if (!shootNee) {
                                 ray.o = h.p;
+                                ray.ri = sr.ri;
                                 advancePath();
                             }
                         }
@@ -421,13 +475,13 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                     if (best.prim == chosenPrim) {
                         Hit lh = finishHit(sv, best, ray.o, ray.d);
                         const wpt_material& lm = resolveMaterial<F>(sv, lh.material, lh);
-                        f4 rad = mul(sclr(divs(mul(att, directAtt), directPdf), neeWeight), materialEmitted<F>(sv, lm, lh));
+                        f4 rad = mul(neeFactor, materialEmitted<F>(sv, lm, lh));
                         f3 oplLight = add(opl, scl(lh.a, mk3(ray.ri.x, ray.ri.y, ray.ri.z)));
                         accumulate(par, oplLight, lh.a, rad, acc0, acc1, acc2);
                     }
                 } else if (F & FEAT_ENVMAP) {
                     if (best.prim == NO_HIT) {
-                        f4 rad = mul(sclr(divs(mul(att, directAtt), directPdf), neeWeight), envL(sv, ray.d));
+                        f4 rad = mul(neeFactor, envL(sv, ray.d));
                         accumulate(par, mk3(k_maxval, k_maxval, k_maxval), k_maxval, rad, acc0, acc1, acc2);
                     }
                 }

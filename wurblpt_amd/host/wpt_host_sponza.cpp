@@ -215,7 +215,7 @@ extern "C" wpt_host_scene* wpt_host_sponza_like(unsigned int seed, float detail,
     const float halfL = 1400.0f, halfW = 600.0f, wallH = 1100.0f;
 
     /* floor: the largest share of the triangles, like Sponza's tiled floor */
-    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f), vec3(halfL, halfW, 1.0f), layFlat), scaled(detail, 300, 2))), floorMat));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f), vec3(halfL, halfW, 1.0f), layFlat), scaled(detail, 270, 2))), floorMat));
     /* four walls */
     const int ws = scaled(detail, 64, 1);
     scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH * 0.5f, -halfW), vec3(halfL, wallH * 0.5f, 1.0f)), ws)), wallMat));
@@ -247,7 +247,7 @@ extern "C" wpt_host_scene* wpt_host_sponza_like(unsigned int seed, float detail,
                             scaled(detail, 20, 1))), curtainMat[i % 3]));
     }
     /* vases and a mirror sphere on the floor */
-    const int sphSlices = scaled(detail, 128, 8), sphStacks = scaled(detail, 64, 4);
+    const int sphSlices = scaled(detail, 96, 8), sphStacks = scaled(detail, 48, 4);
     for (int i = 0; i < 6; i++) {
         float x = -halfL * 0.6f + i * (2.0f * halfL * 0.6f / 5.0f) + 40.0f * (rng.u01() - 0.5f);
         float z = (i % 2 == 0 ? -170.0f : 170.0f) + 60.0f * (rng.u01() - 0.5f);
