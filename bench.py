@@ -76,6 +76,8 @@ def cpu_baseline(scene, w, target_seconds):
     orc = oracle_loader.load("portable")
     width, height = w["width"], w["height"]
     cores = host_cores()
+    if scene.d.envmap.type != 0 and scene.d.envmap.N > 0 and not scene.d.envmap.M:
+        scene.set_envmap_tables(*orc.envmap_tables(scene))  # the CPU side builds its own importance tables
 
     def run(pixels):
         pixels = max(width, min(pixels - pixels % width, width * height))

@@ -1320,6 +1320,8 @@ int wpt_oracle_render(const wpt_scene_desc* scene, const wpt_camera* camera, con
         return 1;
     if (uint64_t(block_start) + block_size > uint64_t(width) * height)
         return 1;
+    if (scene->envmap.type != WPT_ENV_NONE && scene->envmap.N > 0 && (!scene->envmap.M || !scene->envmap.Ms || !scene->envmap.Mcs))
+        return 2; /* importance tables requested but not attached: see wpt_oracle_envmap_tables */
     unsigned int samples = samples_sqrt * samples_sqrt;
     float invSamples = 1.0f / samples;
     float invSamplesSqrt = 1.0f / samples_sqrt;
