@@ -15,8 +15,8 @@
  *   wpt_render_block()   replaces one iteration of the block loop: the OpenMP pixel loop,
  *                        Prng(pixel), the sample loop, Camera::getRay, tracePath and
  *                        Sensor::finishPixel (wurblpt.hpp:319-383, sensor_rgb.hpp:63-87)
- *   wpt_block_queue_*    replace MPICoordinator::getBlock/submitBlock (mpi.hpp:241-262)
- *                        for several GPUs driven from one process
+ *   MPICoordinator::getBlock/submitBlock (mpi.hpp:241-262) stay on the caller's side: blocks are
+ *   plain (start, size) arguments (include/wurblpt/mpi.hpp, wurblpt_amd/blocks.py)
  *
  * All structs are plain C PODs; the caller keeps ownership of everything it
  * passes in (the callee copies during wpt_scene_upload).  No C++ types, no
@@ -258,6 +258,10 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera,
 wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera,
         const wpt_params* params, uint32_t width, uint32_t height, uint32_t samples_sqrt,
         uint32_t block_start, uint32_t block_size, float* block_rgb);
+
+/* Waits for the device; WPT_ERR_HIP if a launch on this scene aborted (every wait inside the
+ * kernels is bounded, so a protocol failure ends the launch instead of hanging the GPU). */
+wpt_status wpt_scene_check(wpt_scene* scene);
 
 /* Kernel launch geometry knobs (0 = default); for benchmarking only, results do not change. */
 wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant);

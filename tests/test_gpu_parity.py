@@ -69,9 +69,10 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 0x10, 0x11, 0x12])
 def test_kernel_variants_agree_bit_for_bit(dev, oracle, variant):
-    """0 = scene in LDS, 1 = scene fetched from HBM/L2, 2 = the all-features kernel"""
+    """0 = scene in LDS, 1 = scene fetched from HBM/L2, 2 = the all-features kernel;
+    +0x10 = the same three instantiations of the workgroup ray-pool kernel"""
     sc = host.cornell(64, 48, 1, 2)
     ref, _ = oracle.render(sc, 5)
     dev.lib().wpt_set_launch_config(0, variant)
@@ -91,7 +92,7 @@ def test_scheduler_tuning_never_changes_results(dev, oracle, leave, heavy):
     try:
         got, _ = dev.DeviceScene(sc).render(4)
     finally:
-        dev.lib().wpt_set_launch_config(0, (3 << 8) | (17 << 16) | (16 << 24))
+        dev.lib().wpt_set_launch_config(0, 0)
     assert bits_equal(got, ref)
 
 
@@ -231,6 +232,12 @@ def test_sponza_like_textures_modphong_envmap_bit_exact(dev, oracle):
     assert gc == rc
     got2, _ = dev.DeviceScene(sc).render(4)  # tables handed in by the caller
     assert bits_equal(got2, ref)
+    dev.lib().wpt_set_launch_config(0, 0x10)  # the ray-pool kernel, all features, scene in HBM
+    try:
+        got3, _ = ds.render(4)
+    finally:
+        dev.lib().wpt_set_launch_config(0, 0)
+    assert bits_equal(got3, ref)
 
 
 def test_sponza_like_without_importance_sampling(dev, oracle):

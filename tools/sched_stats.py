@@ -15,7 +15,13 @@ ds = device.DeviceScene(sc)
 stats = torch.zeros(11, dtype=torch.int64, device="cuda")
 device.lib().wpt_set_scheduler_stats.argtypes = [C.c_void_p]
 device.lib().wpt_set_scheduler_stats(C.c_void_p(stats.data_ptr()))
-frame, cnt = ds.render(2 if len(sys.argv) > 2 else 4, with_counters=True)
+spp_sqrt = 2 if len(sys.argv) > 2 else 4
+frame, cnt = ds.render(spp_sqrt, with_counters=True)
+if len(sys.argv) > 3 and sys.argv[3] == "pool":
+    # statistics of the ray-pool kernel: work counters from the counted launch above, scheduler
+    # statistics from an uncounted launch
+    stats.zero_()
+    ds.render(spp_sqrt)
 s = [int(x) for x in stats.cpu().tolist()]
 n = cnt["samples"]
 print("per sample:", {k: round(v / n, 3) for k, v in cnt.items()})

@@ -1,0 +1,294 @@
+/*
+ * wpt_blocks.h -- the per-path logic of the integrator as three device functions that a
+ * kernel runs for the lanes whose path is at that point:
+ *
+ *   blockNew     start the pixel's next sample: jitter, Camera::getRay (wurblpt.hpp:348-360)
+ *   blockShade   one path component after its ray came back: emission, scatter, next-event
+ *                set-up with MIS (wurblpt.hpp:131-252)
+ *   blockNeeEnd  the next-event ray came back: add its contribution (wurblpt.hpp:203-218,236-250)
+ *
+ * each followed by `advancePath` (wurblpt.hpp:254-273) where the path continues.  They return
+ * what the lane needs next: a ray to be traced (ps.ray / ps.rayKind are set), a new sample, or
+ * nothing more (all samples done).  The traversal of the ray is the kernel's business.
+ */
+#ifndef WPT_BLOCKS_H
+#define WPT_BLOCKS_H
+
+#include "wpt_device.h"
+
+namespace wptk {
+
+using namespace wptd;
+
+constexpr uint32_t NO_HIT = 0xffffffffu;
+
+enum { RAY_PATH = 0, RAY_NEE_LIGHT = 1, RAY_NEE_ENV = 2 };
+enum { NEXT_TRACE = 0, NEXT_NEW = 1, NEXT_DONE = 2 };
+
+struct LaneCounters {
+    uint32_t rays, nodes, leaves, pdfs, scatters;
+};
+
+/* everything a pixel's path carries between blocks (registers) */
+struct PathState {
+    Prng prng;
+    float acc0, acc1, acc2;
+    uint32_t px, py;
+    uint32_t sampleIndex, pathComponent;
+    int rayKind;
+    Ray ray;
+    f4 att;
+    f3 opl; /* opticalPathLength; SensorRGB reads channels 0..2 only */
+    /* continuation of the path while a next-event ray is in flight */
+    f4 nextAtt;
+    f4 neeFactor; /* attenuation * directSR.attenuation / directPdf * weight (wurblpt.hpp:211,243) */
+    f3 srDir;
+    uint32_t chosenPrim;
+};
+
+struct FrameArgs {
+    wpt_camera cam;
+    wpt_params par;
+    uint32_t width, height, samplesSqrt;
+};
+
+WPT_D void pathStateInit(PathState& ps, uint32_t pixel, uint32_t width)
+{
+    prngSeed(ps.prng, pixel);
+    ps.acc0 = ps.acc1 = ps.acc2 = 0.0f;
+    ps.px = pixel % width;
+    ps.py = pixel / width;
+    ps.sampleIndex = 0;
+    ps.pathComponent = 0;
+    ps.rayKind = RAY_PATH;
+    ps.ray.o = mk3(0.0f, 0.0f, 0.0f);
+    ps.ray.d = mk3(0.0f, 0.0f, 1.0f);
+    ps.ray.ri = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+    ps.att = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+    ps.opl = mk3(0.0f, 0.0f, 0.0f);
+    ps.nextAtt = ps.att;
+    ps.neeFactor = ps.att;
+    ps.srDir = ps.ray.d;
+    ps.chosenPrim = NO_HIT;
+}
+
+/* HitableTriangle::pdfValue (hitable_triangle.hpp:405-423) for one hot spot */
+WPT_D float hotSpotPdfValue(float4 g0, float4 g1, float4 g2, f3 org, f3 dir, const RayAux& h)
+{
+    const f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
+    Candidate c;
+    float value = 0.0f;
+    if (triangleTest(v0, v1, v2, org, h, 0.0f, k_maxval, c)) {
+        f3 edgeCross = cross(sub(v1, v0), sub(v2, v0));
+        float edgeCrossLength = __builtin_sqrtf(dot(edgeCross, edgeCross));
+        f3 faceNormal = divs(edgeCross, edgeCrossLength);
+        float faceArea = 0.5f * edgeCrossLength;
+        float cosine = __builtin_fabsf(dot(faceNormal, neg(dir)));
+        float distance_squared = c.a * c.a;
+        value = distance_squared / (cosine * faceArea);
+    }
+    return value;
+}
+
+/* mean pdf over all hot spots of hitting them from org along dir (wurblpt.hpp:181-184) */
+template<bool COUNT, class Tri4>
+WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, LaneCounters& lc)
+{
+    const RayAux h = rayAux(dir);
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < sv.hotspotCount; i++) {
+        const uint32_t p = sv.hotspots[i].prim;
+        sum += hotSpotPdfValue(tri4(3 * p), tri4(3 * p + 1), tri4(3 * p + 2), org, dir, h);
+        if (COUNT)
+            lc.pdfs++;
+    }
+    sum *= 1.0f / (float)sv.hotspotCount;
+    return sum;
+}
+
+/* SensorRGB::accumulateRadiance (sensor_rgb.hpp:63-80) */
+WPT_D void accumulateRadiance(const wpt_params& par, f3 opl, float distanceToLight, f4 radiance, PathState& ps)
+{
+    const bool dOk = distanceToLight >= par.min_dist_to_light && distanceToLight <= par.max_dist_to_light;
+    if (dOk && opl.x >= par.min_path_len && opl.x <= par.max_path_len)
+        ps.acc0 += radiance.x;
+    if (dOk && opl.y >= par.min_path_len && opl.y <= par.max_path_len)
+        ps.acc1 += radiance.y;
+    if (dOk && opl.z >= par.min_path_len && opl.z <= par.max_path_len)
+        ps.acc2 += radiance.z;
+}
+
+/* wurblpt.hpp:254-273: continue along the scattered direction (ps.ray.o already is the hit
+ * position, ps.ray.ri the index to continue with), Russian roulette */
+WPT_D int advancePath(const wpt_params& par, PathState& ps)
+{
+    ps.att = ps.nextAtt;
+    ps.ray.d = ps.srDir;
+    const float mx = max4(ps.att);
+    if (mx < par.rr_threshold && ps.pathComponent >= 5) {
+        const float q = clampr(1.0f - mx, 0.0f, 0.95f);
+        if (in01(ps.prng) < q)
+            return NEXT_NEW;
+        const float rrWeight = 1.0f / (1.0f - q);
+        ps.att = sclr(ps.att, rrWeight);
+    }
+    ps.pathComponent++;
+    ps.rayKind = RAY_PATH;
+    return NEXT_TRACE;
+}
+
+/* wurblpt.hpp:348-360 + Camera::getRay (camera.hpp:123-185), pinhole or thin lens */
+template<uint32_t F>
+WPT_D int blockNew(const FrameArgs& fa, PathState& ps)
+{
+    const uint32_t samples = fa.samplesSqrt * fa.samplesSqrt;
+    if (ps.sampleIndex >= samples)
+        return NEXT_DONE;
+    float u = (float)ps.px, v = (float)ps.py;
+    if (fa.par.randomize_ray_over_pixel) {
+        /* stratified jitter; the reference compiler draws the vertical stratum first */
+        const uint32_t j = ps.sampleIndex / fa.samplesSqrt;
+        const uint32_t i = ps.sampleIndex % fa.samplesSqrt;
+        const float fj = (float)j + in01(ps.prng);
+        const float fi = (float)i + in01(ps.prng);
+        const float invSamplesSqrt = 1.0f / (float)fa.samplesSqrt;
+        u += fi * invSamplesSqrt;
+        v += fj * invSamplesSqrt;
+    } else {
+        u += 0.5f;
+        v += 0.5f;
+    }
+    u *= 1.0f / (float)fa.width;
+    v *= 1.0f / (float)fa.height;
+    f3 P = mk3(mixr(fa.cam.l, fa.cam.r, u), mixr(fa.cam.b, fa.cam.t, v), -1.0f);
+    f3 O = mk3(0.0f, 0.0f, 0.0f);
+    if ((F & FEAT_LENS) && fa.cam.lens_radius > 0.0f) {
+        P = sclr(P, fa.cam.focus_dist);
+        f2 d = inUnitDisk(in01x2(ps.prng));
+        O = mk3(fa.cam.lens_radius * d.x, fa.cam.lens_radius * d.y, 0.0f);
+    }
+    f3 D = sub(P, O);
+    O = add(O, mk3(0.0f, 0.0f, 0.0f));
+    ps.ray.o = add(ld3(fa.cam.translation), quatRotate(fa.cam.rotation, mul(O, ld3(fa.cam.scaling))));
+    ps.ray.d = normalize(quatRotate(fa.cam.rotation, D));
+    ps.ray.ri = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+    ps.att = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+    ps.opl = mk3(0.0f, 0.0f, 0.0f);
+    ps.pathComponent = 0;
+    ps.sampleIndex++;
+    ps.rayKind = RAY_PATH;
+    return NEXT_TRACE;
+}
+
+/* tracePath, one path component (wurblpt.hpp:131-252); `best` is the path ray's result */
+template<uint32_t F, bool COUNT, class Tri4>
+WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PathState& ps, const Candidate& best, LaneCounters& lc)
+{
+    const bool haveEnv = (F & FEAT_ENVMAP) && sv.envType != WPT_ENV_NONE;
+    if (best.prim == NO_HIT) {
+        if (haveEnv) {
+            f4 rad = mul(ps.att, envL(sv, ps.ray.d));
+            accumulateRadiance(par, mk3(k_maxval, k_maxval, k_maxval), k_maxval, rad, ps);
+        }
+        return NEXT_NEW;
+    }
+    ps.opl = add(ps.opl, scl(best.a, mk3(ps.ray.ri.x, ps.ray.ri.y, ps.ray.ri.z)));
+    if (!(ps.pathComponent + 1 < par.max_path_components))
+        return NEXT_NEW;
+    Hit h = finishHit(sv, best, ps.ray.o, ps.ray.d);
+    const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
+    if (COUNT)
+        lc.scatters++;
+    const Scatter sr = materialScatter<F>(sv, m, ps.ray, h, ps.prng);
+    {
+        f4 rad = mul(ps.att, materialEmitted<F>(sv, m, h));
+        accumulateRadiance(par, ps.opl, (ps.pathComponent == 0 ? 0.0f : h.a), rad, ps);
+    }
+    if (sr.type == SCATTER_NONE)
+        return NEXT_NEW;
+    ps.nextAtt = mul(ps.att, sr.att);
+    if (sr.type == SCATTER_RANDOM) {
+        if (sr.pdf > 0.0f)
+            ps.nextAtt = divs(ps.nextAtt, sr.pdf);
+        else
+            ps.nextAtt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    ps.srDir = sr.dir;
+    if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
+        /* light sampling with MIS (wurblpt.hpp:179-220) */
+        const float hotSpotsPdf = hotSpotsMeanPdf<COUNT>(sv, tri4, h.p, sr.dir, lc);
+        ps.nextAtt = sclr(ps.nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
+        uint32_t idx = (uint32_t)(in01(ps.prng) * (float)sv.hotspotCount);
+        idx = idx < sv.hotspotCount - 1 ? idx : sv.hotspotCount - 1;
+        const wpt_hotspot& hs = sv.hotspots[idx];
+        /* HitableTriangle::direction (hitable_triangle.hpp:425-443) */
+        const f3 bary = inTriangle(in01x2(ps.prng));
+        f3 p = add(add(scl(bary.x, ld3(hs.p0)), scl(bary.y, ld3(hs.p1))), scl(bary.z, ld3(hs.p2)));
+        if (hs.transform)
+            p = mat4mulPoint(hs.M, p);
+        const f3 directDir = normalize(sub(p, h.p));
+        const float directPdf = hotSpotsMeanPdf<COUNT>(sv, tri4, h.p, directDir, lc);
+        if (directPdf > 0.0f) {
+            float dpdf;
+            f4 directAtt;
+            materialEval<F>(sv, m, ps.ray, h, directDir, directAtt, dpdf);
+            if (dpdf > 0.0f) {
+                ps.neeFactor = sclr(divs(mul(ps.att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
+                ps.chosenPrim = hs.prim;
+                ps.ray.o = h.p;
+                ps.ray.d = directDir;
+                ps.rayKind = RAY_NEE_LIGHT;
+                return NEXT_TRACE;
+            }
+        }
+    } else if ((F & FEAT_ENVMAP) && sr.type == SCATTER_RANDOM && haveEnv && sv.envN > 0) {
+        /* environment sampling with MIS (wurblpt.hpp:221-252) */
+        const float lightsP = envP(sv, sr.dir);
+        ps.nextAtt = sclr(ps.nextAtt, powerHeuristicWeight(sr.pdf, lightsP));
+        const f3 lightDir = envD(sv, ps.prng);
+        const float directPdf = envP(sv, lightDir);
+        float dpdf;
+        f4 directAtt;
+        materialEval<F>(sv, m, ps.ray, h, lightDir, directAtt, dpdf);
+        if (dpdf > 0.0f) {
+            ps.neeFactor = sclr(divs(mul(ps.att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
+            ps.ray.o = h.p;
+            ps.ray.d = lightDir;
+            ps.rayKind = RAY_NEE_ENV;
+            return NEXT_TRACE;
+        }
+    }
+    /* No next-event ray.  The scattered ray's refractive index: every ScatterRandom record
+     * carries the incoming ray's index unchanged (material_lambertian.hpp:83, material_ggx.hpp:224,
+     * material_modphong.hpp:307), so while a next-event ray is in flight ray.ri already is the
+     * value to continue with; only explicit scattering (glass, transparent ModPhong) changes it. */
+    ps.ray.o = h.p;
+    ps.ray.ri = sr.ri;
+    return advancePath(par, ps);
+}
+
+/* the next-event ray's result (wurblpt.hpp:208-218: only the CHOSEN hot spot as nearest hit
+ * counts; :240-250: the environment counts if nothing was hit), then the path continues */
+template<uint32_t F>
+WPT_D int blockNeeEnd(const SceneView& sv, const wpt_params& par, PathState& ps, const Candidate& best)
+{
+    if (ps.rayKind == RAY_NEE_LIGHT) {
+        if (best.prim == ps.chosenPrim) {
+            Hit lh = finishHit(sv, best, ps.ray.o, ps.ray.d);
+            const wpt_material& lm = resolveMaterial<F>(sv, lh.material, lh);
+            f4 rad = mul(ps.neeFactor, materialEmitted<F>(sv, lm, lh));
+            f3 oplLight = add(ps.opl, scl(lh.a, mk3(ps.ray.ri.x, ps.ray.ri.y, ps.ray.ri.z)));
+            accumulateRadiance(par, oplLight, lh.a, rad, ps);
+        }
+    } else if (F & FEAT_ENVMAP) {
+        if (best.prim == NO_HIT) {
+            f4 rad = mul(ps.neeFactor, envL(sv, ps.ray.d));
+            accumulateRadiance(par, mk3(k_maxval, k_maxval, k_maxval), k_maxval, rad, ps);
+        }
+    }
+    return advancePath(par, ps);
+}
+
+} /* namespace wptk */
+
+#endif

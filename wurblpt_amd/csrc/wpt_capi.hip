@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "../../include/wurblpt_hip.h"
-#include "wpt_pathtrace.inc.h"
+#include "wpt_pathtrace_pc.inc.h"
 
 using namespace wptd;
 using namespace wptk;
@@ -80,6 +80,7 @@ struct wpt_scene {
     uint32_t features;
     uint32_t nodeCount, triCount;
     std::vector<void*> allocations;
+    uint32_t* status; /* device word: set by a launch that aborted */
     std::vector<float> envM, envMcs;
     std::vector<int32_t> envMs;
 };
@@ -88,7 +89,7 @@ namespace {
 
 uint32_t g_threadsPerGroup = WG;
 uint32_t g_variant = 0;
-uint32_t g_leaveEighths = 2;
+uint32_t g_leaveEighths = 0; /* 0 = default: 2 eighths (single-role kernel) / patience 8 rounds (ray-pool kernel) */
 uint32_t g_heavyMin = 0; /* 0 = chosen per scene size at launch */
 uint32_t g_leafBias = 0;
 unsigned long long* g_schedStats = nullptr;
@@ -308,6 +309,12 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     UP(uploadArray(s, desc->textures, desc->texture_count, &s->view.textures));
     UP(uploadArray(s, desc->texels, desc->texel_bytes, &s->view.texels));
     UP(uploadArray(s, desc->hotspots, desc->hotspot_count, &s->view.hotspots));
+    {
+        const uint32_t zero = 0;
+        const uint32_t* statusWord = nullptr;
+        UP(uploadArray(s, &zero, 1, &statusWord));
+        s->status = const_cast<uint32_t*>(statusWord);
+    }
     s->view.nodeCount = desc->node_count;
     s->view.triCount = desc->tri_count;
     s->view.hotspotCount = desc->hotspot_count;
@@ -411,9 +418,12 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     args.blockSize = block_size;
     args.frame = frame_device;
     args.counters = counters_device;
+    args.status = scene->status;
     args.schedStats = g_schedStats;
     /* a wave covers an 8x8 pixel tile when the block consists of whole groups of 8 rows */
-    args.leaveEighths = g_leaveEighths;
+    /* clamped: with more than 8 eighths the traversal block would leave before doing anything */
+    args.leaveEighths = g_leaveEighths ? (g_leaveEighths > 8u ? 8u : g_leaveEighths) : 2u;
+    args.patience = 8;
 
     args.tiled = (width % 8 == 0 && block_start % width == 0 && block_size % (8 * width) == 0) ? 1u : 0u;
     uint32_t need = scene->features | (camera->lens_radius > 0.0f ? FEAT_LENS : 0u);
@@ -427,18 +437,36 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     const bool smallScene = ldsBytes <= LDS_SCENE_MAX_BYTES;
     args.heavyMin = g_heavyMin ? g_heavyMin : (smallScene ? 16u : 8u);
     args.leafBias = g_leafBias ? g_leafBias : (smallScene ? 16u : 32u);
-    if ((need & ~FEAT_BASIC) == 0 && g_variant != 2) {
-        if (count)
+    /* kernel choice: the single-role kernel (wpt_pathtrace.inc.h) is the product path and the only
+     * one with work counters.  Variant bit 0x10 selects the workgroup ray-pool kernel
+     * (wpt_pathtrace_pc.inc.h), kept as a measured experiment: same results, slower.
+     * Low nibble: 1 = keep the scene in HBM, 2 = all features. */
+    const uint32_t force = g_variant & 0xfu;
+    const bool singleRole = (g_variant & 0x10u) == 0;
+    const bool basic = (need & ~FEAT_BASIC) == 0 && force != 2;
+    const bool lds = smallScene && force != 1;
+    if (count) {
+        if (basic)
             launchBasicCount(args, grid, stream);
-        else if (ldsBytes <= LDS_SCENE_MAX_BYTES && g_variant != 1)
-            launchBasicLds(args, grid, ldsBytes, stream);
         else
-            launchBasic(args, grid, stream);
-    } else {
-        if (count)
             launchFullCount(args, grid, stream);
+    } else if (singleRole) {
+        if (basic && lds)
+            launchBasicLds(args, grid, ldsBytes, stream);
+        else if (basic)
+            launchBasic(args, grid, stream);
         else
             launchFull(args, grid, stream);
+    } else {
+        args.heavyMin = g_heavyMin ? g_heavyMin : 32u; /* waiting is free (the wave traverses meanwhile): shade well filled */
+        args.patience = g_leaveEighths ? g_leaveEighths : 8u;
+        dim3 pcGrid((block_size + PC_SLOTS - 1) / PC_SLOTS);
+        if (basic && lds)
+            launchPcBasicLds(args, pcGrid, ldsBytes, stream);
+        else if (basic)
+            launchPcBasic(args, pcGrid, stream);
+        else
+            launchPcFull(args, pcGrid, stream);
     }
     HIP_TRY(hipGetLastError());
     return WPT_OK;
@@ -458,6 +486,8 @@ wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera, const wp
     float* biased = dBlock - size_t(block_start) * 3;
     wpt_status st = wpt_render_block_device(scene, camera, params, width, height, samples_sqrt, block_start, block_size,
             biased, nullptr, nullptr);
+    if (st == WPT_OK)
+        st = wpt_scene_check(scene);
     if (st == WPT_OK) {
         hipError_t e = hipMemcpy(block_rgb, dBlock, size_t(block_size) * 3 * sizeof(float), hipMemcpyDeviceToHost);
         if (e != hipSuccess)
@@ -473,12 +503,32 @@ wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant)
         return fail(WPT_ERR_UNSUPPORTED, "this build uses 256 threads per workgroup");
     g_threadsPerGroup = WG;
     g_variant = variant & 0xffu;
+    g_leaveEighths = 0;
+    g_heavyMin = 0;
+    g_leafBias = 0;
     if ((variant >> 8) & 0xffu)
         g_leaveEighths = ((variant >> 8) & 0xffu) - 1; /* byte 1: leave threshold in eighths, plus one */
     if ((variant >> 16) & 0xffu)
         g_heavyMin = ((variant >> 16) & 0xffu) - 1;     /* byte 2: lanes a long block needs, plus one */
     if ((variant >> 24) & 0xffu)
         g_leafBias = (variant >> 24) & 0xffu;           /* byte 3: leaf bias */
+    return WPT_OK;
+}
+
+/* Waits for the device and reports whether any launch on this scene had to abort (a bounded
+ * wait inside the kernel ran out); clears the flag. */
+wpt_status wpt_scene_check(wpt_scene* scene)
+{
+    if (!scene)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpy(&st, scene->status, sizeof(st), hipMemcpyDeviceToHost));
+    if (st != 0) {
+        const uint32_t zero = 0;
+        HIP_TRY(hipMemcpy(scene->status, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        return fail(WPT_ERR_HIP, "a path tracing launch aborted: a bounded wait inside the kernel ran out");
+    }
     return WPT_OK;
 }
 

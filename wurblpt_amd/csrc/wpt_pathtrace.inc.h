@@ -35,14 +35,13 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/wurblpt_hip.h"
-#include "wpt_device.h"
+#include "wpt_blocks.h"
 
 namespace wptk {
 
 using namespace wptd;
 
 constexpr int WG = 256; /* threads per workgroup: 4 waves, one per SIMD */
-constexpr uint32_t NO_HIT = 0xffffffffu;
 constexpr uint32_t NODE_INNER = 0xffffffffu; /* device node: marker in the primitive slot */
 constexpr uint32_t NODE_EMPTY = 0xfffffffeu;
 constexpr uint32_t LDS_SCENE_MAX_BYTES = 48 * 1024;
@@ -62,18 +61,15 @@ struct KernelArgs {
     uint32_t leaveEighths; /* scheduler: leave the NODE loop when fewer than this many eighths of the entering lanes remain */
     uint32_t heavyMin;     /* scheduler: lanes a long block needs before it runs */
     uint32_t leafBias;     /* scheduler: leaf tests run when waiting lanes * leafBias >= walking lanes * 8 */
+    uint32_t patience;     /* ray-pool kernel: traversal rounds a wave may spend before it shades what it has */
     float* frame;
     wpt_counters* counters;
     unsigned long long* schedStats; /* COUNT builds: 11 scheduler statistics, or NULL */
-};
-
-struct LaneCounters {
-    uint32_t rays, nodes, leaves, pdfs, scatters;
+    uint32_t* status;               /* set to 1 by a launch that had to abort (bounded waits) */
 };
 
 /* lane states, in scheduling priority order for ties */
 enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5 };
-enum { RAY_PATH = 0, RAY_NEE_LIGHT = 1, RAY_NEE_ENV = 2 };
 
 /* HitableTriangle::pdfValue (hitable_triangle.hpp:405-423) for one hot spot */
 __device__ __forceinline__ float hotSpotPdf(float4 g0, float4 g1, float4 g2, f3 org, f3 dir, const RayAux& h)

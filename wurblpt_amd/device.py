@@ -15,7 +15,7 @@ def lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libwurblpt_hip.so")
 
 
-EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_scene_upload", "wpt_scene_free",
+EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_scene_upload", "wpt_scene_free", "wpt_scene_check",
            "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_kernel_name",
            "wpt_last_error"]
 
@@ -32,6 +32,7 @@ def lib():
         L.wpt_select_device.argtypes = [C.c_int]
         L.wpt_scene_upload.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(C.c_void_p)]
         L.wpt_scene_free.argtypes = [C.c_void_p]
+        L.wpt_scene_check.argtypes = [C.c_void_p]
         L.wpt_render_block_device.argtypes = [C.c_void_p, C.POINTER(_abi.Camera), C.POINTER(_abi.Params),
                                               C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
@@ -74,6 +75,10 @@ class DeviceScene:
         except Exception:
             pass
 
+    def check(self):
+        """Synchronises and raises if a launch on this scene aborted."""
+        _check(lib().wpt_scene_check(self._handle))
+
     def render_block_into(self, frame, samples_sqrt, block=None, params=None, counters=None, stream=None,
                           width=None, height=None):
         """Asynchronously renders pixels [start, start+size) into `frame`, a CUDA float32 tensor
@@ -99,6 +104,7 @@ class DeviceScene:
         stream = torch.cuda.current_stream()
         self.render_block_into(frame, samples_sqrt, block, params, counters, stream, w, h)
         torch.cuda.synchronize()
+        self.check()
         cnt = None
         if with_counters:
             names = ("samples", "rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")
