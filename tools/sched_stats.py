@@ -12,7 +12,7 @@ if var:
     device.lib().wpt_set_launch_config(0, var)
 sc = host.sponza_like(1920, 1080) if (len(sys.argv) > 2 and sys.argv[2] == "sponza") else host.cornell(1024, 1024, 1, 2)
 ds = device.DeviceScene(sc)
-stats = torch.zeros(11, dtype=torch.int64, device="cuda")
+stats = torch.zeros(16, dtype=torch.int64, device="cuda")
 device.lib().wpt_set_scheduler_stats.argtypes = [C.c_void_p]
 device.lib().wpt_set_scheduler_stats(C.c_void_p(stats.data_ptr()))
 spp_sqrt = 2 if len(sys.argv) > 2 else 4
@@ -32,3 +32,9 @@ for i, nm in enumerate(names[1:]):
     print("%s: rounds per 64 samples %.3f avg lanes %.1f (lane-execs %.3f/sample)" % (nm, r * 64 / n, l / max(1, r), l / n))
 tot_rounds = s[0] + s[3] + s[5] + s[7] + s[9]
 print("scheduler rounds per 64 samples: %.2f" % (tot_rounds * 64 / n))
+if sum(s[11:15]) > 0:
+    tot = float(sum(s[11:15]))
+    print("shader clock per block kind: traversal %.1f%%  shade %.1f%%  nee-end %.1f%%  new %.1f%%  (ticks per 64 samples: %.0f)" % (
+        100 * s[11] / tot, 100 * s[12] / tot, 100 * s[13] / tot, 100 * s[14] / tot, tot * 64 / n))
+    print("ticks per round: node-iter %.0f (incl. leaf iters)  shade %.0f  nee-end %.0f  new %.0f" % (
+        s[11] / max(1, s[1] + s[3]), s[12] / max(1, s[5]), s[13] / max(1, s[7]), s[14] / max(1, s[9])))

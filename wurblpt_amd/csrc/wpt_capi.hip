@@ -55,6 +55,16 @@ __global__ void wpt_env_importance_kernel(SceneView sv, int N, float* importance
     importance[i] = L.x + L.y + L.z + L.w;
 }
 
+/* decodes one image texture into the RGBA float4 pool (see imageTexelDecode) */
+__global__ void wpt_expand_texels_kernel(const uint8_t* pool, const wpt_texture t, float4* out)
+{
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(t.width) * t.height)
+        return;
+    const f4 v = imageTexelDecode(pool, t, i % t.width, i / t.width);
+    out[i] = make_float4(v.x, v.y, v.z, v.w);
+}
+
 /* ---- host side of the C ABI ---- */
 
 thread_local std::string g_error;
@@ -306,8 +316,50 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     s->view.triAttr = attr;
     UP(uploadArray(s, desc->instances, desc->instance_count, &s->view.instances));
     UP(uploadArray(s, desc->materials, desc->material_count, &s->view.materials));
-    UP(uploadArray(s, desc->textures, desc->texture_count, &s->view.textures));
-    UP(uploadArray(s, desc->texels, desc->texel_bytes, &s->view.texels));
+    {
+        /* Image textures are decoded once, here, into one pool of RGBA float4 texels (16 bytes
+         * per texel whatever the file format was: HBM is large, instructions per lookup are
+         * not); the device copies of the texture records index that pool. */
+        std::vector<wpt_texture> devTex(desc->textures, desc->textures + desc->texture_count);
+        size_t texelCount = 0;
+        for (wpt_texture& t : devTex) {
+            if (t.type == WPT_TEX_IMAGE) {
+                t.texel_offset = texelCount;
+                texelCount += size_t(t.width) * t.height;
+            }
+        }
+        UP(uploadArray(s, devTex.data(), devTex.size(), &s->view.textures));
+        void* pool = nullptr;
+        hipError_t e = hipMalloc(&pool, texelCount > 0 ? texelCount * sizeof(float4) : 16);
+        if (e != hipSuccess) {
+            wpt_scene_free(s);
+            return fail(e == hipErrorOutOfMemory ? WPT_ERR_OUT_OF_MEMORY : WPT_ERR_HIP, std::string("hipMalloc for the decoded texel pool: ") + hipGetErrorString(e));
+        }
+        s->allocations.push_back(pool);
+        s->view.texels4 = static_cast<const float4*>(pool);
+        if (texelCount > 0) {
+            uint8_t* raw = nullptr;
+            e = hipMalloc(reinterpret_cast<void**>(&raw), desc->texel_bytes > 0 ? desc->texel_bytes : 16);
+            if (e == hipSuccess)
+                e = hipMemcpy(raw, desc->texels, desc->texel_bytes, hipMemcpyHostToDevice);
+            for (uint32_t i = 0; e == hipSuccess && i < desc->texture_count; i++) {
+                const wpt_texture& t = desc->textures[i];
+                if (t.type != WPT_TEX_IMAGE)
+                    continue;
+                const size_t n = size_t(t.width) * t.height;
+                hipLaunchKernelGGL(wpt_expand_texels_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, 0,
+                        raw, t, static_cast<float4*>(pool) + devTex[i].texel_offset);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess)
+                e = hipDeviceSynchronize();
+            (void)hipFree(raw);
+            if (e != hipSuccess) {
+                wpt_scene_free(s);
+                return fail(e == hipErrorOutOfMemory ? WPT_ERR_OUT_OF_MEMORY : WPT_ERR_HIP, std::string("texel decode: ") + hipGetErrorString(e));
+            }
+        }
+    }
     UP(uploadArray(s, desc->hotspots, desc->hotspot_count, &s->view.hotspots));
     {
         const uint32_t zero = 0;

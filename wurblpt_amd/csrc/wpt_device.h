@@ -381,7 +381,7 @@ struct SceneView {
     const wpt_instance* instances;
     const wpt_material* materials;
     const wpt_texture* textures;
-    const uint8_t* texels;
+    const float4* texels4; /* decoded RGBA texels of all image textures */
     const wpt_hotspot* hotspots;
     const float* envM;
     const int32_t* envMs;
@@ -448,13 +448,15 @@ WPT_D float srgbToRgb(float x)
     return (x <= 0.04045f ? (x * (1.0f / 12.92f)) : wptm::powf_((x + 0.055f) * (1.0f / 1.055f), 2.4f));
 }
 
-WPT_D f4 imageTexel(const SceneView& sv, const wpt_texture& t, size_t x, size_t y)
+/* TextureImage texel decode (texture_image.hpp:85-140): component type, sRGB linearisation of
+ * the colour components, grey / grey+alpha / RGB / RGBA expansion.  Runs once per texel when a
+ * scene is uploaded (wpt_expand_texels_kernel): the device texel pool holds the decoded RGBA
+ * float4 of every texel, so a lookup in the path tracer is one 16-byte load instead of up to
+ * four component loads and three pow() evaluations.  Decoding is a pure function of the texel,
+ * so the values are the ones the per-lookup decode would give. */
+WPT_D f4 imageTexelDecode(const uint8_t* pool, const wpt_texture& t, size_t x, size_t y)
 {
-    if (x >= t.width)
-        x = t.width - 1;
-    if (y >= t.height)
-        y = t.height - 1;
-    const uint8_t* base = sv.texels + t.texel_offset;
+    const uint8_t* base = pool + t.texel_offset;
     const size_t idx = (y * (size_t)t.width + x) * t.comps;
     float d[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
     const bool lin = t.linearize_srgb != 0;
@@ -476,6 +478,18 @@ WPT_D f4 imageTexel(const SceneView& sv, const wpt_texture& t, size_t x, size_t 
     if (t.comps == 1)
         return mk4(d[0], d[0], d[0], 1.0f);
     return mk4(d[0], d[0], d[0], d[1]);
+}
+
+/* texel fetch with the reference's clamp at the far edges (texture_image.hpp:142-150); in the
+ * device copy of a texture record texel_offset counts float4 texels of the decoded pool */
+WPT_D f4 imageTexel(const SceneView& sv, const wpt_texture& t, size_t x, size_t y)
+{
+    if (x >= t.width)
+        x = t.width - 1;
+    if (y >= t.height)
+        y = t.height - 1;
+    const float4 v = sv.texels4[t.texel_offset + y * (size_t)t.width + x];
+    return mk4(v.x, v.y, v.z, v.w);
 }
 
 WPT_D f4 mix4(f4 a, f4 b, float k)

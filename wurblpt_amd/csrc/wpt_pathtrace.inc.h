@@ -160,7 +160,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
     LaneCounters lc = { 0, 0, 0, 0, 0 };
     /* wave-level scheduler statistics (COUNT builds): rounds and lane counts per state */
-    unsigned long long sched[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long sched[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 
     /* ---- per-lane state ---- */
     int state = inBlock ? S_NEW : S_DONE;
@@ -290,6 +290,9 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             }
         }
 
+        long long tBlock = 0;
+        if (COUNT)
+            tBlock = clock64();
         if (pick == S_NODE) {
             /* Leave when fewer than leaveEighths/8 of the entering lanes are still traversing
              * (never below 1: the loop must end when no lane is left in it). */
@@ -528,6 +531,8 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 }
             }
         }
+        if (COUNT) /* shader clock spent in this block, by kind: [11] traversal [12] shade [13] nee-end [14] new */
+            sched[pick == S_NODE ? 11 : pick == S_SHADE ? 12 : pick == S_NEEEND ? 13 : 14] += (unsigned long long)(clock64() - tBlock);
     }
 
     if (inBlock) {
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         atomicAdd((unsigned long long*)&args.counters->scatters, (unsigned long long)lc.scatters);
     }
     if (COUNT && args.schedStats && (threadIdx.x & 63) == 0) {
-        for (int i = 0; i < 11; i++)
+        for (int i = 0; i < 16; i++)
             atomicAdd(args.schedStats + i, sched[i]);
     }
 }
