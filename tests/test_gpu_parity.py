@@ -51,6 +51,31 @@ def test_device_pow_atan2_bit_identical(dev, oracle):
     assert np.array_equal(dev.selftest_math(5, a, b).view(np.uint32), oracle.math(5, a, b).view(np.uint32))
 
 
+def test_device_box_test_matches_reference_including_nan_slabs(dev, oracle, golden):
+    """The kernels evaluate AABB::mayHit with min/max instructions and fall back to the
+    reference's comparison chains when a slab distance is NaN (origin on a slab plane, direction
+    parallel to it).  Checked on the reference's own golden cases and on a million adversarial
+    ones drawn from few values, so that zero directions, touching planes and flat boxes are common."""
+    ref = golden.i64("aabb_mayhit")
+    assert np.array_equal(dev.selftest_aabb(golden.f32("aabb_boxes"), golden.f32("aabb_rays")).astype(np.int64), ref)
+    rng = np.random.RandomState(11)
+    n = 1 << 20
+    vals = np.array([-1.0, -0.5, 0.0, 0.25, 0.5, 1.0, 2.0], dtype=np.float32)
+    dirs = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.25, 1e-30, -1e-30], dtype=np.float32)
+    lo = vals[rng.randint(0, 4, (n, 3))]
+    hi = np.maximum(lo, vals[rng.randint(2, len(vals), (n, 3))])
+    boxes = np.concatenate([lo, hi], axis=1)
+    org = vals[rng.randint(0, len(vals), (n, 3))]
+    d = dirs[rng.randint(0, len(dirs), (n, 3))]
+    amin = np.array([0.0, 1e-4, 0.5], dtype=np.float32)[rng.randint(0, 3, (n, 1))]
+    amax = np.array([0.75, 3.0, np.finfo(np.float32).max], dtype=np.float32)[rng.randint(0, 3, (n, 1))]
+    rays = np.concatenate([org, d, amin, amax], axis=1).astype(np.float32)
+    want = oracle.simple("wpt_oracle_aabb", n, 1, boxes, rays, out_dtype=np.int32).reshape(-1)
+    got = dev.selftest_aabb(boxes, rays)
+    assert 0.05 < want.mean() < 0.95
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
 @pytest.mark.parametrize("tall,short", [(0, 0), (1, 2)])
 def test_cornell_frame_bit_exact(dev, oracle, tall, short):
     """configs 1 and 2 at a size the oracle finishes in seconds"""

@@ -41,6 +41,17 @@ __global__ void wpt_selftest_kernel(int op, int n, const float* a, const float* 
     out[i] = r;
 }
 
+/* AABB::mayHit as the kernels evaluate it; same argument layout as the oracle's probe:
+ * boxes lo(3) hi(3); rays origin(3) dir(3) amin amax */
+__global__ void wpt_selftest_aabb_kernel(int n, const float* boxes, const float* rays, int32_t* out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const RayAux h = rayAux(ld3(rays + 8 * i + 3));
+    out[i] = boxTest(ld3(boxes + 6 * i), ld3(boxes + 6 * i + 3), ld3(rays + 8 * i), h.inv, rays[8 * i + 6], rays[8 * i + 7]) ? 1 : 0;
+}
+
 /* per-bin importance of the environment map (envmap.hpp:128-140) */
 __global__ void wpt_env_importance_kernel(SceneView sv, int N, float* importance)
 {
@@ -603,6 +614,16 @@ const char* wpt_last_error(void)
 }
 
 /* test hook: evaluates one arithmetic primitive on the device for n inputs (device pointers) */
+wpt_status wpt_selftest_aabb(int n, const float* boxes_device, const float* rays_device, int32_t* out_device)
+{
+    if (n <= 0 || !boxes_device || !rays_device || !out_device)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "bad self test arguments");
+    hipLaunchKernelGGL(wpt_selftest_aabb_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, boxes_device, rays_device, out_device);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return WPT_OK;
+}
+
 wpt_status wpt_selftest_math(int op, int n, const float* a_device, const float* b_device, float* out_device)
 {
     if (n <= 0)

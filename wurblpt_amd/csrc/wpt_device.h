@@ -346,11 +346,11 @@ WPT_D bool triangleTest(f3 v0, f3 v1, f3 v2, f3 org, const RayAux& h, float amin
     return true;
 }
 
-/* AABB::mayHit (aabb.hpp:70-86) with its NaN-skipping max/min reductions */
-WPT_D bool boxTest(f3 lo, f3 hi, f3 org, f3 inv, float amin, float amax)
+/* AABB::mayHit (aabb.hpp:70-86) written out with the reference's comparison chains, whose
+ * results for NaN slab distances (0 * inf: origin on a slab plane, direction parallel to it)
+ * depend on the operand order */
+WPT_D bool boxTestChains(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z, float amin, float amax)
 {
-    float t0x = (lo.x - org.x) * inv.x, t0y = (lo.y - org.y) * inv.y, t0z = (lo.z - org.z) * inv.z;
-    float t1x = (hi.x - org.x) * inv.x, t1y = (hi.y - org.y) * inv.y, t1z = (hi.z - org.z) * inv.z;
     float mnx = fminr(t0x, t1x), mny = fminr(t0y, t1y), mnz = fminr(t0z, t1z);
     float mxx = fmaxr(t0x, t1x), mxy = fmaxr(t0y, t1y), mxz = fmaxr(t0z, t1z);
     float tmin = amin;
@@ -362,6 +362,24 @@ WPT_D bool boxTest(f3 lo, f3 hi, f3 org, f3 inv, float amin, float amax)
     if (mxy < tmax) tmax = mxy;
     if (mxz < tmax) tmax = mxz;
     return tmin <= tmax;
+}
+
+/* AABB::mayHit.  When none of the six slab distances is NaN the comparison chains are plain
+ * minima and maxima (the sign of a zero cannot change the final comparison), which the hardware
+ * has as single instructions (v_min_f32 / v_max3_f32) where a compare + select pair costs three
+ * issue slots; the rare lanes with a NaN take the chains as written. */
+WPT_D bool boxTest(f3 lo, f3 hi, f3 org, f3 inv, float amin, float amax)
+{
+    const float t0x = (lo.x - org.x) * inv.x, t0y = (lo.y - org.y) * inv.y, t0z = (lo.z - org.z) * inv.z;
+    const float t1x = (hi.x - org.x) * inv.x, t1y = (hi.y - org.y) * inv.y, t1z = (hi.z - org.z) * inv.z;
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+            __builtin_fmaxf(__builtin_fminf(t0z, t1z), amin));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+            __builtin_fminf(__builtin_fmaxf(t0z, t1z), amax));
+    bool hit = tmin <= tmax;
+    if (__builtin_expect(__builtin_isunordered(t0x, t1x) || __builtin_isunordered(t0y, t1y) || __builtin_isunordered(t0z, t1z), 0))
+        hit = boxTestChains(t0x, t0y, t0z, t1x, t1y, t1z, amin, amax);
+    return hit;
 }
 
 /* full HitRecord (hitable.hpp:39-64) */

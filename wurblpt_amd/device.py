@@ -125,6 +125,20 @@ class DeviceScene:
         return out
 
 
+def selftest_aabb(boxes, rays):
+    """AABB::mayHit as the kernels evaluate it: boxes (n,6) lo hi, rays (n,8) origin dir amin amax."""
+    import numpy as np
+    import torch
+    tb = torch.as_tensor(np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6), device="cuda")
+    tr = torch.as_tensor(np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8), device="cuda")
+    assert tb.shape[0] == tr.shape[0]
+    out = torch.empty(tb.shape[0], dtype=torch.int32, device="cuda")
+    L = lib()
+    L.wpt_selftest_aabb.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(L.wpt_selftest_aabb(tb.shape[0], C.c_void_p(tb.data_ptr()), C.c_void_p(tr.data_ptr()), C.c_void_p(out.data_ptr())))
+    return out.cpu().numpy()
+
+
 def selftest_math(op, a, b=None):
     """Evaluates one arithmetic primitive of the kernel on the GPU (see wpt_selftest_kernel)."""
     import torch
