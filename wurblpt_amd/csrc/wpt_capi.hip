@@ -110,7 +110,7 @@ namespace {
 
 uint32_t g_threadsPerGroup = WG;
 uint32_t g_variant = 0;
-uint32_t g_leaveEighths = 0; /* 0 = default: 2 eighths (single-role kernel) / patience 8 rounds (ray-pool kernel) */
+uint32_t g_leaveEighths = 0; /* 0 = default: chosen per scene size (single-role kernel) / patience 8 rounds (ray-pool kernel) */
 uint32_t g_heavyMin = 0; /* 0 = chosen per scene size at launch */
 uint32_t g_leafBias = 0;
 unsigned long long* g_schedStats = nullptr;
@@ -483,11 +483,10 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     args.counters = counters_device;
     args.status = scene->status;
     args.schedStats = g_schedStats;
-    /* a wave covers an 8x8 pixel tile when the block consists of whole groups of 8 rows */
-    /* clamped: with more than 8 eighths the traversal block would leave before doing anything */
-    args.leaveEighths = g_leaveEighths ? (g_leaveEighths > 8u ? 8u : g_leaveEighths) : 2u;
     args.patience = 8;
+    args.fuse = (g_variant & 0x20u) ? 0u : 1u; /* variant bit 0x20: separate SHADE / NEE-END / NEW rounds (the older scheduler) */
 
+    /* a wave covers an 8x8 pixel tile when the block consists of whole groups of 8 rows */
     args.tiled = (width % 8 == 0 && block_start % width == 0 && block_size % (8 * width) == 0) ? 1u : 0u;
     uint32_t need = scene->features | (camera->lens_radius > 0.0f ? FEAT_LENS : 0u);
     dim3 grid((block_size + WG - 1) / WG);
@@ -498,6 +497,8 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
      * Sponza-class scene (deep tree in HBM: traversal dominates, so long blocks may run with fewer
      * lanes and leaf tests earlier) */
     const bool smallScene = ldsBytes <= LDS_SCENE_MAX_BYTES;
+    /* clamped: with more than 8 eighths the traversal block would leave before doing anything */
+    args.leaveEighths = g_leaveEighths ? (g_leaveEighths > 8u ? 8u : g_leaveEighths) : (smallScene ? 1u : 3u);
     args.heavyMin = g_heavyMin ? g_heavyMin : (smallScene ? 16u : 8u);
     args.leafBias = g_leafBias ? g_leafBias : (smallScene ? 16u : 32u);
     /* kernel choice: the single-role kernel (wpt_pathtrace.inc.h) is the product path and the only

@@ -62,6 +62,7 @@ struct KernelArgs {
     uint32_t heavyMin;     /* scheduler: lanes a long block needs before it runs */
     uint32_t leafBias;     /* scheduler: leaf tests run when waiting lanes * leafBias >= walking lanes * 8 */
     uint32_t patience;     /* ray-pool kernel: traversal rounds a wave may spend before it shades what it has */
+    uint32_t fuse;         /* scheduler: 1 = one long round serves SHADE, NEE-END and NEW lanes together */
     float* frame;
     wpt_counters* counters;
     unsigned long long* schedStats; /* COUNT builds: 11 scheduler statistics, or NULL */
@@ -271,10 +272,15 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         if ((cTrav | cShade | cNee | cNew) == 0)
             break;
         int pick;
+        const bool fused = args.fuse != 0;
         {
             /* at least 1: a block must never be picked with no lane in it */
             const int heavyMin = (int)args.heavyMin < 1 ? 1 : (int)args.heavyMin;
-            if (cShade >= heavyMin) {
+            if (fused) {
+                /* one long round for every lane that is not traversing: fewer lanes wait for
+                 * "their" block to fill up, at the price of running up to three code sections */
+                pick = (cShade + cNee + cNew >= heavyMin || cTrav == 0) ? (int)S_SHADE : (int)S_NODE;
+            } else if (cShade >= heavyMin) {
                 pick = S_SHADE;
             } else if (cNee >= heavyMin) {
                 pick = S_NEEEND;
@@ -289,7 +295,6 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 if (cNew > most) { pick = S_NEW; most = cNew; }
             }
         }
-
         long long tBlock = 0;
         if (COUNT)
             tBlock = clock64();
@@ -366,8 +371,12 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                     }
                 }
             }
-        } else if (pick == S_SHADE) {
+        }
+        if (COUNT && pick == S_NODE)
+            sched[11] += (unsigned long long)(clock64() - tBlock);
+        if (pick != S_NODE && (fused ? cShade > 0 : pick == S_SHADE)) {
             if (COUNT) {
+                tBlock = clock64();
                 sched[5]++;
                 sched[6] += cShade;
             }
@@ -463,8 +472,12 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                     }
                 }
             }
-        } else if (pick == S_NEEEND) {
+            if (COUNT)
+                sched[12] += (unsigned long long)(clock64() - tBlock);
+        }
+        if (pick != S_NODE && (fused ? cNee > 0 : pick == S_NEEEND)) {
             if (COUNT) {
+                tBlock = clock64();
                 sched[7]++;
                 sched[8] += cNee;
             }
@@ -486,10 +499,15 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 }
                 advancePath();
             }
-        } else { /* S_NEW */
+            if (COUNT)
+                sched[13] += (unsigned long long)(clock64() - tBlock);
+        }
+        /* last: in a fused round it also serves the lanes whose path has just ended above */
+        if (pick != S_NODE && (fused ? __ballot(state == S_NEW) != 0 : pick == S_NEW)) {
             if (COUNT) {
+                tBlock = clock64();
                 sched[9]++;
-                sched[10] += cNew;
+                sched[10] += __popcll(__ballot(state == S_NEW));
             }
             if (state == S_NEW) {
                 if (sampleIndex >= samples) {
@@ -530,9 +548,9 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                     beginRay(RAY_PATH);
                 }
             }
+            if (COUNT) /* shader clock spent per kind of block: [11] traversal [12] shade [13] nee-end [14] new */
+                sched[14] += (unsigned long long)(clock64() - tBlock);
         }
-        if (COUNT) /* shader clock spent in this block, by kind: [11] traversal [12] shade [13] nee-end [14] new */
-            sched[pick == S_NODE ? 11 : pick == S_SHADE ? 12 : pick == S_NEEEND ? 13 : 14] += (unsigned long long)(clock64() - tBlock);
     }
 
     if (inBlock) {
