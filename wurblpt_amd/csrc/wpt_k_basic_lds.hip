@@ -5,7 +5,7 @@ namespace wptk {
 
 void launchBasicLds(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false, true, 3, ORDERED_KERNELS>), grid, dim3(WG), ldsBytes, stream, args);
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false, true, 4, ORDERED_KERNELS>), grid, dim3(WG), ldsBytes, stream, args);
 }
 
 }
