@@ -33,6 +33,9 @@ WORKLOADS = {
     "cornell_256x256_64spp_lambertian": dict(kind="cornell", tall=0, short=0, width=256, height=256, samples_sqrt=8),
     # BASELINE configs[2]: procedural Sponza-class stand-in (the real OBJ is not available offline)
     "sponza_like_1920x1080_256spp_envmap_is": dict(kind="sponza", width=1920, height=1080, samples_sqrt=16),
+    # BASELINE configs[3]: procedural San-Miguel-class stand-in, ~10 M triangles; 128 spp is not a perfect
+    # square (spp = samplesSqrt^2, wurblpt.hpp:304), so 11^2 = 121 spp as SURVEY.md section 8(d) says
+    "courtyard_like_10M_1920x1080_121spp": dict(kind="courtyard", triangles=10_000_000, width=1920, height=1080, samples_sqrt=11),
 }
 
 
@@ -42,6 +45,8 @@ def build_scene(w):
         return host.cornell(w["width"], w["height"], w["tall"], w["short"])
     if w["kind"] == "sponza":
         return host.sponza_like(w["width"], w["height"], seed=1, detail=w.get("detail", 1.0))
+    if w["kind"] == "courtyard":
+        return host.courtyard_like(w["width"], w["height"], seed=2, triangles=w["triangles"])
     raise ValueError(w["kind"])
 
 

@@ -94,11 +94,12 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 0x20, 0x22, 0x10, 0x11, 0x12])
+@pytest.mark.parametrize("variant", [0, 1, 2, 0x20, 0x22, 0x10, 0x11, 0x12, 0x40, 0x41, 0x42])
 def test_kernel_variants_agree_bit_for_bit(dev, oracle, variant):
     """0 = scene in LDS, 1 = scene fetched from HBM/L2, 2 = the all-features kernel;
     +0x20 = separate SHADE / NEE-END / NEW rounds instead of the fused long round;
-    +0x10 = the same three instantiations of the workgroup ray-pool kernel"""
+    +0x10 = the same three instantiations of the workgroup ray-pool kernel;
+    +0x40 = the same three of the kernel that keeps the pixel states in LDS"""
     sc = host.cornell(64, 48, 1, 2)
     ref, _ = oracle.render(sc, 5)
     dev.lib().wpt_set_launch_config(0, variant)
@@ -272,3 +273,22 @@ def test_sponza_like_without_importance_sampling(dev, oracle):
     ref, rc = oracle.render(sc, 3)
     got, gc = dev.DeviceScene(sc).render(3, with_counters=True)
     assert bits_equal(got, ref) and gc == rc
+
+
+def test_courtyard_like_two_sided_foliage_constant_env_bit_exact(dev, oracle):
+    """BASELINE config 4 stand-in at test size: a triangle soup of two-sided leaf quads with alpha
+    textures, every material two-sided, constant environment map without importance sampling
+    (radiance on escape only), scene in HBM, all-features kernel."""
+    sc = host.courtyard_like(64, 36, triangles=20000, tex_size=16)
+    assert sc.d.tri_count > 20000 and sc.d.hotspot_count == 0 and sc.d.envmap.N == 0
+    ref, rc = oracle.render(sc, 4)
+    ds = dev.DeviceScene(sc)
+    got, gc = ds.render(4, with_counters=True)
+    assert np.isfinite(got).all() and got.sum() > 0
+    assert bits_equal(got, ref) and gc == rc
+    dev.lib().wpt_set_launch_config(0, 0x40)  # pixel states in LDS, all-features instantiation
+    try:
+        got2, _ = ds.render(4)
+    finally:
+        dev.lib().wpt_set_launch_config(0, 0)
+    assert bits_equal(got2, ref)

@@ -12,6 +12,7 @@
 
 #include "../../include/wurblpt_hip.h"
 #include "wpt_pathtrace_pc.inc.h"
+#include "wpt_pathtrace_wf.inc.h"
 
 using namespace wptd;
 using namespace wptk;
@@ -102,6 +103,9 @@ struct wpt_scene {
     uint32_t nodeCount, triCount;
     std::vector<void*> allocations;
     uint32_t* status; /* device word: set by a launch that aborted */
+    uint32_t* pixelCounters; /* LDS-state kernel: one "next pixel" word per launch in flight (64 of them) */
+    uint32_t launchSeq;
+    int cuCount;
     std::vector<float> envM, envMcs;
     std::vector<int32_t> envMs;
 };
@@ -271,15 +275,17 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
         /* Device node form.  The reference pops a stack to find the next node after a subtree
          * (bvh.hpp:296,305); in a depth-first array that node is the first one behind the
          * subtree, so it is stored per node ("skip") and the kernel needs no stack.
-         * Eight copies of the tree are stored, one per sign octant of the ray direction: copy k
+         * With ORDERED_KERNELS (off by default) eight copies of the tree are stored, one per sign
+         * octant of the ray direction: copy k
          * lists at every inner node first the child that is nearer for such rays along the
          * node's split axis (the builder sorts by centre along the longest axis of the node's
          * box, bvh.hpp:110-113, and the left child takes the low side).  Copy 0 (all signs
          * positive) is the reference's own order: left child first everywhere. */
         const uint32_t n = desc->node_count;
-        std::vector<float4> dev(size_t(n) * 2 * 8);
+        const uint32_t copies = ORDERED_KERNELS ? 8u : 1u;
+        std::vector<float4> dev(size_t(n) * 2 * copies);
         struct Item { uint32_t src; uint32_t pos; bool done; };
-        for (uint32_t oct = 0; oct < 8; oct++) {
+        for (uint32_t oct = 0; oct < copies; oct++) {
             float4* out = dev.data() + size_t(oct) * n * 2;
             uint32_t cursor = 0;
             std::vector<Item> stack;
@@ -373,10 +379,14 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     }
     UP(uploadArray(s, desc->hotspots, desc->hotspot_count, &s->view.hotspots));
     {
-        const uint32_t zero = 0;
+        const uint32_t zeros[1 + 64] = { 0 };
         const uint32_t* statusWord = nullptr;
-        UP(uploadArray(s, &zero, 1, &statusWord));
+        UP(uploadArray(s, zeros, 1 + 64, &statusWord));
         s->status = const_cast<uint32_t*>(statusWord);
+        s->pixelCounters = s->status + 1;
+        s->launchSeq = 0;
+        hipDeviceProp_t prop;
+        s->cuCount = hipGetDeviceProperties(&prop, s->device) == hipSuccess ? prop.multiProcessorCount : 256;
     }
     s->view.nodeCount = desc->node_count;
     s->view.triCount = desc->tri_count;
@@ -509,11 +519,36 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     const bool singleRole = (g_variant & 0x10u) == 0;
     const bool basic = (need & ~FEAT_BASIC) == 0 && force != 2;
     const bool lds = smallScene && force != 1;
+    const bool ldsState = (g_variant & 0x40u) != 0;
+    args.travWaves = 8;
+    args.heavyWaves = 4;
+    args.pixelCounter = nullptr;
     if (count) {
         if (basic)
             launchBasicCount(args, grid, stream);
         else
             launchFullCount(args, grid, stream);
+    } else if (ldsState) {
+        /* variant bit 0x40: pixel states in LDS, persistent workgroups (wpt_pathtrace_wf.inc.h);
+         * byte 1 of the variant word, if set, is the number of traversal waves per workgroup */
+        args.travWaves = g_leaveEighths ? g_leaveEighths : 8u;
+        args.heavyWaves = g_heavyMin ? g_heavyMin : 4u;
+        if (args.travWaves + args.heavyWaves > uint32_t(WF_WAVES))
+            return fail(WPT_ERR_INVALID_ARGUMENT, "more traversal + heavy waves than the workgroup has");
+        args.heavyMin = 16; /* not used by this kernel */
+        args.patience = 8;
+        args.pixelCounter = scene->pixelCounters + (scene->launchSeq++ & 63u);
+        HIP_TRY(hipMemsetAsync(args.pixelCounter, 0, sizeof(uint32_t), stream));
+        const bool wfLds = basic && force != 1 && ldsBytes <= WF_LDS_SCENE_MAX_BYTES;
+        const uint32_t groups = (block_size + WF_SLOTS - 1) / WF_SLOTS;
+        dim3 wfGrid(groups < uint32_t(scene->cuCount) ? groups : uint32_t(scene->cuCount));
+        const size_t wfBytes = wfLdsBytes(wfLds ? uint32_t(ldsBytes) : 0u);
+        if (wfLds)
+            launchWfBasicLds(args, wfGrid, wfBytes, stream);
+        else if (basic)
+            launchWfBasic(args, wfGrid, wfBytes, stream);
+        else
+            launchWfFull(args, wfGrid, wfBytes, stream);
     } else if (singleRole) {
         if (basic && lds)
             launchBasicLds(args, grid, ldsBytes, stream);

@@ -63,6 +63,9 @@ struct KernelArgs {
     uint32_t leafBias;     /* scheduler: leaf tests run when waiting lanes * leafBias >= walking lanes * 8 */
     uint32_t patience;     /* ray-pool kernel: traversal rounds a wave may spend before it shades what it has */
     uint32_t fuse;         /* scheduler: 1 = one long round serves SHADE, NEE-END and NEW lanes together */
+    uint32_t travWaves;    /* LDS-state kernel: waves of a workgroup that hold traversal contexts */
+    uint32_t heavyWaves;   /* LDS-state kernel: waves of a workgroup that run heavy batches */
+    uint32_t* pixelCounter; /* LDS-state kernel: next unassigned pixel of the block (zero at launch) */
     float* frame;
     wpt_counters* counters;
     unsigned long long* schedStats; /* COUNT builds: 11 scheduler statistics, or NULL */

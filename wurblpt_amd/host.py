@@ -29,6 +29,8 @@ def lib():
         L.wpt_host_random_triangles.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint, C.c_float]
         L.wpt_host_sponza_like.restype = C.c_void_p
         L.wpt_host_sponza_like.argtypes = [C.c_uint, C.c_float, C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint]
+        L.wpt_host_courtyard_like.restype = C.c_void_p
+        L.wpt_host_courtyard_like.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
         L.wpt_host_scene_desc.restype = C.POINTER(_abi.SceneDesc)
         L.wpt_host_scene_desc.argtypes = [C.c_void_p]
         L.wpt_host_scene_camera.restype = C.POINTER(_abi.Camera)
@@ -101,6 +103,14 @@ def sponza_like(width, height, seed=1, detail=1.0, tex_size=1024, env_width=2048
     maps, procedural sun + sky environment map with importance sampling."""
     h = lib().wpt_host_sponza_like(seed, detail, tex_size, env_width, importance_n, width, height)
     return HostScene(h, width, height, "sponza_like(seed=%d,detail=%g)" % (seed, detail))
+
+
+def courtyard_like(width, height, seed=2, triangles=10_000_000, tex_size=1024):
+    """BASELINE config 4 stand-in: seeded San-Miguel-class courtyard dominated by foliage (clouds
+    of small two-sided leaf quads), every material two-sided, constant environment without
+    importance sampling (wurblpt-san-miguel.cpp:36-44).  `triangles` is the approximate total."""
+    h = lib().wpt_host_courtyard_like(seed, triangles, tex_size, width, height)
+    return HostScene(h, width, height, "courtyard_like(seed=%d,triangles=%d)" % (seed, triangles))
 
 
 def bvh_build(boxes):

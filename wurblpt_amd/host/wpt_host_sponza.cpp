@@ -264,3 +264,130 @@ extern "C" wpt_host_scene* wpt_host_sponza_like(unsigned int seed, float detail,
     /* camera of wurblpt-sponza.cpp:145-148 */
     return wptHostFinish(scenePtr, width, height, radians(70.0f), vec3(0.0f, 1.7f, 0.0f), vec3(0.0f, 1.7f, -1.0f), 0.0f, 1.0f);
 }
+
+/* BASELINE config 4 stand-in ("San-Miguel-class", wurblpt-san-miguel.cpp:36-44,58-70): a
+ * courtyard whose triangle count is dominated by foliage -- clouds of small two-sided leaf quads
+ * around tree crowns and hedges -- plus ground, facades, arcade columns and furniture.  As in the
+ * reference application every material is two-sided (ImportBitTwoSidedMaterials), there are no
+ * light sources, and the environment is a constant texture without importance sampling, so all
+ * light comes from rays that escape.  `triangles` is the approximate total. */
+extern "C" wpt_host_scene* wpt_host_courtyard_like(unsigned int seed, unsigned int triangles, unsigned int texSize,
+        unsigned int width, unsigned int height)
+{
+    Scene* scenePtr = new Scene;
+    Scene& scene = *scenePtr;
+    Rng rng(seed);
+    const int ts = int(texSize);
+    const float detail = std::sqrt(float(triangles) / 1.0e7f); /* tessellation of the architecture */
+
+    Texture* groundTex = makeColorTexture(scene, rng, ts, vec3(0.5f, 0.45f, 0.38f), vec3(0.72f, 0.68f, 0.6f), 16, 16, false);
+    Texture* groundNrm = makeNormalMap(scene, rng, ts, 5.0f);
+    Texture* facadeTex = makeColorTexture(scene, rng, ts, vec3(0.75f, 0.6f, 0.4f), vec3(0.9f, 0.8f, 0.62f), 10, 6, false);
+    Texture* leafTex = makeColorTexture(scene, rng, ts / 2 > 4 ? ts / 2 : 4, vec3(0.08f, 0.3f, 0.05f), vec3(0.3f, 0.6f, 0.15f), 2, 2, true);
+    Texture* barkTex = makeColorTexture(scene, rng, ts / 2 > 4 ? ts / 2 : 4, vec3(0.25f, 0.17f, 0.1f), vec3(0.4f, 0.3f, 0.2f), 1, 8, false);
+
+    auto twoSided = [&](Material* m) { return scene.take(new MaterialTwoSided(m, m), "two-sided"); };
+    MaterialLambertian* groundBase = new MaterialLambertian(vec3(0.7f), groundTex);
+    groundBase->normalTex = groundNrm;
+    Material* groundMat = twoSided(scene.take(groundBase, "ground"));
+    MaterialModPhong* facadeBase = new MaterialModPhong;
+    facadeBase->haveNIR = false;
+    facadeBase->diffuse = vec4(0.7f, 0.7f, 0.7f, 0.0f);
+    facadeBase->diffuseTex = facadeTex;
+    facadeBase->specular = vec4(0.05f, 0.05f, 0.05f, 0.0f);
+    facadeBase->shininess = 20.0f;
+    facadeBase->opacity = 1.0f;
+    Material* facadeMat = twoSided(scene.take(facadeBase, "facade"));
+    MaterialModPhong* leafBase = new MaterialModPhong;
+    leafBase->haveNIR = false;
+    leafBase->diffuse = vec4(0.6f, 0.6f, 0.6f, 0.0f);
+    leafBase->diffuseTex = leafTex;
+    leafBase->diffuseTexHasAlpha = true;
+    leafBase->specular = vec4(0.06f, 0.06f, 0.06f, 0.0f);
+    leafBase->shininess = 25.0f;
+    leafBase->opacity = 1.0f;
+    Material* leafMat = twoSided(scene.take(leafBase, "leaf"));
+    Material* barkMat = twoSided(scene.take(new MaterialLambertian(vec3(0.6f), barkTex), "bark"));
+    Material* woodMat = twoSided(scene.take(new MaterialModPhong(vec3(0.5f, 0.35f, 0.22f), vec3(0.12f), 40.0f), "wood"));
+
+    size_t soFar = 0; /* triangles of the architecture */
+    auto addInstance = [&](Mesh* mesh, const Material* material) {
+        soFar += mesh->triangleCount();
+        scene.take(new MeshInstance(mesh, material));
+    };
+    const quat layFlat = toQuat(radians(-90.0f), vec3(1.0f, 0.0f, 0.0f));
+    const float halfX = 14.0f, halfZ = 10.0f, wallH = 9.0f;
+    auto T = [&](const vec3& t, const vec3& s, const quat& r = quat::null()) { return Transformation(t, r, s); };
+    addInstance(scene.take(generateQuad(T(vec3(0.0f), vec3(halfX, halfZ, 1.0f), layFlat), scaled(detail, 300, 2))), groundMat);
+    const int ws = scaled(detail, 120, 1);
+    addInstance(scene.take(generateQuad(T(vec3(0.0f, wallH * 0.5f, -halfZ), vec3(halfX, wallH * 0.5f, 1.0f)), ws)), facadeMat);
+    addInstance(scene.take(generateQuad(T(vec3(0.0f, wallH * 0.5f, halfZ), vec3(halfX, wallH * 0.5f, 1.0f), toQuat(radians(180.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), facadeMat);
+    addInstance(scene.take(generateQuad(T(vec3(-halfX, wallH * 0.5f, 0.0f), vec3(halfZ, wallH * 0.5f, 1.0f), toQuat(radians(90.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), facadeMat);
+    addInstance(scene.take(generateQuad(T(vec3(halfX, wallH * 0.5f, 0.0f), vec3(halfZ, wallH * 0.5f, 1.0f), toQuat(radians(-90.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), facadeMat);
+    /* arcade columns along the long sides, tables in the middle */
+    const int cylSlices = scaled(detail, 160, 6);
+    for (int side = 0; side < 2; side++)
+        for (int i = 0; i < 10; i++) {
+            float x = -halfX * 0.9f + i * (2.0f * halfX * 0.9f / 9.0f);
+            float z = (side == 0 ? -1.0f : 1.0f) * halfZ * 0.8f;
+            addInstance(scene.take(generateClosedCylinder(T(vec3(x, 1.8f, z), vec3(0.22f, 1.8f, 0.22f)), cylSlices)), facadeMat);
+        }
+    for (int i = 0; i < 8; i++) {
+        float x = -halfX * 0.5f + (i % 4) * (halfX / 3.0f) + 0.4f * (rng.u01() - 0.5f);
+        float z = (i < 4 ? -1.5f : 1.5f) + 0.4f * (rng.u01() - 0.5f);
+        addInstance(scene.take(generateCube(T(vec3(x, 0.72f, z), vec3(0.6f, 0.03f, 0.6f)), scaled(detail, 6, 1))), woodMat);
+        addInstance(scene.take(generateClosedCylinder(T(vec3(x, 0.36f, z), vec3(0.05f, 0.36f, 0.05f)), scaled(detail, 24, 6))), woodMat);
+    }
+    /* trees: trunk + a crown of leaf quads; hedges along the short sides: the same leaf soup in a box */
+    const size_t leafQuads = triangles / 2 > soFar / 2 + 64 ? triangles / 2 - soFar / 2 : 64;
+    const int trees = 12, hedges = 4;
+    const size_t perCloud = leafQuads / size_t(trees + hedges);
+    auto leafCloud = [&](const vec3& centre, const vec3& radii, bool box, size_t count) {
+        std::vector<vec3> pos, nrm;
+        std::vector<vec2> tc;
+        std::vector<unsigned int> ind;
+        pos.reserve(count * 4); nrm.reserve(count * 4); tc.reserve(count * 4); ind.reserve(count * 6);
+        for (size_t q = 0; q < count; q++) {
+            vec3 p;
+            if (box) {
+                p = vec3(2.0f * rng.u01() - 1.0f, 2.0f * rng.u01() - 1.0f, 2.0f * rng.u01() - 1.0f);
+            } else {
+                do {
+                    p = vec3(2.0f * rng.u01() - 1.0f, 2.0f * rng.u01() - 1.0f, 2.0f * rng.u01() - 1.0f);
+                } while (dot(p, p) > 1.0f);
+            }
+            p = centre + p * radii;
+            vec3 n = normalize(vec3(rng.u01() - 0.5f, rng.u01() - 0.2f, rng.u01() - 0.5f) + vec3(0.0f, 1e-3f, 0.0f));
+            vec3 a = normalize(cross(n, std::fabs(n.y()) < 0.9f ? vec3(0.0f, 1.0f, 0.0f) : vec3(1.0f, 0.0f, 0.0f)));
+            vec3 b = cross(n, a);
+            const float size = 0.025f + 0.035f * rng.u01();
+            const unsigned int base = (unsigned int)pos.size();
+            pos.push_back(p - size * a - size * b); pos.push_back(p + size * a - size * b);
+            pos.push_back(p - size * a + size * b); pos.push_back(p + size * a + size * b);
+            for (int k = 0; k < 4; k++)
+                nrm.push_back(n);
+            tc.push_back(vec2(0.0f, 0.0f)); tc.push_back(vec2(1.0f, 0.0f)); tc.push_back(vec2(0.0f, 1.0f)); tc.push_back(vec2(1.0f, 1.0f));
+            const unsigned int t[6] = { base, base + 1, base + 2, base + 1, base + 3, base + 2 };
+            ind.insert(ind.end(), t, t + 6);
+        }
+        addInstance(scene.take(new Mesh(pos, nrm, tc, ind)), leafMat);
+    };
+    for (int i = 0; i < trees; i++) {
+        float x = -halfX * 0.75f + (i % 6) * (2.0f * halfX * 0.75f / 5.0f) + 0.8f * (rng.u01() - 0.5f);
+        float z = (i < 6 ? -1.0f : 1.0f) * (halfZ * 0.42f + 0.8f * rng.u01());
+        float trunkH = 2.2f + 1.2f * rng.u01();
+        addInstance(scene.take(generateClosedCylinder(T(vec3(x, trunkH * 0.5f, z), vec3(0.16f, trunkH * 0.5f, 0.16f)), scaled(detail, 48, 6))), barkMat);
+        leafCloud(vec3(x, trunkH + 1.3f, z), vec3(1.7f + 0.5f * rng.u01(), 1.4f, 1.7f + 0.5f * rng.u01()), false, perCloud);
+    }
+    for (int i = 0; i < hedges; i++) {
+        float x = (i < 2 ? -1.0f : 1.0f) * halfX * 0.93f;
+        float z = (i % 2 == 0 ? -1.0f : 1.0f) * halfZ * 0.35f;
+        leafCloud(vec3(x, 0.6f, z), vec3(0.4f, 0.6f, halfZ * 0.3f), true, perCloud);
+    }
+
+    /* wurblpt-san-miguel.cpp:41-43: a constant environment, no importance sampling */
+    Texture* envTex = scene.take(new TextureConstant(vec4(1.0f)));
+    scene.take(new EnvironmentMapEquiRect(envTex));
+    /* a standing viewer in a corner of the courtyard looking across it (45 degrees, :58) */
+    return wptHostFinish(scenePtr, width, height, radians(45.0f), vec3(-halfX * 0.8f, 1.6f, halfZ * 0.6f), vec3(0.0f, 1.8f, -halfZ * 0.3f), 0.0f, 1.0f);
+}
