@@ -219,11 +219,11 @@ def main():
         achieved = bps * avg_samples / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:
+            # HBM bytes per launch of this workload, from the committed rocprofv3 PMC passes
+            # (FETCH_SIZE / WRITE_SIZE, separate runs; tools/profile_round.sh + tools/collect_profiles.py)
             try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == name and world == 1:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("workloads", {}).get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

@@ -1,0 +1,61 @@
+"""Copies the judged summaries of a tools/profile_round.sh run from gpurun_out/ into profiles/.
+usage: python tools/collect_profiles.py <tag> <round-prefix>     e.g.  v3 r01_v3"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, prefix = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "profiles")
+WORK = {"c": ("cornell", "cornell_1024x1024_1024spp_ggx_glass"),
+        "s": ("sponza", "sponza_like_1920x1080_256spp_envmap_is"),
+        "y": ("courtyard", "courtyard_like_10M_1920x1080_121spp")}
+
+
+def counters(suffix):
+    agg = collections.defaultdict(list)
+    for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_*" % suffix, ""))):
+        f = os.path.join(d, "pmc_counter_collection.csv")
+        if not os.path.exists(f):
+            continue
+        for r in csv.DictReader(open(f)):
+            if "wpt_pathtrace" in r["Kernel_Name"]:
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+traffic = {}
+for letter, (short, workload) in WORK.items():
+    st = os.path.join(ROOT, "gpurun_out", "stats_%s_%s" % (tag, short), "stats_kernel_stats.csv")
+    if os.path.exists(st):
+        shutil.copy(st, os.path.join(OUT, "%s_kernel_stats_%s.csv" % (prefix, short)))
+    log = os.path.join(ROOT, "gpurun_out", "stats_%s_%s.log" % (tag, short))
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith("{\"metric\"")]
+        if lines:
+            open(os.path.join(OUT, "%s_bench_under_rocprof_%s.json" % (prefix, short)), "w").write(lines[-1])
+    agg = counters(tag + letter)
+    if not agg:
+        continue
+    with open(os.path.join(OUT, "%s_pmc_%s.txt" % (prefix, short)), "w") as f:
+        f.write("# rocprofv3 --pmc passes (one counter group per run, tools/profile_round.sh) of\n# python3 bench.py --workload %s --no-cpu-baseline; mean over the launches of each kernel\n" % workload)
+        for (k, c), v in sorted(agg.items()):
+            f.write("%-58s %-30s launches=%d mean=%.6g\n" % (k, c, len(v), sum(v) / len(v)))
+    prod = [k for (k, c) in agg if c == "FETCH_SIZE" and ", true, false, 2" not in k]
+    if prod:
+        k = prod[0]
+        fetch = sum(agg[(k, "FETCH_SIZE")]) / len(agg[(k, "FETCH_SIZE")])
+        write = sum(agg[(k, "WRITE_SIZE")]) / len(agg[(k, "WRITE_SIZE")]) if (k, "WRITE_SIZE") in agg else 0.0
+        traffic[workload] = {
+            "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
+            "fetch_size_kib": fetch, "write_size_kib": write, "kernel": k,
+            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_%s.txt); "
+                   "FETCH_SIZE x 2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KiB -> bytes" % (prefix, short)}
+if traffic:
+    json.dump({"workloads": traffic}, open(os.path.join(OUT, "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))

@@ -13,7 +13,8 @@
  * stream 48 B per triangle (three dwordx4 loads), the shading stream 96 B per triangle and is
  * touched once per ray, after traversal (the reference builds the full HitRecord for every
  * accepted candidate, hitable_triangle.hpp:277-324; deferring it to the final candidate does
- * not change any value).  The traversal stack lives in LDS, one column per lane.
+ * not change any value).  Traversal needs no stack: every node carries the index of the first
+ * node behind its subtree (wpt_pathtrace.inc.h).
  */
 #ifndef WPT_DEVICE_H
 #define WPT_DEVICE_H

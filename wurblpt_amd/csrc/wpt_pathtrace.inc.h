@@ -10,9 +10,9 @@
  *
  *  - Every lane is a small state machine (NEW ray -> NODE steps <-> LEAF tests -> SHADE or
  *    NEE-END -> ...).  The 64 lanes of a wave are in different states at any time, so the wave
- *    runs its own scheduler: each round it counts the lanes per state with ballots, runs the
- *    code of the most populated state for exactly those lanes, and leaves the hot NODE loop
- *    as soon as too few lanes remain in it.  Lanes in other states simply wait for their turn.
+ *    runs its own scheduler: each round it counts the lanes per state with ballots and runs
+ *    either the traversal loop (left as soon as too few lanes remain in it) or one long round
+ *    that serves the SHADE, NEE-END and NEW lanes together.  Lanes in other states simply wait.
  *    Each lane still executes its own operations in the reference's order, so results do not
  *    change; only SIMD utilisation does (v0 without the scheduler: 18 % active lanes).
  *
@@ -68,7 +68,7 @@ struct KernelArgs {
     uint32_t* pixelCounter; /* LDS-state kernel: next unassigned pixel of the block (zero at launch) */
     float* frame;
     wpt_counters* counters;
-    unsigned long long* schedStats; /* COUNT builds: 11 scheduler statistics, or NULL */
+    unsigned long long* schedStats; /* COUNT builds: 16 scheduler statistics, or NULL */
     uint32_t* status;               /* set to 1 by a launch that had to abort (bounded waits) */
 };
 
