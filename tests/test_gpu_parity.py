@@ -292,3 +292,18 @@ def test_courtyard_like_two_sided_foliage_constant_env_bit_exact(dev, oracle):
     finally:
         dev.lib().wpt_set_launch_config(0, 0)
     assert bits_equal(got2, ref)
+
+
+@pytest.mark.parametrize("material", [0, 2, 3, 5])
+def test_furnace_scenes_bit_exact(dev, oracle, material):
+    """wurblpt-furnace-test.cpp with a tessellated sphere (Lambertian, ModPhong diffuse and
+    specular lobes, GGX) in a constant environment, no pixel jitter: GPU == oracle, and for the
+    Lambertian the analytic value albedo * 1 in the centre of the sphere."""
+    sc = host.furnace(48, 48, material, slices=32)
+    p = host.default_params()
+    p.randomize_ray_over_pixel = 0
+    ref, rc = oracle.render(sc, 4, p)
+    got, gc = dev.DeviceScene(sc).render(4, params=p, with_counters=True)
+    assert bits_equal(got, ref) and gc == rc
+    if material == 0:
+        assert float(np.median(got[18:30, 18:30])) == pytest.approx(0.42, rel=1e-6)

@@ -146,3 +146,74 @@ def test_random_triangle_scene_is_consistent(oracle):
     frame, c = oracle.render(sc, 2)
     assert np.isfinite(frame).all() and frame.sum() > 0
     assert c["rays"] >= c["samples"]
+
+
+def _furnace_centre(oracle, material, spp_sqrt=6):
+    """wurblpt-furnace-test.cpp (tessellated sphere): centre block of the sphere, no pixel jitter"""
+    sc = host.furnace(64, 64, material)
+    p = host.default_params()
+    p.randomize_ray_over_pixel = 0
+    img, cnt = oracle.render(sc, spp_sqrt, p)
+    assert np.isfinite(img).all()
+    assert np.array_equal(img[0, 0], np.ones(3, np.float32))  # background: the constant environment, exactly
+    return img[24:40, 24:40, 0], img, cnt
+
+
+def test_furnace_lambertian_is_exact(oracle):
+    """A cosine-sampled Lambertian sphere of albedo a in a constant environment of radiance 1:
+    every sample that escapes contributes a * cos/pi / (cos/pi) * 1 = a, so a pixel is a times the
+    fraction of its samples that escape at once (a path that meets the tessellated sphere again,
+    because the shading normal lies above the facet, returns a^2 or nothing) -- an analytic pin of MaterialLambertian::scatter, the
+    attenuation/pdf bookkeeping of tracePath and EnvironmentMap::L on escape that needs no
+    reference build (rows a4, a15, a21)."""
+    for material, albedo in ((0, 0.42), (1, 1.0)):
+        c, _, cnt = _furnace_centre(oracle, material)
+        exact = np.abs(c / np.float32(albedo) - 1.0) < 1e-6  # all 36 samples escaped after one bounce
+        assert exact.mean() > 0.9, exact.mean()
+        assert c.max() <= albedo * (1 + 1e-6) and np.median(c) == pytest.approx(albedo, rel=1e-6)
+        assert c.mean() == pytest.approx(albedo, rel=5e-3)
+        assert cnt["pdf_tests"] == 0  # no hot spots: no light sampling
+
+
+def test_furnace_ggx_matches_an_independent_evaluation_of_the_published_model(oracle):
+    """MaterialGGX with albedo 1 (Schlick F = 1): the weight of a sample is G2/G1 of Heitz 2018,
+    VNDF-sampled.  The expectation is evaluated here with numpy from the paper's formulas only,
+    for the incidence angles of the centre block (row a17)."""
+    c, _, _ = _furnace_centre(oracle, 5, spp_sqrt=8)
+    a = 0.5
+    rng = np.random.default_rng(3)
+
+    def expected(theta, n=200000):
+        V = np.array([np.sin(theta), 0.0, np.cos(theta)])
+        u1, u2 = rng.random(n), rng.random(n)
+        Vh = np.array([a * V[0], a * V[1], V[2]])
+        Vh /= np.linalg.norm(Vh)
+        lensq = Vh[0] ** 2 + Vh[1] ** 2
+        T1 = np.array([-Vh[1], Vh[0], 0.0]) / np.sqrt(lensq) if lensq > 0 else np.array([1.0, 0.0, 0.0])
+        T2 = np.cross(Vh, T1)
+        r, phi = np.sqrt(u1), 2 * np.pi * u2
+        t1, t2 = r * np.cos(phi), r * np.sin(phi)
+        s = 0.5 * (1 + Vh[2])
+        t2 = (1 - s) * np.sqrt(1 - t1 * t1) + s * t2
+        Nh = t1[:, None] * T1 + t2[:, None] * T2 + np.sqrt(np.maximum(0, 1 - t1 * t1 - t2 * t2))[:, None] * Vh
+        Ne = np.stack([a * Nh[:, 0], a * Nh[:, 1], np.maximum(0, Nh[:, 2])], 1)
+        Ne /= np.linalg.norm(Ne, axis=1)[:, None]
+        L = 2 * (Ne @ V)[:, None] * Ne - V
+
+        def lam(v):
+            return 0.5 * (-1 + np.sqrt(1 + (a * a * v[..., 0] ** 2 + a * a * v[..., 1] ** 2) / v[..., 2] ** 2))
+        w = np.where(L[:, 2] > 0, (1 + lam(V)) / (1 + lam(V) + lam(L)), 0.0)
+        return w.mean()
+    want = np.mean([expected(t) for t in (0.0, 0.2, 0.4, 0.6)])
+    assert c.mean() == pytest.approx(want, rel=0.03), (c.mean(), want)
+
+
+def test_furnace_modphong_conserves_energy_in_expectation(oracle):
+    """MaterialModPhong(kd = 1, ks = 0): the lobe choice is clamped to [0.1, 0.9]
+    (material_modphong.hpp:213-219), so single samples vary, but the estimator stays unbiased:
+    the centre of the sphere converges to 1 (row a19); no material returns more than it received."""
+    c, _, _ = _furnace_centre(oracle, 2, spp_sqrt=10)
+    assert c.mean() == pytest.approx(1.0, abs=0.01)
+    for material in (3, 4):
+        c, _, _ = _furnace_centre(oracle, material, spp_sqrt=6)
+        assert 0.8 < c.mean() < 1.005

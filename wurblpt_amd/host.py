@@ -29,6 +29,8 @@ def lib():
         L.wpt_host_random_triangles.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint, C.c_float]
         L.wpt_host_sponza_like.restype = C.c_void_p
         L.wpt_host_sponza_like.argtypes = [C.c_uint, C.c_float, C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint]
+        L.wpt_host_furnace.restype = C.c_void_p
+        L.wpt_host_furnace.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_uint]
         L.wpt_host_courtyard_like.restype = C.c_void_p
         L.wpt_host_courtyard_like.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
         L.wpt_host_scene_desc.restype = C.POINTER(_abi.SceneDesc)
@@ -111,6 +113,14 @@ def courtyard_like(width, height, seed=2, triangles=10_000_000, tex_size=1024):
     importance sampling (wurblpt-san-miguel.cpp:36-44).  `triangles` is the approximate total."""
     h = lib().wpt_host_courtyard_like(seed, triangles, tex_size, width, height)
     return HostScene(h, width, height, "courtyard_like(seed=%d,triangles=%d)" % (seed, triangles))
+
+
+def furnace(width, height, material=0, slices=64):
+    """wurblpt-furnace-test.cpp with a tessellated sphere: one material in a constant environment
+    of radiance 1.  material: 0 Lambertian 0.42, 1 Lambertian 1, 2 ModPhong(1,0), 3 ModPhong(0,1),
+    4 ModPhong(.5,.5), 5 GGX albedo 1 roughness 0.5."""
+    h = lib().wpt_host_furnace(material, slices, width, height)
+    return HostScene(h, width, height, "furnace(material=%d)" % material)
 
 
 def bvh_build(boxes):

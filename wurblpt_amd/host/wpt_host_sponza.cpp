@@ -391,3 +391,29 @@ extern "C" wpt_host_scene* wpt_host_courtyard_like(unsigned int seed, unsigned i
     /* a standing viewer in a corner of the courtyard looking across it (45 degrees, :58) */
     return wptHostFinish(scenePtr, width, height, radians(45.0f), vec3(-halfX * 0.8f, 1.6f, halfZ * 0.6f), vec3(0.0f, 1.8f, -halfZ * 0.3f), 0.0f, 1.0f);
 }
+
+/* wurblpt-furnace-test.cpp:36-86 with the tessellated sphere the file keeps as its alternative
+ * (the analytic Sphere hitable is a "next" row): a unit sphere of one material inside a constant
+ * environment of radiance 1, camera at (0,0,5), 40 degrees.  With a cosine-sampled Lambertian
+ * of albedo a every sample of a pixel on the sphere is a * 1 exactly (up to rounding), which
+ * pins scatter / attenuation / pdf and the environment term without any reference build.
+ * material: 0 Lambertian 0.42, 1 Lambertian 1, 2 ModPhong(1,0), 3 ModPhong(0,1), 4 ModPhong(.5,.5),
+ * 5 GGX albedo 1 roughness 0.5 */
+extern "C" wpt_host_scene* wpt_host_furnace(int material, int slices, unsigned int width, unsigned int height)
+{
+    Scene* scenePtr = new Scene;
+    Scene& scene = *scenePtr;
+    Texture* tex = scene.take(new TextureConstant(vec4(1.0f)));
+    scene.take(new EnvironmentMapEquiRect(tex));
+    Material* mat;
+    switch (material) {
+    case 0: mat = scene.take(new MaterialLambertian(vec3(0.42f))); break;
+    case 1: mat = scene.take(new MaterialLambertian(vec3(1.0f))); break;
+    case 2: mat = scene.take(new MaterialModPhong(vec3(1.0f), vec3(0.0f))); break;
+    case 3: mat = scene.take(new MaterialModPhong(vec3(0.0f), vec3(1.0f))); break;
+    case 4: mat = scene.take(new MaterialModPhong(vec3(0.5f), vec3(0.5f))); break;
+    default: mat = scene.take(new MaterialGGX(vec3(1.0f), vec2(0.5f, 0.5f))); break;
+    }
+    scene.take(new MeshInstance(scene.take(generateSphere(Transformation(), slices, slices / 2)), mat));
+    return wptHostFinish(scenePtr, width, height, radians(40.0f), vec3(0.0f, 0.0f, 5.0f), vec3(0.0f, 0.0f, 0.0f), 0.0f, 1.0f);
+}
