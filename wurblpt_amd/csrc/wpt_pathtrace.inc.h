@@ -105,7 +105,7 @@ __device__ __forceinline__ void accumulate(const wpt_params& par, f3 opl, float 
         a2 += radiance.z;
 }
 
-template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, bool ORDERED>
+template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, bool ORDERED, bool PAIRS = false>
 __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 {
     extern __shared__ float4 ldsScene[];
@@ -354,23 +354,40 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         sched[2] += nNode;
                     }
                     if (state == S_NODE) {
-                        /* AABB::mayHit + the stackless form of BVH::hit's walk */
-                        const float4 n0 = node4(2 * (nodeBase + node));
-                        const float4 n1 = node4(2 * (nodeBase + node) + 1);
-                        if (COUNT)
-                            lc.nodes++;
-                        const uint32_t skip = __float_as_uint(n1.z);
-                        const uint32_t prim = __float_as_uint(n1.w);
-                        const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray.o, aux.inv, par.min_hit_distance,
-                                (ORDERED && !exact) ? amaxCull : amax);
-                        /* select form of: hit & inner -> next node; hit & leaf -> test it; else -> skip */
-                        const bool toLeaf = hit && prim < NODE_EMPTY;
-                        const uint32_t next = (hit && prim == NODE_INNER) ? node + 1 : skip;
-                        leafPrim = toLeaf ? prim : leafPrim;
-                        node = toLeaf ? node : next;
-                        state = toLeaf ? (int)S_LEAF : (int)S_NODE;
-                        if (!toLeaf && node >= nodeCount)
-                            state = endOfRayState();
+                        /* AABB::mayHit + the stackless form of BVH::hit's walk; true when the walk
+                         * descends into the node's first child, which is the next node in memory */
+                        auto nodeStep = [&](const float4& n0, const float4& n1) {
+                            if (COUNT)
+                                lc.nodes++;
+                            const uint32_t skip = __float_as_uint(n1.z);
+                            const uint32_t prim = __float_as_uint(n1.w);
+                            const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray.o, aux.inv, par.min_hit_distance,
+                                    (ORDERED && !exact) ? amaxCull : amax);
+                            /* select form of: hit & inner -> next node; hit & leaf -> test it; else -> skip */
+                            const bool toLeaf = hit && prim < NODE_EMPTY;
+                            const bool down = hit && prim == NODE_INNER;
+                            const uint32_t next = down ? node + 1 : skip;
+                            leafPrim = toLeaf ? prim : leafPrim;
+                            node = toLeaf ? node : next;
+                            state = toLeaf ? (int)S_LEAF : (int)S_NODE;
+                            if (!toLeaf && node >= nodeCount)
+                                state = endOfRayState();
+                            return down;
+                        };
+                        const uint32_t at = 2 * (nodeBase + node);
+                        const float4 n0 = node4(at), n1 = node4(at + 1);
+                        if (PAIRS) {
+                            /* Option for scenes in HBM, measured slower and off (Sponza-class 0.95x,
+                             * 10 M triangles 0.93x): a node step is a dependent memory round trip, so
+                             * the neighbouring node (the first child, usually in the same 128-byte
+                             * line) is fetched with it and a lane that descends takes two steps per trip */
+                            const uint32_t at1 = node + 1 < nodeCount ? at + 2 : at;
+                            const float4 m0 = node4(at1), m1 = node4(at1 + 1);
+                            if (nodeStep(n0, n1))
+                                nodeStep(m0, m1);
+                        } else {
+                            nodeStep(n0, n1);
+                        }
                     }
                 }
             }
