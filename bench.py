@@ -112,7 +112,9 @@ def main():
     ap.add_argument("--samples-sqrt", type=int, default=0, help="override spp (debug only; changes the workload name)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--streams", type=int, default=4, help="concurrent block launches per GPU when N > 1")
+    ap.add_argument("--streams", type=int, default=8, help="concurrent block launches per GPU when N > 1")
+    ap.add_argument("--force-blocks", type=int, default=0, metavar="RANKS",
+                    help="N = 1 only (rehearsal): run the N > 1 code path -- block queue, worker threads, streams -- as if RANKS ranks shared the frame; this process renders every block")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant / scheduler tuning word for wpt_set_launch_config (experiments)")
     args = ap.parse_args()
 
@@ -128,10 +130,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the path tracer has no CPU fallback"
+    # rehearsal on a one-GPU box: WPT_BENCH_DEVICE=0 WPT_BENCH_BACKEND=gloo puts every rank on cuda:0
+    # (RCCL refuses two ranks on one device); the driver's runs use neither
+    if "WPT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["WPT_BENCH_DEVICE"])
+    backend = os.environ.get("WPT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     w = dict(WORKLOADS[args.workload])
     name = args.workload
@@ -160,12 +170,13 @@ def main():
     # ---- the step ----
     kernel_ms = []  # (milliseconds, samples) per launch on this rank, timed steps only
     from wurblpt_amd import blocks
+    sharded = world > 1 or args.force_blocks > 0
     store = dist.distributed_c10d._get_default_store() if world > 1 else None
-    streams = [torch.cuda.Stream() for _ in range(args.streams)] if world > 1 else []
-    block_size = blocks.plan_block_size(pixels, width, world, args.streams) if world > 1 else pixels
+    streams = [torch.cuda.Stream() for _ in range(args.streams)] if sharded else []
+    block_size = blocks.plan_block_size(pixels, width, max(world, args.force_blocks), args.streams) if sharded else pixels
 
     def step(index, timed):
-        if world == 1:
+        if not sharded:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main_stream)
             dscene.render_block_into(frame, ssqrt, None, params, None, main_stream)

@@ -55,9 +55,12 @@ def free_port():
 
 
 def test_plan_block_size():
-    assert blocks.plan_block_size(1024 * 1024, 1024, 1, 1) == 1024 * 1024 // 2
-    bs = blocks.plan_block_size(1024 * 1024, 1024, 8, 4)
-    assert bs % (8 * 1024) == 0 and 4096 <= bs <= 1024 * 1024 // 32
+    assert blocks.plan_block_size(1024 * 1024, 1024, 1, 1) == 1024 * 1024
+    assert blocks.plan_block_size(1024 * 1024, 1024, 1, 1, blocks_per_worker=2) == 1024 * 1024 // 2
+    bs = blocks.plan_block_size(1024 * 1024, 1024, 8, 8)  # one block per worker: 64 strips of 16 rows
+    assert bs == 16 * 1024
+    bs = blocks.plan_block_size(1920 * 1080, 1920, 8, 8)
+    assert bs % (8 * 1920) == 0 and 4096 <= bs <= 1920 * 1080 // 64
     assert blocks.plan_block_size(100, 10, 8, 4) == 100  # never below the reference's 4096 -> whole frame
 
 

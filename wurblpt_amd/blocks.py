@@ -12,10 +12,13 @@ Backend agnostic: tests run it with gloo on CPU tensors and the CPU restatement 
 import threading
 
 
-def plan_block_size(pixels, width, world, workers_per_rank, min_block=4096, blocks_per_worker=2):
+def plan_block_size(pixels, width, world, workers_per_rank, min_block=4096, blocks_per_worker=1):
     """Whole rows, about `blocks_per_worker` blocks per worker, never below the reference's
     default block of 4096 pixels (mpi.hpp:178), and a multiple of 8 rows where possible so that
-    the kernel can map waves to 8x8 pixel tiles."""
+    the kernel can map waves to 8x8 pixel tiles.  One block per worker by default: a lane owns a
+    pixel for all its samples, so a GPU is only as busy as the number of its pixels that are in
+    flight -- with all workers' blocks launched at once (one HIP stream each) every pixel of the
+    rank's share is resident from the start, and the strips of a rank interleave over the image."""
     size = max(min_block, -(-pixels // max(1, world * workers_per_rank * blocks_per_worker)))
     rows = -(-size // width)
     if rows > 8:
@@ -86,5 +89,8 @@ def reduce_frame(frame, dst=0):
     """Final gather: sum of the per-rank frames onto rank `dst` (RCCL over xGMI for CUDA tensors)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
+        if frame.is_cuda and dist.get_backend() == "gloo":
+            dist.all_reduce(frame, op=dist.ReduceOp.SUM)  # gloo has no reduce for device tensors (rehearsals only)
+        else:
+            dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
     return frame
