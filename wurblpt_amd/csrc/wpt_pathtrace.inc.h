@@ -75,36 +75,6 @@ struct KernelArgs {
 /* lane states, in scheduling priority order for ties */
 enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5 };
 
-/* HitableTriangle::pdfValue (hitable_triangle.hpp:405-423) for one hot spot */
-__device__ __forceinline__ float hotSpotPdf(float4 g0, float4 g1, float4 g2, f3 org, f3 dir, const RayAux& h)
-{
-    const f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
-    Candidate c;
-    float value = 0.0f;
-    if (triangleTest(v0, v1, v2, org, h, 0.0f, k_maxval, c)) {
-        f3 edgeCross = cross(sub(v1, v0), sub(v2, v0));
-        float edgeCrossLength = __builtin_sqrtf(dot(edgeCross, edgeCross));
-        f3 faceNormal = divs(edgeCross, edgeCrossLength);
-        float faceArea = 0.5f * edgeCrossLength;
-        float cosine = __builtin_fabsf(dot(faceNormal, neg(dir)));
-        float distance_squared = c.a * c.a;
-        value = distance_squared / (cosine * faceArea);
-    }
-    return value;
-}
-
-/* SensorRGB::accumulateRadiance (sensor_rgb.hpp:63-80) */
-__device__ __forceinline__ void accumulate(const wpt_params& par, f3 opl, float distanceToLight, f4 radiance, float& a0, float& a1, float& a2)
-{
-    const bool dOk = distanceToLight >= par.min_dist_to_light && distanceToLight <= par.max_dist_to_light;
-    if (dOk && opl.x >= par.min_path_len && opl.x <= par.max_path_len)
-        a0 += radiance.x;
-    if (dOk && opl.y >= par.min_path_len && opl.y <= par.max_path_len)
-        a1 += radiance.y;
-    if (dOk && opl.z >= par.min_path_len && opl.z <= par.max_path_len)
-        a2 += radiance.z;
-}
-
 template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, bool ORDERED, bool PAIRS = false>
 __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 {
@@ -150,35 +120,22 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     }
     if (!inBlock)
         pixel = args.blockStart;
-    const uint32_t px = pixel % args.width;
-    const uint32_t py = pixel / args.width;
     const uint32_t samples = args.samplesSqrt * args.samplesSqrt;
-    const float invSamplesSqrt = 1.0f / (float)args.samplesSqrt;
-    const float invW = 1.0f / (float)args.width;
-    const float invH = 1.0f / (float)args.height;
-    const float invHotSpots = 1.0f / (float)sv.hotspotCount;
-    const bool haveEnv = (F & FEAT_ENVMAP) && sv.envType != WPT_ENV_NONE;
+    FrameArgs fa;
+    fa.cam = args.cam;
+    fa.par = args.par;
+    fa.width = args.width;
+    fa.height = args.height;
+    fa.samplesSqrt = args.samplesSqrt;
 
-    Prng prng;
-    prngSeed(prng, pixel);
-    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+    /* ---- per-lane state: the pixel's path (wpt_blocks.h) and the traversal registers ---- */
+    PathState ps;
+    pathStateInit(ps, pixel, args.width);
     LaneCounters lc = { 0, 0, 0, 0, 0 };
     /* wave-level scheduler statistics (COUNT builds): rounds and lane counts per state */
     unsigned long long sched[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-
-    /* ---- per-lane state ---- */
     int state = inBlock ? S_NEW : S_DONE;
-    uint32_t sampleIndex = 0;
-    uint32_t pathComponent = 0;
-    int rayKind = RAY_PATH;
-    Ray ray;
-    ray.o = mk3(0.0f, 0.0f, 0.0f);
-    ray.d = mk3(0.0f, 0.0f, 1.0f);
-    ray.ri = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-    f4 att = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-    f3 opl = mk3(0.0f, 0.0f, 0.0f); /* opticalPathLength; SensorRGB reads channels 0..2 only */
-    /* traversal registers */
-    RayAux aux = rayAux(ray.d);
+    RayAux aux = rayAux(ps.ray.d);
     uint32_t node = 0, leafPrim = 0;
     uint32_t nodeBase = 0; /* ORDERED: first node of the ray's octant copy of the BVH */
     bool exact = !ORDERED; /* true: the reference's own walk (copy 0, exact bounds) */
@@ -187,25 +144,20 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     Candidate best;
     best.prim = NO_HIT;
     best.a = best.invDet = best.U = best.V = best.W = 0.0f;
-    /* pending continuation of the path while a next-event ray is in flight */
-    f4 nextAtt = att;
-    f4 neeFactor = att; /* attenuation * directSR.attenuation / directPdf * weight (wurblpt.hpp:211,243), complete except for the emitted radiance */
-    f3 srDir = ray.d;
-    uint32_t chosenPrim = NO_HIT;
 
-    auto beginRay = [&](int kind) {
-        aux = rayAux(ray.d);
+    /* start the traversal of ps.ray */
+    auto beginRay = [&]() {
+        aux = rayAux(ps.ray.d);
         node = 0;
         amax = k_maxval;
         best.prim = NO_HIT;
         if (ORDERED) {
-            const uint32_t octant = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
+            const uint32_t octant = (ps.ray.d.x < 0.0f ? 1u : 0u) | (ps.ray.d.y < 0.0f ? 2u : 0u) | (ps.ray.d.z < 0.0f ? 4u : 0u);
             nodeBase = octant * nodeCount;
             exact = false;
             amaxCull = k_maxval;
             second = k_maxval;
         }
-        rayKind = kind;
         state = S_NODE;
         if (COUNT)
             lc.rays++;
@@ -226,40 +178,14 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             best.prim = NO_HIT;
             return (int)S_NODE;
         }
-        return rayKind == RAY_PATH ? (int)S_SHADE : (int)S_NEEEND;
+        return ps.rayKind == RAY_PATH ? (int)S_SHADE : (int)S_NEEEND;
     };
-
-    /* mean pdf over all hot spots of hitting them from org along dir (wurblpt.hpp:181-184) */
-    auto hotSpotsMeanPdf = [&](f3 org, f3 dir) {
-        const RayAux h = rayAux(dir);
-        float sum = 0.0f;
-        for (uint32_t i = 0; i < sv.hotspotCount; i++) {
-            const uint32_t p = sv.hotspots[i].prim;
-            sum += hotSpotPdf(tri4(3 * p), tri4(3 * p + 1), tri4(3 * p + 2), org, dir, h);
-            if (COUNT)
-                lc.pdfs++;
-        }
-        sum *= invHotSpots;
-        return sum;
-    };
-
-    /* wurblpt.hpp:254-273: continue the path along the scattered direction (ray.o already is
-     * the hit position), Russian roulette */
-    auto advancePath = [&]() {
-        att = nextAtt;
-        ray.d = srDir;
-        const float mx = max4(att);
-        if (mx < par.rr_threshold && pathComponent >= 5) {
-            const float q = clampr(1.0f - mx, 0.0f, 0.95f);
-            if (in01(prng) < q) {
-                state = S_NEW;
-                return;
-            }
-            const float rrWeight = 1.0f / (1.0f - q);
-            att = sclr(att, rrWeight);
-        }
-        pathComponent++;
-        beginRay(RAY_PATH);
+    /* what a block of wpt_blocks.h asks for next */
+    auto afterBlock = [&](int next) {
+        if (next == NEXT_TRACE)
+            beginRay();
+        else
+            state = next == NEXT_NEW ? (int)S_NEW : (int)S_DONE;
     };
 
     for (;;) {
@@ -327,7 +253,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
                         Candidate c;
                         const float bound = (ORDERED && !exact) ? amaxCull : amax;
-                        if (triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), ray.o, aux,
+                        if (triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), ps.ray.o, aux,
                                     par.min_hit_distance, bound, c)) {
                             c.prim = leafPrim;
                             if (ORDERED && !exact) {
@@ -361,7 +287,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                                 lc.nodes++;
                             const uint32_t skip = __float_as_uint(n1.z);
                             const uint32_t prim = __float_as_uint(n1.w);
-                            const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray.o, aux.inv, par.min_hit_distance,
+                            const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.ray.o, aux.inv, par.min_hit_distance,
                                     (ORDERED && !exact) ? amaxCull : amax);
                             /* select form of: hit & inner -> next node; hit & leaf -> test it; else -> skip */
                             const bool toLeaf = hit && prim < NODE_EMPTY;
@@ -400,98 +326,8 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 sched[5]++;
                 sched[6] += cShade;
             }
-            if (state == S_SHADE) {
-                /* tracePath, one path component (wurblpt.hpp:131-252) */
-                if (best.prim == NO_HIT) {
-                    if (haveEnv) {
-                        f4 rad = mul(att, envL(sv, ray.d));
-                        accumulate(par, mk3(k_maxval, k_maxval, k_maxval), k_maxval, rad, acc0, acc1, acc2);
-                    }
-                    state = S_NEW;
-                } else {
-                    opl = add(opl, scl(best.a, mk3(ray.ri.x, ray.ri.y, ray.ri.z)));
-                    if (!(pathComponent + 1 < par.max_path_components)) {
-                        state = S_NEW;
-                    } else {
-                        Hit h = finishHit(sv, best, ray.o, ray.d);
-                        const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
-                        if (COUNT)
-                            lc.scatters++;
-                        const Scatter sr = materialScatter<F>(sv, m, ray, h, prng);
-                        {
-                            f4 rad = mul(att, materialEmitted<F>(sv, m, h));
-                            accumulate(par, opl, (pathComponent == 0 ? 0.0f : h.a), rad, acc0, acc1, acc2);
-                        }
-                        if (sr.type == SCATTER_NONE) {
-                            state = S_NEW;
-                        } else {
-                            nextAtt = mul(att, sr.att);
-                            if (sr.type == SCATTER_RANDOM) {
-                                if (sr.pdf > 0.0f)
-                                    nextAtt = divs(nextAtt, sr.pdf);
-                                else
-                                    nextAtt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-                            }
-                            srDir = sr.dir;
-                            bool shootNee = false;
-                            if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
-                                /* light sampling with MIS (wurblpt.hpp:179-220) */
-                                const float hotSpotsPdf = hotSpotsMeanPdf(h.p, sr.dir);
-                                nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
-                                uint32_t idx = (uint32_t)(in01(prng) * (float)sv.hotspotCount);
-                                idx = idx < sv.hotspotCount - 1 ? idx : sv.hotspotCount - 1;
-                                const wpt_hotspot& hs = sv.hotspots[idx];
-                                /* HitableTriangle::direction (hitable_triangle.hpp:425-443) */
-                                const f3 bary = inTriangle(in01x2(prng));
-                                f3 p = add(add(scl(bary.x, ld3(hs.p0)), scl(bary.y, ld3(hs.p1))), scl(bary.z, ld3(hs.p2)));
-                                if (hs.transform)
-                                    p = mat4mulPoint(hs.M, p);
-                                const f3 directDir = normalize(sub(p, h.p));
-                                const float directPdf = hotSpotsMeanPdf(h.p, directDir);
-                                if (directPdf > 0.0f) {
-                                    float dpdf;
-                                    f4 directAtt;
-                                    materialEval<F>(sv, m, ray, h, directDir, directAtt, dpdf);
-                                    if (dpdf > 0.0f) {
-                                        neeFactor = sclr(divs(mul(att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
-                                        chosenPrim = hs.prim;
-                                        ray.o = h.p;
-                                        ray.d = directDir;
-                                        shootNee = true;
-                                        beginRay(RAY_NEE_LIGHT);
-                                    }
-                                }
-                            } else if ((F & FEAT_ENVMAP) && sr.type == SCATTER_RANDOM && haveEnv && sv.envN > 0) {
-                                /* environment sampling with MIS (wurblpt.hpp:221-252) */
-                                const float lightsP = envP(sv, sr.dir);
-                                nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, lightsP));
-                                const f3 lightDir = envD(sv, prng);
-                                const float directPdf = envP(sv, lightDir);
-                                float dpdf;
-                                f4 directAtt;
-                                materialEval<F>(sv, m, ray, h, lightDir, directAtt, dpdf);
-                                if (dpdf > 0.0f) {
-                                    neeFactor = sclr(divs(mul(att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
-                                    ray.o = h.p;
-                                    ray.d = lightDir;
-                                    shootNee = true;
-                                    beginRay(RAY_NEE_ENV);
-                                }
-                            }
-                            /* The scattered ray's refractive index: every ScatterRandom record
-                             * carries the incoming ray's index unchanged (material_lambertian.hpp:83,
-                             * material_ggx.hpp:224, material_modphong.hpp:307), so while a next-event
-                             * ray is in flight ray.ri already is the value to continue with; only
-                             * explicit scattering (glass, transparent ModPhong) changes it. */
-                            if (!shootNee) {
-                                ray.o = h.p;
-                                ray.ri = sr.ri;
-                                advancePath();
-                            }
-                        }
-                    }
-                }
-            }
+            if (state == S_SHADE) /* tracePath, one path component (wurblpt.hpp:131-252) */
+                afterBlock(blockShade<F, COUNT>(sv, par, tri4, ps, best, lc));
             if (COUNT)
                 sched[12] += (unsigned long long)(clock64() - tBlock);
         }
@@ -501,24 +337,8 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 sched[7]++;
                 sched[8] += cNee;
             }
-            if (state == S_NEEEND) {
-                if (rayKind == RAY_NEE_LIGHT) {
-                    /* wurblpt.hpp:208-218: only the CHOSEN hot spot as nearest hit counts */
-                    if (best.prim == chosenPrim) {
-                        Hit lh = finishHit(sv, best, ray.o, ray.d);
-                        const wpt_material& lm = resolveMaterial<F>(sv, lh.material, lh);
-                        f4 rad = mul(neeFactor, materialEmitted<F>(sv, lm, lh));
-                        f3 oplLight = add(opl, scl(lh.a, mk3(ray.ri.x, ray.ri.y, ray.ri.z)));
-                        accumulate(par, oplLight, lh.a, rad, acc0, acc1, acc2);
-                    }
-                } else if (F & FEAT_ENVMAP) {
-                    if (best.prim == NO_HIT) {
-                        f4 rad = mul(neeFactor, envL(sv, ray.d));
-                        accumulate(par, mk3(k_maxval, k_maxval, k_maxval), k_maxval, rad, acc0, acc1, acc2);
-                    }
-                }
-                advancePath();
-            }
+            if (state == S_NEEEND) /* the next-event ray's contribution, then the path continues */
+                afterBlock(blockNeeEnd<F>(sv, par, ps, best));
             if (COUNT)
                 sched[13] += (unsigned long long)(clock64() - tBlock);
         }
@@ -529,45 +349,8 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 sched[9]++;
                 sched[10] += __popcll(__ballot(state == S_NEW));
             }
-            if (state == S_NEW) {
-                if (sampleIndex >= samples) {
-                    state = S_DONE;
-                } else {
-                    /* wurblpt.hpp:349-360: stratified jitter, the vertical stratum is drawn first */
-                    float u = (float)px, v = (float)py;
-                    if (par.randomize_ray_over_pixel) {
-                        const uint32_t j = sampleIndex / args.samplesSqrt;
-                        const uint32_t i = sampleIndex % args.samplesSqrt;
-                        const float fj = (float)j + in01(prng);
-                        const float fi = (float)i + in01(prng);
-                        u += fi * invSamplesSqrt;
-                        v += fj * invSamplesSqrt;
-                    } else {
-                        u += 0.5f;
-                        v += 0.5f;
-                    }
-                    u *= invW;
-                    v *= invH;
-                    /* Camera::getRay (camera.hpp:123-185), pinhole or thin lens */
-                    f3 P = mk3(mixr(args.cam.l, args.cam.r, u), mixr(args.cam.b, args.cam.t, v), -1.0f);
-                    f3 O = mk3(0.0f, 0.0f, 0.0f);
-                    if ((F & FEAT_LENS) && args.cam.lens_radius > 0.0f) {
-                        P = sclr(P, args.cam.focus_dist);
-                        f2 d = inUnitDisk(in01x2(prng));
-                        O = mk3(args.cam.lens_radius * d.x, args.cam.lens_radius * d.y, 0.0f);
-                    }
-                    f3 D = sub(P, O);
-                    O = add(O, mk3(0.0f, 0.0f, 0.0f));
-                    ray.o = add(ld3(args.cam.translation), quatRotate(args.cam.rotation, mul(O, ld3(args.cam.scaling))));
-                    ray.d = normalize(quatRotate(args.cam.rotation, D));
-                    ray.ri = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-                    att = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-                    opl = mk3(0.0f, 0.0f, 0.0f);
-                    pathComponent = 0;
-                    sampleIndex++;
-                    beginRay(RAY_PATH);
-                }
-            }
+            if (state == S_NEW) /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
+                afterBlock(blockNew<F>(fa, ps));
             if (COUNT) /* shader clock spent per kind of block: [11] traversal [12] shade [13] nee-end [14] new */
                 sched[14] += (unsigned long long)(clock64() - tBlock);
         }
@@ -577,9 +360,9 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         /* SensorRGB::finishPixel (sensor_rgb.hpp:82-87) */
         const float invSamples = 1.0f / (float)samples;
         float* out = args.frame + 3 * (size_t)pixel;
-        out[0] = invSamples * acc0;
-        out[1] = invSamples * acc1;
-        out[2] = invSamples * acc2;
+        out[0] = invSamples * ps.acc0;
+        out[1] = invSamples * ps.acc1;
+        out[2] = invSamples * ps.acc2;
     }
     if (COUNT && args.counters && inBlock) {
         atomicAdd((unsigned long long*)&args.counters->samples, (unsigned long long)samples);
