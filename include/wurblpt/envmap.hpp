@@ -43,7 +43,33 @@ public:
         out.compat = _compatibility == CompatibilityMitsuba ? WPT_ENV_COMPAT_MITSUBA : WPT_ENV_COMPAT_SURROUND_VIDEO;
         out.tex = ctx.indexOf(_tex);
         out.N = N;
+        for (int k = 0; k < 6; k++)
+            out.cube_tex[k] = -1;
         return out.tex >= 0;
+    }
+};
+
+/* envmap.hpp:250-285: six textures, +x -x +y -y +z -z */
+class EnvironmentMapCube final : public EnvironmentMap
+{
+private:
+    const Texture* _cubesides[6];
+
+public:
+    EnvironmentMapCube(const Texture* posx, const Texture* negx, const Texture* posy, const Texture* negy,
+            const Texture* posz, const Texture* negz) : _cubesides { posx, negx, posy, negy, posz, negz } {}
+    virtual bool describe(wpt_envmap& out, FlattenContext& ctx) const override
+    {
+        memset(&out, 0, sizeof(out));
+        out.type = WPT_ENV_CUBE;
+        out.tex = -1;
+        out.N = N;
+        for (int k = 0; k < 6; k++) {
+            out.cube_tex[k] = ctx.indexOf(_cubesides[k]);
+            if (out.cube_tex[k] < 0)
+                return false;
+        }
+        return true;
     }
 };
 

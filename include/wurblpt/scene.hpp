@@ -3,8 +3,9 @@
  * (scene.hpp:52-191), plus the flattener that turns it into the POD buffers of
  * include/wurblpt_hip.h.
  *
- * Hitable order = order of take() calls, triangles of an instance in index order; this is
- * the order the BVH builder sees (scene.hpp:151-162), so it is part of the results contract.
+ * Hitable order = order of take() calls, triangles of an instance in index order, a sphere
+ * where it was taken; this is the order the BVH builder sees (scene.hpp:151-162), so it is part
+ * of the results contract.
  */
 #pragma once
 
@@ -27,9 +28,27 @@ namespace WurblPT {
 
 typedef enum { ColdSpot, HotSpot } HotSpotType;
 
-/* Opaque handle for one hitable of the scene (the reference hands out `const Hitable*`). */
+/* Opaque handle for one hitable of the scene (the reference hands out `const Hitable*`):
+ * its position in the scene's hitable list. */
 struct Hitable {
     unsigned int index;
+};
+
+/* sphere.hpp:35-58: a sphere as a scene component; centre, radius and texture rotation come from
+ * the transformation as in HitableSphere's constructor (hitable_sphere.hpp:71-75) */
+class Sphere : public SceneComponent
+{
+public:
+    const Material* material;
+    const Transformation transformation;
+    const int animationIndex;
+
+    Sphere(const Material* m, const Transformation& T) : material(m), transformation(T), animationIndex(-1) {}
+    Sphere(const Material* m, int ai = -1) : material(m), transformation(), animationIndex(ai) {}
+    Sphere(const vec3& center, float radius, const Material* m) : Sphere(m, Transformation(center, quat::null(), vec3(radius))) {}
+
+    vec3 center() const { return transformation.translation; }
+    float radius() const { return max(transformation.scaling); }
 };
 
 /* The flattened scene: owns the arrays that a wpt_scene_desc points into. */
@@ -44,6 +63,7 @@ public:
     std::vector<wpt_texture> textures;
     std::vector<unsigned char> texels;
     std::vector<wpt_hotspot> hotspots;
+    std::vector<wpt_sphere> spheres;
     wpt_envmap envmap;
     size_t bvhLevels = 0;
 
@@ -58,6 +78,7 @@ public:
         d.material_count = materials.size();
         d.texture_count = textures.size();
         d.hotspot_count = hotspots.size();
+        d.sphere_count = spheres.size();
         d.texel_bytes = texels.size();
         d.nodes = nodes.data();
         d.tri_geom = triGeom.data();
@@ -68,6 +89,7 @@ public:
         d.texels = texels.data();
         d.hotspots = hotspots.data();
         d.envmap = envmap;
+        d.spheres = spheres.data();
         return d;
     }
 };
@@ -83,7 +105,13 @@ private:
     std::vector<std::unique_ptr<Mesh>> _meshes;
     std::vector<std::unique_ptr<SceneComponent>> _components;
     std::vector<const MeshInstance*> _instances;
-    std::vector<Triangle> _triangles;             /* the hitables, in take() order */
+    std::vector<Triangle> _triangles;             /* the triangle hitables, in take() order */
+    std::vector<const Sphere*> _spheres;          /* the sphere hitables, in take() order */
+    struct HitableRef {
+        unsigned int kind;  /* WPT_NODE_TRIANGLE or WPT_NODE_SPHERE */
+        unsigned int index; /* into _triangles or _spheres */
+    };
+    std::vector<HitableRef> _hitables;            /* all hitables, in take() order */
     std::vector<std::unique_ptr<Hitable>> _handles;
     std::vector<const Hitable*> _hotSpots;
     std::unique_ptr<EnvironmentMap> _envmap;
@@ -139,15 +167,34 @@ public:
         _instances.push_back(instance);
         size_t n = instance->mesh->triangleCount();
         _triangles.reserve(_triangles.size() + n);
+        _hitables.reserve(_hitables.size() + n);
         for (size_t i = 0; i < n; i++) {
-            Hitable* h = new Hitable { (unsigned int)(_triangles.size()) };
+            Hitable* h = new Hitable { (unsigned int)(_hitables.size()) };
             _handles.push_back(std::unique_ptr<Hitable>(h));
+            _hitables.push_back(HitableRef { WPT_NODE_TRIANGLE, (unsigned int)(_triangles.size()) });
             _triangles.push_back(Triangle { instance, instanceIndex, (unsigned int)(i) });
             handles.push_back(h);
         }
         if (hotSpotType == HotSpot)
             _hotSpots.insert(_hotSpots.end(), handles.begin(), handles.end());
         _components.push_back(std::unique_ptr<SceneComponent>(instance));
+        _bvhNeedsRebuild = true;
+        return handles;
+    }
+
+    /* scene.hpp:127-149 for a component that creates one HitableSphere (sphere.hpp:60-63) */
+    std::vector<const Hitable*> take(Sphere* sphere, HotSpotType hotSpotType = ColdSpot)
+    {
+        if (sphere->animationIndex >= 0)
+            _error = "animated spheres are outside the device path";
+        Hitable* h = new Hitable { (unsigned int)(_hitables.size()) };
+        _handles.push_back(std::unique_ptr<Hitable>(h));
+        _hitables.push_back(HitableRef { WPT_NODE_SPHERE, (unsigned int)(_spheres.size()) });
+        _spheres.push_back(sphere);
+        std::vector<const Hitable*> handles(1, h);
+        if (hotSpotType == HotSpot)
+            _hotSpots.push_back(h);
+        _components.push_back(std::unique_ptr<SceneComponent>(sphere));
         _bvhNeedsRebuild = true;
         return handles;
     }
@@ -166,15 +213,29 @@ public:
             fprintf(stderr, "Bounding volume hierarchy does not need updating.\n");
             return;
         }
-        fprintf(stderr, "Building bounding volume hierarchy for %zu hitables\n", _triangles.size());
-        std::vector<AABB> boxes(_triangles.size());
-        for (size_t i = 0; i < _triangles.size(); i++) {
-            vec3 v[3];
-            corners(_triangles[i], v);
-            boxes[i] = AABB(min(v[0], v[1], v[2]), max(v[0], v[1], v[2]));
+        fprintf(stderr, "Building bounding volume hierarchy for %zu hitables\n", _hitables.size());
+        std::vector<AABB> boxes(_hitables.size());
+        for (size_t i = 0; i < _hitables.size(); i++) {
+            if (_hitables[i].kind == WPT_NODE_TRIANGLE) {
+                vec3 v[3];
+                corners(_triangles[_hitables[i].index], v);
+                boxes[i] = AABB(min(v[0], v[1], v[2]), max(v[0], v[1], v[2]));
+            } else {
+                /* HitableSphere::aabb (hitable_sphere.hpp:88-91) */
+                const Sphere* sp = _spheres[_hitables[i].index];
+                boxes[i] = AABB(sp->center() - vec3(sp->radius()), sp->center() + vec3(sp->radius()));
+            }
         }
         BVHBuilder builder(boxes);
         _bvh = builder.build(&_bvhLevels);
+        /* the builder's leaves refer to the hitable list: make them refer to their own array */
+        for (wpt_bvh_node& nd : _bvh) {
+            if (nd.kind == WPT_NODE_TRIANGLE) {
+                const HitableRef& r = _hitables[nd.link];
+                nd.kind = r.kind;
+                nd.link = r.index;
+            }
+        }
         fprintf(stderr, "Linearized bounding volume hierarchy with %zu nodes on %zu levels\n", _bvh.size(), _bvhLevels);
         _bvhNeedsRebuild = false;
     }
@@ -182,7 +243,7 @@ public:
     const std::vector<const Hitable*>& hotSpots() const { return _hotSpots; }
     const EnvironmentMap* environmentMap() const { return _envmap.get(); }
     const std::vector<wpt_bvh_node>& bvhNodes() const { return _bvh; }
-    size_t hitableCount() const { return _triangles.size(); }
+    size_t hitableCount() const { return _hitables.size(); }
 
     int materialIndex(const Material* mat) const
     {
@@ -256,13 +317,36 @@ public:
                         tan[c][k] = src[Mesh::tangentOffset + k];
             }
         }
+        out.spheres.resize(_spheres.size());
+        for (size_t i = 0; i < _spheres.size(); i++) {
+            const Sphere* sp = _spheres[i];
+            wpt_sphere& r = out.spheres[i];
+            memset(&r, 0, sizeof(r));
+            for (int k = 0; k < 3; k++)
+                r.center[k] = sp->center()[k];
+            r.radius = sp->radius();
+            r.rotation[0] = sp->transformation.rotation.x;
+            r.rotation[1] = sp->transformation.rotation.y;
+            r.rotation[2] = sp->transformation.rotation.z;
+            r.rotation[3] = sp->transformation.rotation.w;
+            int m = ctx.indexOf(sp->material);
+            if (m < 0)
+                return fail(ctx.error);
+            r.material = m;
+        }
         out.hotspots.resize(_hotSpots.size());
         for (size_t i = 0; i < _hotSpots.size(); i++) {
-            const Triangle& t = _triangles[_hotSpots[i]->index];
-            const Mesh* mesh = t.instance->mesh;
+            const HitableRef& ref = _hitables[_hotSpots[i]->index];
             wpt_hotspot& h = out.hotspots[i];
             memset(&h, 0, sizeof(h));
-            h.prim = _hotSpots[i]->index;
+            h.prim = ref.index;
+            if (ref.kind == WPT_NODE_SPHERE) {
+                h.kind = WPT_HOTSPOT_SPHERE;
+                continue;
+            }
+            h.kind = WPT_HOTSPOT_TRIANGLE;
+            const Triangle& t = _triangles[ref.index];
+            const Mesh* mesh = t.instance->mesh;
             h.transform = t.instance->transformation.isIdentity() ? 0 : 1;
             float* p[3] = { h.p0, h.p1, h.p2 };
             for (int c = 0; c < 3; c++) {

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define WPT_ABI_VERSION 1u
+#define WPT_ABI_VERSION 2u
 
 typedef enum {
     WPT_OK = 0,
@@ -52,8 +52,8 @@ typedef enum {
 
 /* One node of the depth-first linearized BVH; 32 bytes like BVHNodeLinear
  * (bvh.hpp:217-225).  Child 1 of an inner node is the next node in the array
- * (bvh.hpp:301), child 2 is `link`.  For a leaf, `link` is the primitive index. */
-enum { WPT_NODE_INNER = 0, WPT_NODE_TRIANGLE = 1, WPT_NODE_EMPTY = 3 };
+ * (bvh.hpp:301), child 2 is `link`.  For a leaf, `link` is the index of the triangle or sphere. */
+enum { WPT_NODE_INNER = 0, WPT_NODE_TRIANGLE = 1, WPT_NODE_SPHERE = 2, WPT_NODE_EMPTY = 3 };
 typedef struct wpt_bvh_node {
     float lo[3];
     float hi[3];
@@ -92,12 +92,26 @@ typedef struct wpt_instance {
     uint32_t reserved;
 } wpt_instance;
 
-/* A hot spot (scene.hpp:113-125): the triangle, plus what HitableTriangle::direction()
- * needs (hitable_triangle.hpp:425-443): untransformed positions and the instance mat4. */
+/* A sphere (HitableSphere, hitable_sphere.hpp:32-76): centre = T.translation, radius =
+ * max(T.scaling), rotation = T.rotation (turns the normal into texture space). 48 bytes. */
+typedef struct wpt_sphere {
+    float center[3];
+    float radius;
+    float rotation[4]; /* quaternion x, y, z, w */
+    uint32_t material;
+    uint32_t reserved[3];
+} wpt_sphere;
+
+/* A hot spot (scene.hpp:113-125).  WPT_HOTSPOT_TRIANGLE: `prim` is the triangle, plus what
+ * HitableTriangle::direction() needs (hitable_triangle.hpp:425-443): untransformed positions
+ * and the instance mat4.  WPT_HOTSPOT_SPHERE: `prim` is the sphere; nothing else is used
+ * (HitableSphere::pdfValue/direction, hitable_sphere.hpp:149-220, read the sphere record). */
+enum { WPT_HOTSPOT_TRIANGLE = 0, WPT_HOTSPOT_SPHERE = 1 };
 typedef struct wpt_hotspot {
     uint32_t prim;
     uint32_t transform;
-    uint32_t reserved[2];
+    uint32_t kind;
+    uint32_t reserved;
     float p0[3], p1[3], p2[3];
     float M[16];
 } wpt_hotspot;
@@ -162,10 +176,11 @@ typedef struct wpt_texture {
     float b[4];
 } wpt_texture;
 
-enum { WPT_ENV_NONE = 0, WPT_ENV_EQUIRECT = 1 };
+enum { WPT_ENV_NONE = 0, WPT_ENV_EQUIRECT = 1, WPT_ENV_CUBE = 2 };
 enum { WPT_ENV_COMPAT_MITSUBA = 0, WPT_ENV_COMPAT_SURROUND_VIDEO = 1 };
-/* Environment map (envmap.hpp): texture + host-built importance tables (envmap.hpp:121-158).
- * N == 0 means no importance sampling support. */
+/* Environment map (envmap.hpp): texture(s) + host-built importance tables (envmap.hpp:121-158).
+ * N == 0 means no importance sampling support.  EQUIRECT uses `tex` (envmap.hpp:213-247),
+ * CUBE uses `cube_tex` in the order +x -x +y -y +z -z (envmap.hpp:250-285). */
 typedef struct wpt_envmap {
     uint32_t type;
     uint32_t compat;
@@ -174,6 +189,7 @@ typedef struct wpt_envmap {
     const float* M;
     const int32_t* Ms;
     const float* Mcs;
+    int32_t cube_tex[6];
 } wpt_envmap;
 
 typedef struct wpt_scene_desc {
@@ -184,7 +200,7 @@ typedef struct wpt_scene_desc {
     uint32_t material_count;
     uint32_t texture_count;
     uint32_t hotspot_count;
-    uint32_t reserved;
+    uint32_t sphere_count;
     uint64_t texel_bytes;
     const wpt_bvh_node* nodes;
     const wpt_tri_geom* tri_geom;
@@ -195,6 +211,7 @@ typedef struct wpt_scene_desc {
     const uint8_t* texels;
     const wpt_hotspot* hotspots;
     wpt_envmap envmap;
+    const wpt_sphere* spheres;
 } wpt_scene_desc;
 
 /* ---- camera, parameters ---------------------------------------------- */

@@ -33,6 +33,7 @@
 #include "optics.hpp"
 #include "camera.hpp"
 #include "geometryproc.hpp"
+#include "hitable_sphere.hpp"
 
 using namespace WurblPT;
 
@@ -544,6 +545,91 @@ int main(int argc, char* argv[])
         floats("geom_tangents", ftng);
         floats("geom_normals_weighted", fn0);
         floats("geom_normals_average", fn1);
+    }
+
+    /* ---- HitableSphere (hitable_sphere.hpp:32-220) and the samplers it uses ---- */
+    {
+        std::mt19937 srng(4242);
+        auto su01 = [&srng]() { return float(srng() >> 8) * (1.0f / 16777216.0f); };
+        auto sdir = [&]() {
+            for (;;) {
+                vec3 d(su01() * 2.0f - 1.0f, su01() * 2.0f - 1.0f, su01() * 2.0f - 1.0f);
+                float l = dot(d, d);
+                if (l > 1e-4f && l <= 1.0f)
+                    return normalize(d);
+            }
+        };
+        std::vector<const Animation*> noAnimations;
+        AnimationCache cache(noAnimations, 0.0f);
+        std::vector<float> spheres, rays, hits, pdfs, dirs, onSphereU, onSphereOut, toSphereIn, toSphereOut;
+        std::vector<long long> seeds;
+        const int n = 2048;
+        for (int i = 0; i < n; i++) {
+            vec3 center(su01() * 4.0f - 2.0f, su01() * 4.0f - 2.0f, su01() * 4.0f - 2.0f);
+            float radius = 0.05f + 1.5f * su01();
+            quat rot = (i % 3 == 0) ? quat::null() : toQuat(radians(360.0f * su01()), sdir());
+            /* non-uniform scaling on purpose: the radius is max(scaling) */
+            vec3 scaling = (i % 5 == 0) ? vec3(radius * 0.5f, radius, radius * 0.25f) : vec3(radius);
+            HitableSphere sphere(Transformation(center, rot, scaling), nullptr);
+            /* origins: far away, close to the surface, inside, exactly on the centre */
+            vec3 origin;
+            switch (i % 8) {
+            case 0: origin = center; break;
+            case 1: origin = center + (radius * 0.5f) * sdir(); break;
+            case 2: origin = center + (radius * (1.0f + 1e-4f)) * sdir(); break;
+            case 3: origin = center + (radius * (1.0f - 1e-4f)) * sdir(); break;
+            default: origin = center + (radius * (1.5f + 6.0f * su01())) * sdir(); break;
+            }
+            /* directions: towards the sphere (with jitter that also produces grazing rays and misses) or random */
+            vec3 direction = (i % 4 == 3) ? sdir() : normalize(center + (radius * 1.05f * su01()) * sdir() - origin + vec3(1e-6f));
+            float amin = (i % 7 == 0) ? 0.0f : 1e-5f;
+            float amax = (i % 11 == 0) ? 3.0f : maxval;
+            Ray ray(origin, direction, 0.0f, 1.0f);
+            Prng unused(0);
+            HitRecord hr = sphere.hit(ray, RayIntersectionHelper(ray), amin, amax, 0.0f, cache, unused);
+            push3(spheres, center);
+            spheres.push_back(radius);
+            spheres.push_back(rot.x); spheres.push_back(rot.y); spheres.push_back(rot.z); spheres.push_back(rot.w);
+            spheres.push_back(scaling.x()); spheres.push_back(scaling.y()); spheres.push_back(scaling.z());
+            push3(rays, origin);
+            push3(rays, direction);
+            rays.push_back(amin);
+            rays.push_back(amax);
+            hits.push_back(hr.haveHit ? 1.0f : 0.0f);
+            hits.push_back(hr.haveHit ? hr.a : 0.0f);
+            push3(hits, hr.haveHit ? hr.position : vec3(0.0f));
+            push3(hits, hr.haveHit ? hr.normal : vec3(0.0f));
+            push3(hits, hr.haveHit ? hr.tangent : vec3(0.0f));
+            hits.push_back(hr.haveHit ? hr.texcoords.x() : 0.0f);
+            hits.push_back(hr.haveHit ? hr.texcoords.y() : 0.0f);
+            hits.push_back(hr.haveHit && hr.backside ? 1.0f : 0.0f);
+            pdfs.push_back(sphere.pdfValue(origin, direction, cache, unused));
+            Prng prng(1000 + i);
+            seeds.push_back(1000 + i);
+            push3(dirs, sphere.direction(origin, cache, prng));
+        }
+        floats("sphere_records", spheres); /* centre(3) radius rotation(xyzw) scaling(3) */
+        floats("sphere_rays", rays);       /* origin(3) direction(3) amin amax */
+        floats("sphere_hits", hits);       /* haveHit a position(3) normal(3) tangent(3) texcoords(2) backside */
+        floats("sphere_pdf", pdfs);
+        ints("sphere_direction_seeds", seeds);
+        floats("sphere_direction", dirs);
+        for (int j = 0; j < 16; j++)
+            for (int i = 0; i < 16; i++) {
+                vec2 u((i + 0.37f) / 16.0f, (j + 0.61f) / 16.0f);
+                onSphereU.push_back(u.x());
+                onSphereU.push_back(u.y());
+                push3(onSphereOut, Sampler::onUnitSphere(u));
+                vec3 d = sdir();
+                float cosThetaMax = su01();
+                push3(toSphereIn, d);
+                toSphereIn.push_back(cosThetaMax);
+                push3(toSphereOut, Sampler::toSphere(d, cosThetaMax, u));
+            }
+        floats("sampler_sphere_u", onSphereU);
+        floats("sampler_on_unit_sphere", onSphereOut);
+        floats("sampler_to_sphere_in", toSphereIn); /* direction(3) cosThetaMax */
+        floats("sampler_to_sphere", toSphereOut);
     }
 
     fprintf(out, "\n}\n");

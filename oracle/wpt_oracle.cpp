@@ -301,6 +301,24 @@ struct TangentSpace {
     }
 };
 
+/* sampler.hpp:69-77 */
+inline V3 onUnitSphere(V2 u)
+{
+    float z = 1.0f - 2.0f * u.x;
+    float r = std::sqrt(fmax_(0.0f, 1.0f - z * z));
+    float phi = 2.0f * k_pi * u.y;
+    return V3 { r * m_cos(phi), r * m_sin(phi), z };
+}
+/* sampler.hpp:112-120 */
+inline V3 toSphere(V3 direction, float cosThetaMax, V2 u)
+{
+    float cosTheta = (1.0f - u.x) + u.x * cosThetaMax;
+    float sinTheta = std::sqrt(fmax_(0.0f, 1.0f - cosTheta * cosTheta));
+    float phi = u.y * 2.0f * k_pi;
+    V3 vectorAroundZ = V3 { m_cos(phi) * sinTheta, m_sin(phi) * sinTheta, cosTheta };
+    return normalize(TangentSpace(direction).toWorldSpace(vectorAroundZ));
+}
+
 /* ---- fresnel.hpp:48-72 ---- */
 inline V4 fresnelSchlick(V4 r0, float cosTheta)
 {
@@ -504,8 +522,136 @@ inline V3 triangleDirection(const Ctx& c, uint32_t hotspot, V3 origin, Prng& prn
     return normalize(p - origin);
 }
 
+/* ---- hitable_sphere.hpp ----
+ * A sphere's HitRecord carries prim = PRIM_SPHERE | index (stands for the Hitable pointer). */
+constexpr uint32_t PRIM_SPHERE = 0x80000000u;
+constexpr float k_cosOrthoAngleTolerance = 0.0003f; /* constants.hpp:41 */
+
+/* hitable_sphere.hpp:42-75 */
+inline HitRecord sphereHitRecord(const Ray& ray, float a, V3 center, const float* rotation, uint32_t prim)
+{
+    HitRecord hr;
+    V3 p = ray.at(a);
+    V3 n = normalize(p - center);
+    V3 rn = quat_rotate(rotation, n);
+    float alpha = m_atan2(rn.x, rn.z);
+    float beta = m_asin(clamp_(rn.y, -1.0f, +1.0f));
+    float u = 0.5f * k_inv_pi * (alpha + k_pi);
+    float v = k_inv_pi * (beta + 0.5f * k_pi);
+    V3 t = V3 { m_cos(alpha), 0.0f, -m_sin(alpha) };
+    if (std::fabs(dot(rn, t)) >= k_cosOrthoAngleTolerance)
+        t = v3(0.0f);
+    bool backside = false;
+    if (dot(n, -ray.direction) < 0.0f) {
+        backside = true;
+        n = -n;
+    }
+    hr.haveHit = true;
+    hr.a = a;
+    hr.position = p;
+    hr.normal = n;
+    hr.tangent = t;
+    hr.texcoords = V2 { u, v };
+    hr.backside = backside;
+    hr.prim = prim;
+    return hr;
+}
+
+/* hitable_sphere.hpp:104-147 (static scene: no animation) */
+inline HitRecord sphereHit(const wpt_sphere& sp, uint32_t index, const Ray& ray, float amin, float amax)
+{
+    V3 center = v3(sp.center);
+    float radius = sp.radius;
+    V3 oc = ray.origin - center;
+    float aq = -dot(oc, ray.direction);
+    V3 tmp = oc - dot(oc, ray.direction) * ray.direction;
+    float discriminant = radius * radius - dot(tmp, tmp);
+    HitRecord hr;
+    if (discriminant > 0.0f) {
+        float a1, a2;
+        if (aq < 0.0f) {
+            a2 = aq - std::sqrt(discriminant);
+            a1 = 2.0f * aq - a2;
+        } else {
+            a1 = aq + std::sqrt(discriminant);
+            a2 = 2.0f * aq - a1;
+        }
+        if (a2 > amin && a2 < amax)
+            hr = sphereHitRecord(ray, a2, center, sp.rotation, PRIM_SPHERE | index);
+        else if (a1 > amin && a1 < amax)
+            hr = sphereHitRecord(ray, a1, center, sp.rotation, PRIM_SPHERE | index);
+    }
+    return hr;
+}
+
+/* hitable_sphere.hpp:149-186 */
+inline float spherePdfValue(Ctx& c, uint32_t index, V3 origin, V3 direction)
+{
+    c.cnt.pdf_tests++;
+    const wpt_sphere& sp = c.sc->spheres[index];
+    V3 center = v3(sp.center);
+    float radius = sp.radius;
+    float value = 0.0f;
+    V3 cmo = center - origin;
+    float distanceSquared = dot(cmo, cmo);
+    float radiusSquared = radius * radius;
+    if (distanceSquared <= radiusSquared) {
+        value = 0.25f * k_inv_pi;
+    } else {
+        HitRecord hr = sphereHit(sp, index, Ray { origin, direction, 0.0f, v4(0.0f) }, 0.0f, k_maxval);
+        if (hr.haveHit) {
+            float discriminant = 1.0f - radiusSquared / distanceSquared;
+            float cosThetaMax = (discriminant > 0.0f ? std::sqrt(discriminant) : 0.0f);
+            float solidAngle = 2.0f * k_pi * (1.0f - cosThetaMax);
+            value = 1.0f / solidAngle;
+        }
+    }
+    return value;
+}
+
+/* hitable_sphere.hpp:188-219 */
+inline V3 sphereDirection(const Ctx& c, uint32_t index, V3 origin, Prng& prng)
+{
+    const wpt_sphere& sp = c.sc->spheres[index];
+    V3 center = v3(sp.center);
+    float radius = sp.radius;
+    V3 dir;
+    V3 cmo = center - origin;
+    float distanceSquared = dot(cmo, cmo);
+    float radiusSquared = radius * radius;
+    if (distanceSquared <= radiusSquared) {
+        dir = onUnitSphere(prng.in01x2());
+    } else {
+        float discriminant = 1.0f - radiusSquared / distanceSquared;
+        float cosThetaMax = (discriminant > 0.0f ? std::sqrt(discriminant) : 0.0f);
+        dir = toSphere(normalize(cmo), cosThetaMax, prng.in01x2());
+    }
+    return dir;
+}
+
+/* the virtual Hitable::pdfValue / direction / identity of hot spot i, and Hitable::material() */
+inline float hotSpotPdfValue(Ctx& c, size_t i, V3 origin, V3 direction)
+{
+    const wpt_hotspot& h = c.sc->hotspots[i];
+    return h.kind == WPT_HOTSPOT_SPHERE ? spherePdfValue(c, h.prim, origin, direction) : trianglePdfValue(c, h.prim, origin, direction);
+}
+inline V3 hotSpotDirection(const Ctx& c, size_t i, V3 origin, Prng& prng)
+{
+    const wpt_hotspot& h = c.sc->hotspots[i];
+    return h.kind == WPT_HOTSPOT_SPHERE ? sphereDirection(c, h.prim, origin, prng) : triangleDirection(c, uint32_t(i), origin, prng);
+}
+inline uint32_t hotSpotPrim(const Ctx& c, size_t i)
+{
+    const wpt_hotspot& h = c.sc->hotspots[i];
+    return h.kind == WPT_HOTSPOT_SPHERE ? (PRIM_SPHERE | h.prim) : h.prim;
+}
+inline uint32_t materialOfPrim(const Ctx& c, uint32_t prim)
+{
+    return (prim & PRIM_SPHERE) ? c.sc->spheres[prim & ~PRIM_SPHERE].material : c.sc->tri_geom[prim].material;
+}
+
 /* ---- bvh.hpp:277-311 ---- */
-/* leafHit(prim, amin, amax) stands for the virtual `node.hitable->hit(...)` */
+/* leafHit(kind, index, amin, amax) stands for the virtual `node.hitable->hit(...)` */
 template<typename LeafHit>
 inline HitRecord bvhTraverse(const wpt_bvh_node* nodes, wpt_counters& cnt, const Ray& ray, const RayHelper& rh,
         float amin, float amax, LeafHit&& leafHit)
@@ -522,7 +668,7 @@ inline HitRecord bvhTraverse(const wpt_bvh_node* nodes, wpt_counters& cnt, const
             if (node.kind != WPT_NODE_INNER) {
                 if (node.kind != WPT_NODE_EMPTY) {
                     cnt.leaf_tests++;
-                    HitRecord cur = leafHit(node.link, amin, amax);
+                    HitRecord cur = leafHit(node.kind, node.link, amin, amax);
                     if (cur.haveHit) {
                         hr = cur;
                         amax = hr.a;
@@ -546,8 +692,10 @@ inline HitRecord bvhTraverse(const wpt_bvh_node* nodes, wpt_counters& cnt, const
 
 inline HitRecord bvhHit(Ctx& c, const Ray& ray, const RayHelper& rh, float amin, float amax)
 {
-    return bvhTraverse(c.sc->nodes, c.cnt, ray, rh, amin, amax, [&](uint32_t prim, float lo, float hi) {
-        return triangleHit(c, prim, ray, rh, lo, hi, true, nullptr, nullptr);
+    return bvhTraverse(c.sc->nodes, c.cnt, ray, rh, amin, amax, [&](uint32_t kind, uint32_t index, float lo, float hi) {
+        if (kind == WPT_NODE_SPHERE)
+            return sphereHit(c.sc->spheres[index], index, ray, lo, hi);
+        return triangleHit(c, index, ray, rh, lo, hi, true, nullptr, nullptr);
     });
 }
 
@@ -678,6 +826,28 @@ inline V3 envInvM(V2 uv)
 inline V4 envL(const Ctx& c, V3 direction)
 {
     const wpt_envmap& e = c.sc->envmap;
+    if (e.type == WPT_ENV_CUBE) {
+        /* EnvironmentMapCube::L (envmap.hpp:265-284) */
+        float ax = std::fabs(direction.x);
+        float ay = std::fabs(direction.y);
+        float az = std::fabs(direction.z);
+        int cubeside;
+        float u, v;
+        if (ax > ay && ax > az) {
+            u = 0.5f * (direction.z / -direction.x + 1.0f);
+            v = 0.5f * (direction.y / ax + 1.0f);
+            cubeside = 0 + (std::signbit(direction.x) ? 1 : 0);
+        } else if (ay > az) {
+            u = 0.5f * (direction.x / ay + 1.0f);
+            v = 0.5f * (direction.z / -direction.y + 1.0f);
+            cubeside = 2 + (std::signbit(direction.y) ? 1 : 0);
+        } else {
+            u = 0.5f * (direction.x / direction.z + 1.0f);
+            v = 0.5f * (direction.y / az + 1.0f);
+            cubeside = 4 + (std::signbit(direction.z) ? 1 : 0);
+        }
+        return textureValue(c, e.cube_tex[cubeside], V2 { u, v });
+    }
     float y = m_asin(clamp_(direction.y, -1.0f, 1.0f));
     float x = m_atan2(-direction.x, direction.z);
     if (e.compat == WPT_ENV_COMPAT_MITSUBA) {
@@ -1216,7 +1386,7 @@ void tracePath(Ctx& c, float* sampleAccumulator, const Ray& startRay, size_t hot
         if (!(pathComponent + 1 < params.max_path_components))
             break;
 
-        uint32_t mat = sc.tri_geom[hr.prim].material;
+        uint32_t mat = materialOfPrim(c, hr.prim);
         c.cnt.scatters++;
         ScatterRecord sr = materialScatter(c, mat, ray, hr, prng);
         radianceToAccumulate = attenuation * materialEmitted(c, mat, ray, hr);
@@ -1235,24 +1405,24 @@ void tracePath(Ctx& c, float* sampleAccumulator, const Ray& startRay, size_t hot
         if (sr.type == ScatterRandom && hotSpotsSize > 0) {
             float hotSpotsPdf = 0.0f;
             for (size_t i = 0; i < hotSpotsSize; i++)
-                hotSpotsPdf += trianglePdfValue(c, sc.hotspots[i].prim, hr.position, sr.direction);
+                hotSpotsPdf += hotSpotPdfValue(c, i, hr.position, sr.direction);
             hotSpotsPdf *= invHotSpotsSize;
             nextAttenuation = nextAttenuation * powerHeuristicWeight(sr.pdf, hotSpotsPdf);
             size_t hotSpotIndex = prng.in01() * hotSpotsSize;
             hotSpotIndex = hotSpotIndex < hotSpotsSize - 1 ? hotSpotIndex : hotSpotsSize - 1;
-            V3 directDir = triangleDirection(c, uint32_t(hotSpotIndex), hr.position, prng);
+            V3 directDir = hotSpotDirection(c, hotSpotIndex, hr.position, prng);
             float directPdf = 0.0f;
             for (size_t i = 0; i < hotSpotsSize; i++)
-                directPdf += trianglePdfValue(c, sc.hotspots[i].prim, hr.position, directDir);
+                directPdf += hotSpotPdfValue(c, i, hr.position, directDir);
             directPdf *= invHotSpotsSize;
             if (directPdf > 0.0f) {
                 ScatterRecord directSR = materialScatterToDirection(c, mat, ray, hr, directDir);
                 if (directSR.pdf > 0.0f) {
                     Ray directRay { hr.position, directDir, ray.time, directSR.refractiveIndex };
                     HitRecord directHR = bvhHit(c, directRay, RayHelper(directRay), params.min_hit_distance, k_maxval);
-                    if (directHR.haveHit && directHR.prim == sc.hotspots[hotSpotIndex].prim) {
+                    if (directHR.haveHit && directHR.prim == hotSpotPrim(c, hotSpotIndex)) {
                         float weight = powerHeuristicWeight(directPdf, directSR.pdf);
-                        uint32_t lmat = sc.tri_geom[directHR.prim].material;
+                        uint32_t lmat = materialOfPrim(c, directHR.prim);
                         radianceToAccumulate = attenuation * directSR.attenuation / directPdf * weight
                             * materialEmitted(c, lmat, directRay, directHR);
                         V4 opticalPathLengthToAccumulate = opticalPathLength + directHR.a * directRay.refractiveIndex;
@@ -1446,11 +1616,67 @@ void wpt_oracle_sampler(int which, int n, const float* u_xy, float* out)
             out[2 * i] = r.x;
             out[2 * i + 1] = r.y;
         } else {
-            V3 r = which == 1 ? inTriangle(u) : cosineDirection(u);
+            V3 r = which == 1 ? inTriangle(u) : which == 2 ? cosineDirection(u) : onUnitSphere(u);
             out[3 * i] = r.x;
             out[3 * i + 1] = r.y;
             out[3 * i + 2] = r.z;
         }
+    }
+}
+
+/* Sampler::toSphere: in4 = direction(3) cosThetaMax, u = 2 uniforms -> 3 floats */
+void wpt_oracle_to_sphere(int n, const float* in4, const float* u_xy, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        V3 r = toSphere(v3(in4 + 4 * i), in4[4 * i + 3], V2 { u_xy[2 * i], u_xy[2 * i + 1] });
+        out[3 * i] = r.x;
+        out[3 * i + 1] = r.y;
+        out[3 * i + 2] = r.z;
+    }
+}
+
+/* HitableSphere: records = centre(3) radius rotation(xyzw) scaling(3) (radius = max(scaling), as the
+ * constructor computes it); rays = origin(3) direction(3) amin amax.
+ * hits: haveHit a position(3) normal(3) tangent(3) texcoords(2) backside (14 floats);
+ * pdf: pdfValue(origin, direction); dirs: direction(origin) with Prng(seed). */
+void wpt_oracle_sphere(int n, const float* records, const float* rays, const int64_t* seeds, float* hits, float* pdf, float* dirs)
+{
+    for (int i = 0; i < n; i++) {
+        const float* rec = records + 11 * i;
+        wpt_sphere sp;
+        memset(&sp, 0, sizeof(sp));
+        for (int k = 0; k < 3; k++)
+            sp.center[k] = rec[k];
+        sp.radius = fmax_(fmax_(rec[8], rec[9]), rec[10]) == rec[3] ? rec[3] : fmax_(fmax_(rec[8], rec[9]), rec[10]);
+        for (int k = 0; k < 4; k++)
+            sp.rotation[k] = rec[4 + k];
+        wpt_scene_desc sc;
+        memset(&sc, 0, sizeof(sc));
+        sc.spheres = &sp;
+        sc.sphere_count = 1;
+        wpt_params pr;
+        memset(&pr, 0, sizeof(pr));
+        Ctx c;
+        c.sc = &sc;
+        c.pr = &pr;
+        memset(&c.cnt, 0, sizeof(c.cnt));
+        Ray r { v3(rays + 8 * i), v3(rays + 8 * i + 3), 0.0f, v4(1.0f) };
+        HitRecord hr = sphereHit(sp, 0, r, rays[8 * i + 6], rays[8 * i + 7]);
+        float* o = hits + 14 * i;
+        memset(o, 0, 14 * sizeof(float));
+        if (hr.haveHit) {
+            o[0] = 1.0f;
+            o[1] = hr.a;
+            o[2] = hr.position.x; o[3] = hr.position.y; o[4] = hr.position.z;
+            o[5] = hr.normal.x; o[6] = hr.normal.y; o[7] = hr.normal.z;
+            o[8] = hr.tangent.x; o[9] = hr.tangent.y; o[10] = hr.tangent.z;
+            o[11] = hr.texcoords.x; o[12] = hr.texcoords.y;
+            o[13] = hr.backside ? 1.0f : 0.0f;
+        }
+        pdf[i] = spherePdfValue(c, 0, r.origin, r.direction);
+        Prng prng(uint32_t(seeds[i]));
+        V3 d = sphereDirection(c, 0, r.origin, prng);
+        dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
     }
 }
 
@@ -1567,7 +1793,7 @@ void wpt_oracle_bvh_walk(const wpt_bvh_node* nodes, const float* ray8, const flo
     memset(&cnt, 0, sizeof(cnt));
     Ray r { v3(ray8), v3(ray8 + 3), 0.0f, v4(1.0f) };
     int64_t n = 0;
-    HitRecord hr = bvhTraverse(nodes, cnt, r, RayHelper(r), ray8[6], ray8[7], [&](uint32_t prim, float lo, float hi) {
+    HitRecord hr = bvhTraverse(nodes, cnt, r, RayHelper(r), ray8[6], ray8[7], [&](uint32_t, uint32_t prim, float lo, float hi) {
         if (n < max_log)
             log[n] = prim;
         n++;

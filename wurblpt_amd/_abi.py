@@ -5,10 +5,10 @@ against values compiled from the header.
 """
 import ctypes as C
 
-WPT_ABI_VERSION = 1
+WPT_ABI_VERSION = 2
 WPT_OK = 0
 
-NODE_INNER, NODE_TRIANGLE, NODE_EMPTY = 0, 1, 3
+NODE_INNER, NODE_TRIANGLE, NODE_SPHERE, NODE_EMPTY = 0, 1, 2, 3
 MAT_NONE, MAT_LAMBERTIAN, MAT_LIGHT_DIFFUSE, MAT_MIRROR, MAT_GGX, MAT_GLASS, MAT_MODPHONG, MAT_TWOSIDED = range(8)
 
 
@@ -31,8 +31,13 @@ class Instance(C.Structure):
     _fields_ = [("N", C.c_float * 9), ("material", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class Sphere(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("rotation", C.c_float * 4),
+                ("material", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
 class Hotspot(C.Structure):
-    _fields_ = [("prim", C.c_uint32), ("transform", C.c_uint32), ("reserved", C.c_uint32 * 2),
+    _fields_ = [("prim", C.c_uint32), ("transform", C.c_uint32), ("kind", C.c_uint32), ("reserved", C.c_uint32),
                 ("p0", C.c_float * 3), ("p1", C.c_float * 3), ("p2", C.c_float * 3), ("M", C.c_float * 16)]
 
 
@@ -50,17 +55,17 @@ class Texture(C.Structure):
 
 class Envmap(C.Structure):
     _fields_ = [("type", C.c_uint32), ("compat", C.c_uint32), ("tex", C.c_int32), ("N", C.c_int32),
-                ("M", C.c_void_p), ("Ms", C.c_void_p), ("Mcs", C.c_void_p)]
+                ("M", C.c_void_p), ("Ms", C.c_void_p), ("Mcs", C.c_void_p), ("cube_tex", C.c_int32 * 6)]
 
 
 class SceneDesc(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("node_count", C.c_uint32), ("tri_count", C.c_uint32),
                 ("instance_count", C.c_uint32), ("material_count", C.c_uint32), ("texture_count", C.c_uint32),
-                ("hotspot_count", C.c_uint32), ("reserved", C.c_uint32), ("texel_bytes", C.c_uint64),
+                ("hotspot_count", C.c_uint32), ("sphere_count", C.c_uint32), ("texel_bytes", C.c_uint64),
                 ("nodes", C.POINTER(BvhNode)), ("tri_geom", C.POINTER(TriGeom)), ("tri_attr", C.POINTER(TriAttr)),
                 ("instances", C.POINTER(Instance)), ("materials", C.POINTER(Material)),
                 ("textures", C.POINTER(Texture)), ("texels", C.c_void_p), ("hotspots", C.POINTER(Hotspot)),
-                ("envmap", Envmap)]
+                ("envmap", Envmap), ("spheres", C.POINTER(Sphere))]
 
 
 class Camera(C.Structure):
@@ -85,7 +90,7 @@ class Counters(C.Structure):
 
 STRUCT_SIZES = {
     "wpt_bvh_node": (BvhNode, 32), "wpt_tri_geom": (TriGeom, 48), "wpt_tri_attr": (TriAttr, 96),
-    "wpt_instance": (Instance, 48), "wpt_hotspot": (Hotspot, 116), "wpt_material": (Material, 128),
+    "wpt_instance": (Instance, 48), "wpt_sphere": (Sphere, 48), "wpt_hotspot": (Hotspot, 116), "wpt_material": (Material, 128),
     "wpt_texture": (Texture, 88), "wpt_camera": (Camera, 64), "wpt_params": (Params, 32),
     "wpt_counters": (Counters, 48),
 }

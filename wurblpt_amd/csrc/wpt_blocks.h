@@ -90,15 +90,52 @@ WPT_D float hotSpotPdfValue(float4 g0, float4 g1, float4 g2, f3 org, f3 dir, con
     return value;
 }
 
+/* HitableSphere::pdfValue (hitable_sphere.hpp:149-186) */
+WPT_D float spherePdfValue(const wpt_sphere& sp, f3 org, f3 dir)
+{
+    const f3 cmo = sub(ld3(sp.center), org);
+    const float distanceSquared = dot(cmo, cmo);
+    const float radiusSquared = sp.radius * sp.radius;
+    float value = 0.0f;
+    if (distanceSquared <= radiusSquared) {
+        value = 0.25f * k_inv_pi; /* inside: any direction hits */
+    } else {
+        float a;
+        if (sphereTest(sp, org, dir, 0.0f, k_maxval, a)) {
+            const float discriminant = 1.0f - radiusSquared / distanceSquared;
+            const float cosThetaMax = discriminant > 0.0f ? __builtin_sqrtf(discriminant) : 0.0f;
+            const float solidAngle = 2.0f * k_pi * (1.0f - cosThetaMax);
+            value = 1.0f / solidAngle;
+        }
+    }
+    return value;
+}
+
+/* HitableSphere::direction (hitable_sphere.hpp:188-219) */
+WPT_D f3 sphereDirection(const wpt_sphere& sp, f3 org, Prng& prng)
+{
+    const f3 cmo = sub(ld3(sp.center), org);
+    const float distanceSquared = dot(cmo, cmo);
+    const float radiusSquared = sp.radius * sp.radius;
+    if (distanceSquared <= radiusSquared)
+        return onUnitSphere(in01x2(prng));
+    const float discriminant = 1.0f - radiusSquared / distanceSquared;
+    const float cosThetaMax = discriminant > 0.0f ? __builtin_sqrtf(discriminant) : 0.0f;
+    return toSphere(normalize(cmo), cosThetaMax, in01x2(prng));
+}
+
 /* mean pdf over all hot spots of hitting them from org along dir (wurblpt.hpp:181-184) */
-template<bool COUNT, class Tri4>
+template<uint32_t F, bool COUNT, class Tri4>
 WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, LaneCounters& lc)
 {
     const RayAux h = rayAux(dir);
     float sum = 0.0f;
     for (uint32_t i = 0; i < sv.hotspotCount; i++) {
         const uint32_t p = sv.hotspots[i].prim;
-        sum += hotSpotPdfValue(tri4(3 * p), tri4(3 * p + 1), tri4(3 * p + 2), org, dir, h);
+        if ((F & FEAT_SPHERES) && sv.hotspots[i].kind == WPT_HOTSPOT_SPHERE)
+            sum += spherePdfValue(sv.spheres[p], org, dir);
+        else
+            sum += hotSpotPdfValue(tri4(3 * p), tri4(3 * p + 1), tri4(3 * p + 2), org, dir, h);
         if (COUNT)
             lc.pdfs++;
     }
@@ -195,7 +232,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
     ps.opl = add(ps.opl, scl(best.a, mk3(ps.ray.ri.x, ps.ray.ri.y, ps.ray.ri.z)));
     if (!(ps.pathComponent + 1 < par.max_path_components))
         return NEXT_NEW;
-    Hit h = finishHit(sv, best, ps.ray.o, ps.ray.d);
+    Hit h = finishHit<F>(sv, best, ps.ray.o, ps.ray.d);
     const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
     if (COUNT)
         lc.scatters++;
@@ -216,25 +253,32 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
     ps.srDir = sr.dir;
     if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
         /* light sampling with MIS (wurblpt.hpp:179-220) */
-        const float hotSpotsPdf = hotSpotsMeanPdf<COUNT>(sv, tri4, h.p, sr.dir, lc);
+        const float hotSpotsPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, sr.dir, lc);
         ps.nextAtt = sclr(ps.nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
         uint32_t idx = (uint32_t)(in01(ps.prng) * (float)sv.hotspotCount);
         idx = idx < sv.hotspotCount - 1 ? idx : sv.hotspotCount - 1;
         const wpt_hotspot& hs = sv.hotspots[idx];
-        /* HitableTriangle::direction (hitable_triangle.hpp:425-443) */
-        const f3 bary = inTriangle(in01x2(ps.prng));
-        f3 p = add(add(scl(bary.x, ld3(hs.p0)), scl(bary.y, ld3(hs.p1))), scl(bary.z, ld3(hs.p2)));
-        if (hs.transform)
-            p = mat4mulPoint(hs.M, p);
-        const f3 directDir = normalize(sub(p, h.p));
-        const float directPdf = hotSpotsMeanPdf<COUNT>(sv, tri4, h.p, directDir, lc);
+        f3 directDir;
+        uint32_t hotSpotPrim = hs.prim;
+        if ((F & FEAT_SPHERES) && hs.kind == WPT_HOTSPOT_SPHERE) {
+            directDir = sphereDirection(sv.spheres[hs.prim], h.p, ps.prng);
+            hotSpotPrim = PRIM_SPHERE | hs.prim;
+        } else {
+            /* HitableTriangle::direction (hitable_triangle.hpp:425-443) */
+            const f3 bary = inTriangle(in01x2(ps.prng));
+            f3 p = add(add(scl(bary.x, ld3(hs.p0)), scl(bary.y, ld3(hs.p1))), scl(bary.z, ld3(hs.p2)));
+            if (hs.transform)
+                p = mat4mulPoint(hs.M, p);
+            directDir = normalize(sub(p, h.p));
+        }
+        const float directPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, directDir, lc);
         if (directPdf > 0.0f) {
             float dpdf;
             f4 directAtt;
             materialEval<F>(sv, m, ps.ray, h, directDir, directAtt, dpdf);
             if (dpdf > 0.0f) {
                 ps.neeFactor = sclr(divs(mul(ps.att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
-                ps.chosenPrim = hs.prim;
+                ps.chosenPrim = hotSpotPrim;
                 ps.ray.o = h.p;
                 ps.ray.d = directDir;
                 ps.rayKind = RAY_NEE_LIGHT;
@@ -274,7 +318,7 @@ WPT_D int blockNeeEnd(const SceneView& sv, const wpt_params& par, PathState& ps,
 {
     if (ps.rayKind == RAY_NEE_LIGHT) {
         if (best.prim == ps.chosenPrim) {
-            Hit lh = finishHit(sv, best, ps.ray.o, ps.ray.d);
+            Hit lh = finishHit<F>(sv, best, ps.ray.o, ps.ray.d);
             const wpt_material& lm = resolveMaterial<F>(sv, lh.material, lh);
             f4 rad = mul(ps.neeFactor, materialEmitted<F>(sv, lm, lh));
             f3 oplLight = add(ps.opl, scl(lh.a, mk3(ps.ray.ri.x, ps.ray.ri.y, ps.ray.ri.z)));

@@ -156,6 +156,8 @@ uint32_t sceneFeatures(const wpt_scene_desc* d)
     }
     if (d->envmap.type != WPT_ENV_NONE)
         f |= FEAT_ENVMAP | FEAT_TEXTURES;
+    if (d->sphere_count > 0)
+        f |= FEAT_SPHERES;
     return f;
 }
 
@@ -175,8 +177,11 @@ wpt_status validate(const wpt_scene_desc* d)
             if (n.link >= d->node_count || n.link <= i || i + 1 >= d->node_count)
                 return fail(WPT_ERR_INVALID_ARGUMENT, "BVH inner node links outside the node array");
         } else if (n.kind == WPT_NODE_TRIANGLE) {
-            if (n.link >= d->tri_count || n.link >= NODE_EMPTY)
+            if (n.link >= d->tri_count || n.link >= PRIM_SPHERE)
                 return fail(WPT_ERR_INVALID_ARGUMENT, "BVH leaf references a triangle outside the array");
+        } else if (n.kind == WPT_NODE_SPHERE) {
+            if (n.link >= d->sphere_count || (PRIM_SPHERE | n.link) >= NODE_EMPTY)
+                return fail(WPT_ERR_INVALID_ARGUMENT, "BVH leaf references a sphere outside the array");
         } else if (n.kind != WPT_NODE_EMPTY) {
             return fail(WPT_ERR_UNSUPPORTED, "BVH node kind is not known to the kernel");
         }
@@ -213,13 +218,29 @@ wpt_status validate(const wpt_scene_desc* d)
                 return fail(WPT_ERR_INVALID_ARGUMENT, "image texture lies outside the texel pool");
         }
     }
-    for (uint32_t i = 0; i < d->hotspot_count; i++)
-        if (d->hotspots[i].prim >= d->tri_count)
-            return fail(WPT_ERR_INVALID_ARGUMENT, "hot spot references a triangle outside the array");
-    if (d->envmap.type > WPT_ENV_EQUIRECT)
+    if (d->sphere_count > 0 && !d->spheres)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "sphere array is NULL");
+    for (uint32_t i = 0; i < d->sphere_count; i++)
+        if (d->spheres[i].material >= d->material_count)
+            return fail(WPT_ERR_INVALID_ARGUMENT, "sphere references a material outside the array");
+    for (uint32_t i = 0; i < d->hotspot_count; i++) {
+        const wpt_hotspot& h = d->hotspots[i];
+        if (h.kind > WPT_HOTSPOT_SPHERE)
+            return fail(WPT_ERR_UNSUPPORTED, "hot spot kind is not known to the kernel");
+        if (h.prim >= (h.kind == WPT_HOTSPOT_SPHERE ? d->sphere_count : d->tri_count))
+            return fail(WPT_ERR_INVALID_ARGUMENT, "hot spot references a primitive outside the array");
+    }
+    if (d->envmap.type > WPT_ENV_CUBE)
         return fail(WPT_ERR_UNSUPPORTED, "environment map type is not known to the kernel");
-    if (d->envmap.type != WPT_ENV_NONE && (d->envmap.tex < 0 || uint32_t(d->envmap.tex) >= d->texture_count))
+    if (d->envmap.type == WPT_ENV_EQUIRECT && (d->envmap.tex < 0 || uint32_t(d->envmap.tex) >= d->texture_count))
         return fail(WPT_ERR_INVALID_ARGUMENT, "environment map references a texture outside the array");
+    if (d->envmap.type == WPT_ENV_CUBE) {
+        for (int k = 0; k < 6; k++)
+            if (d->envmap.cube_tex[k] < 0 || uint32_t(d->envmap.cube_tex[k]) >= d->texture_count)
+                return fail(WPT_ERR_INVALID_ARGUMENT, "environment cube map references a texture outside the array");
+        if (d->envmap.N > 0)
+            return fail(WPT_ERR_UNSUPPORTED, "importance sampling of a cube environment map is not built");
+    }
     return WPT_OK;
 }
 
@@ -302,7 +323,8 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
                     continue;
                 }
                 const uint32_t pos = cursor++;
-                const uint32_t prim = nd.kind == WPT_NODE_INNER ? NODE_INNER : nd.kind == WPT_NODE_TRIANGLE ? nd.link : NODE_EMPTY;
+                const uint32_t prim = nd.kind == WPT_NODE_INNER ? NODE_INNER : nd.kind == WPT_NODE_TRIANGLE ? nd.link
+                    : nd.kind == WPT_NODE_SPHERE ? (PRIM_SPHERE | nd.link) : NODE_EMPTY;
                 float pr;
                 memcpy(&pr, &prim, 4);
                 out[2 * size_t(pos)] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0]);
@@ -378,6 +400,10 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
         }
     }
     UP(uploadArray(s, desc->hotspots, desc->hotspot_count, &s->view.hotspots));
+    UP(uploadArray(s, desc->spheres, desc->sphere_count, &s->view.spheres));
+    s->view.sphereCount = desc->sphere_count;
+    for (int k = 0; k < 6; k++)
+        s->view.envCube[k] = desc->envmap.cube_tex[k];
     {
         const uint32_t zeros[1 + 64] = { 0 };
         const uint32_t* statusWord = nullptr;
@@ -516,10 +542,12 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
      * (wpt_pathtrace_pc.inc.h), kept as a measured experiment: same results, slower.
      * Low nibble: 1 = keep the scene in HBM, 2 = all features. */
     const uint32_t force = g_variant & 0xfu;
-    const bool singleRole = (g_variant & 0x10u) == 0;
+    const bool singleRole = (g_variant & 0x10u) == 0 || (scene->features & FEAT_SPHERES) != 0;
     const bool basic = (need & ~FEAT_BASIC) == 0 && force != 2;
     const bool lds = smallScene && force != 1;
-    const bool ldsState = (g_variant & 0x40u) != 0;
+    /* the two experimental kernel families have no sphere leaf test: scenes with spheres run the product kernel */
+    const bool spheres = (scene->features & FEAT_SPHERES) != 0;
+    const bool ldsState = (g_variant & 0x40u) != 0 && !spheres;
     args.travWaves = 8;
     args.heavyWaves = 4;
     args.pixelCounter = nullptr;

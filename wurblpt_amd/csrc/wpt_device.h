@@ -218,6 +218,26 @@ WPT_D Frame frameFromNormal(f3 n) /* Duff et al., tangentspace.hpp:57-74 */
     f.b = mk3(b, sign + n.y * n.y * a, -n.y);
     return f;
 }
+WPT_D Frame frameFromNormal(f3 n);
+WPT_D f3 toWorld(const Frame& f, f3 v);
+/* Sampler::onUnitSphere (sampler.hpp:69-77) */
+WPT_D f3 onUnitSphere(f2 u)
+{
+    const float z = 1.0f - 2.0f * u.x;
+    const float r = __builtin_sqrtf(fmaxr(0.0f, 1.0f - z * z));
+    const float phi = 2.0f * k_pi * u.y;
+    return mk3(r * wptm::cosf_(phi), r * wptm::sinf_(phi), z);
+}
+/* Sampler::toSphere (sampler.hpp:112-120) */
+WPT_D f3 toSphere(f3 direction, float cosThetaMax, f2 u)
+{
+    const float cosTheta = (1.0f - u.x) + u.x * cosThetaMax;
+    const float sinTheta = __builtin_sqrtf(fmaxr(0.0f, 1.0f - cosTheta * cosTheta));
+    const float phi = u.y * 2.0f * k_pi;
+    const f3 vectorAroundZ = mk3(wptm::cosf_(phi) * sinTheta, wptm::sinf_(phi) * sinTheta, cosTheta);
+    return normalize(toWorld(frameFromNormal(direction), vectorAroundZ));
+}
+
 WPT_D Frame frameFromNT(f3 n, f3 t)
 {
     Frame f;
@@ -383,6 +403,22 @@ WPT_D bool boxTest(f3 lo, f3 hi, f3 org, f3 inv, float amin, float amax)
     return hit;
 }
 
+/* feature bits: what a kernel instantiation can evaluate */
+enum {
+    FEAT_TEXTURES = 1,   /* any texture, normal maps */
+    FEAT_MODPHONG = 2,   /* MaterialModPhong */
+    FEAT_ENVMAP = 4,     /* environment map radiance and importance sampling */
+    FEAT_LENS = 8,       /* thin lens camera */
+    FEAT_TWOSIDED = 16,  /* MaterialTwoSided */
+    FEAT_GGX = 32,       /* MaterialGGX */
+    FEAT_GLASS = 64,     /* MaterialGlass, MaterialMirror */
+    FEAT_SPHERES = 128   /* HitableSphere leaves and sphere hot spots */
+};
+
+/* a primitive index with this bit is a sphere (index in the low bits), otherwise a triangle */
+constexpr uint32_t PRIM_SPHERE = 0x80000000u;
+constexpr float k_cosOrthoAngleTolerance = 0.0003f; /* constants.hpp:41 */
+
 /* full HitRecord (hitable.hpp:39-64) */
 struct Hit {
     float a;
@@ -402,6 +438,7 @@ struct SceneView {
     const wpt_texture* textures;
     const float4* texels4; /* decoded RGBA texels of all image textures */
     const wpt_hotspot* hotspots;
+    const wpt_sphere* spheres;
     const float* envM;
     const int32_t* envMs;
     const float* envMcs;
@@ -409,11 +446,75 @@ struct SceneView {
     uint32_t hotspotCount;
     uint32_t envType, envCompat;
     int32_t envTex, envN;
+    int32_t envCube[6]; /* WPT_ENV_CUBE: textures +x -x +y -y +z -z */
+    uint32_t sphereCount;
 };
 
+/* HitableSphere::hit, candidate part (hitable_sphere.hpp:104-147): the nearer root inside
+ * (amin, amax), both bounds exclusive, computed without cancellation */
+WPT_D bool sphereTest(const wpt_sphere& sp, f3 org, f3 dir, float amin, float amax, float& a)
+{
+    const f3 oc = sub(org, ld3(sp.center));
+    const float ocd = dot(oc, dir);
+    const float aq = -ocd;
+    const f3 tmp = sub(oc, scl(ocd, dir));
+    const float discriminant = sp.radius * sp.radius - dot(tmp, tmp);
+    bool hit = false;
+    if (discriminant > 0.0f) {
+        float a1, a2;
+        const float root = __builtin_sqrtf(discriminant);
+        if (aq < 0.0f) {
+            a2 = aq - root;
+            a1 = 2.0f * aq - a2;
+        } else {
+            a1 = aq + root;
+            a2 = 2.0f * aq - a1;
+        }
+        if (a2 > amin && a2 < amax) {
+            a = a2;
+            hit = true;
+        } else if (a1 > amin && a1 < amax) {
+            a = a1;
+            hit = true;
+        }
+    }
+    return hit;
+}
+
+/* HitableSphere::constructHitRecord (hitable_sphere.hpp:42-75) */
+WPT_D Hit finishSphereHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir)
+{
+    const wpt_sphere& sp = sv.spheres[c.prim & ~PRIM_SPHERE];
+    Hit h;
+    h.a = c.a;
+    h.prim = c.prim;
+    h.material = sp.material;
+    h.p = add(org, scl(c.a, dir));
+    f3 n = normalize(sub(h.p, ld3(sp.center)));
+    const f3 rn = quatRotate(sp.rotation, n);
+    const float alpha = wptm::atan2f_(rn.x, rn.z);
+    const float beta = wptm::asinf_(clampr(rn.y, -1.0f, +1.0f));
+    h.tc.x = 0.5f * k_inv_pi * (alpha + k_pi);
+    h.tc.y = k_inv_pi * (beta + 0.5f * k_pi);
+    f3 t = mk3(wptm::cosf_(alpha), 0.0f, -wptm::sinf_(alpha));
+    if (__builtin_fabsf(dot(rn, t)) >= k_cosOrthoAngleTolerance)
+        t = mk3(0.0f, 0.0f, 0.0f); /* at the poles */
+    h.backside = false;
+    if (dot(n, neg(dir)) < 0.0f) {
+        h.backside = true;
+        n = neg(n);
+    }
+    h.n = n;
+    h.t = t;
+    return h;
+}
+
 /* Rebuilds the HitRecord of the surviving candidate (hitable_triangle.hpp:273-324). */
+template<uint32_t F = 0>
 WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir)
 {
+    if ((F & FEAT_SPHERES) && (c.prim & PRIM_SPHERE))
+        return finishSphereHit(sv, c, org, dir);
     Hit h;
     h.a = c.a;
     h.prim = c.prim;
@@ -615,8 +716,29 @@ WPT_D f3 envInvM(f2 uv)
     wptm::sincosf_(lon, &slon, &clon);
     return normalize(mk3(-clat * slon, slat, clat * clon));
 }
+WPT_D f4 textureValue(const SceneView& sv, int tex, f2 tc);
 WPT_D f4 envL(const SceneView& sv, f3 dir)
 {
+    if (sv.envType == WPT_ENV_CUBE) {
+        /* EnvironmentMapCube::L (envmap.hpp:265-284) */
+        const float ax = __builtin_fabsf(dir.x), ay = __builtin_fabsf(dir.y), az = __builtin_fabsf(dir.z);
+        int side;
+        f2 tc;
+        if (ax > ay && ax > az) {
+            tc.x = 0.5f * (dir.z / -dir.x + 1.0f);
+            tc.y = 0.5f * (dir.y / ax + 1.0f);
+            side = 0 + (__builtin_signbit(dir.x) ? 1 : 0);
+        } else if (ay > az) {
+            tc.x = 0.5f * (dir.x / ay + 1.0f);
+            tc.y = 0.5f * (dir.z / -dir.y + 1.0f);
+            side = 2 + (__builtin_signbit(dir.y) ? 1 : 0);
+        } else {
+            tc.x = 0.5f * (dir.x / dir.z + 1.0f);
+            tc.y = 0.5f * (dir.y / az + 1.0f);
+            side = 4 + (__builtin_signbit(dir.z) ? 1 : 0);
+        }
+        return textureValue(sv, sv.envCube[side], tc);
+    }
     float y = wptm::asinf_(clampr(dir.y, -1.0f, 1.0f));
     float x = wptm::atan2f_(-dir.x, dir.z);
     if (sv.envCompat == WPT_ENV_COMPAT_MITSUBA) {
@@ -697,17 +819,6 @@ WPT_D Scatter scatterMake(int type, f3 dir, f4 att, float pdf, f4 ri)
     s.ri = ri;
     return s;
 }
-
-/* feature bits: what a kernel instantiation can evaluate */
-enum {
-    FEAT_TEXTURES = 1,   /* any texture, normal maps */
-    FEAT_MODPHONG = 2,   /* MaterialModPhong */
-    FEAT_ENVMAP = 4,     /* environment map radiance and importance sampling */
-    FEAT_LENS = 8,       /* thin lens camera */
-    FEAT_TWOSIDED = 16,  /* MaterialTwoSided */
-    FEAT_GGX = 32,       /* MaterialGGX */
-    FEAT_GLASS = 64      /* MaterialGlass, MaterialMirror */
-};
 
 template<uint32_t F> WPT_D f4 texOrConst(const SceneView& sv, int tex, const float* c, f2 tc)
 {

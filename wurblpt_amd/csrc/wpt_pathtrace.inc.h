@@ -250,11 +250,19 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         /* HitableTriangle::hit, candidate part (hitable_triangle.hpp:189-271) */
                         if (COUNT)
                             lc.leaves++;
-                        const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
                         Candidate c;
                         const float bound = (ORDERED && !exact) ? amaxCull : amax;
-                        if (triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), ps.ray.o, aux,
-                                    par.min_hit_distance, bound, c)) {
+                        bool accepted;
+                        if ((F & FEAT_SPHERES) && (leafPrim & PRIM_SPHERE)) {
+                            /* HitableSphere::hit (hitable_sphere.hpp:104-147) */
+                            c.invDet = c.U = c.V = c.W = 0.0f;
+                            accepted = sphereTest(sv.spheres[leafPrim & ~PRIM_SPHERE], ps.ray.o, ps.ray.d, par.min_hit_distance, bound, c.a);
+                        } else {
+                            const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
+                            accepted = triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), ps.ray.o, aux,
+                                    par.min_hit_distance, bound, c);
+                        }
+                        if (accepted) {
                             c.prim = leafPrim;
                             if (ORDERED && !exact) {
                                 /* keep the closest; remember how close the runner-up came */
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 }
 
 constexpr uint32_t FEAT_BASIC = FEAT_GGX | FEAT_GLASS;
-constexpr uint32_t FEAT_ALL = FEAT_TEXTURES | FEAT_MODPHONG | FEAT_ENVMAP | FEAT_LENS | FEAT_TWOSIDED | FEAT_GGX | FEAT_GLASS;
+constexpr uint32_t FEAT_ALL = FEAT_TEXTURES | FEAT_MODPHONG | FEAT_ENVMAP | FEAT_LENS | FEAT_TWOSIDED | FEAT_GGX | FEAT_GLASS | FEAT_SPHERES;
 
 /* one launcher per instantiation, each defined in its own translation unit;
  * ldsBytes is the dynamic LDS size (0 for the HBM variants) */

@@ -31,6 +31,8 @@ def lib():
         L.wpt_host_sponza_like.argtypes = [C.c_uint, C.c_float, C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint]
         L.wpt_host_furnace.restype = C.c_void_p
         L.wpt_host_furnace.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_uint]
+        L.wpt_host_spheres.restype = C.c_void_p
+        L.wpt_host_spheres.argtypes = [C.c_int, C.c_uint, C.c_uint]
         L.wpt_host_courtyard_like.restype = C.c_void_p
         L.wpt_host_courtyard_like.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
         L.wpt_host_scene_desc.restype = C.POINTER(_abi.SceneDesc)
@@ -121,6 +123,15 @@ def furnace(width, height, material=0, slices=64):
     4 ModPhong(.5,.5), 5 GGX albedo 1 roughness 0.5."""
     h = lib().wpt_host_furnace(material, slices, width, height)
     return HostScene(h, width, height, "furnace(material=%d)" % material)
+
+
+def spheres(width, height, variant=0):
+    """Scenes with analytic spheres (HitableSphere): 0 = textured / GGX / glass / mirror spheres lit by
+    a sphere light and a quad light (both hot spots), 1 = the same under a cube environment map,
+    2 = wurblpt-furnace-test.cpp as written (every sphere pixel is exactly 0.42), 3 = inside a large
+    emitting sphere that is a hot spot."""
+    h = lib().wpt_host_spheres(variant, width, height)
+    return HostScene(h, width, height, "spheres(variant=%d)" % variant)
 
 
 def bvh_build(boxes):

@@ -417,3 +417,53 @@ extern "C" wpt_host_scene* wpt_host_furnace(int material, int slices, unsigned i
     scene.take(new MeshInstance(scene.take(generateSphere(Transformation(), slices, slices / 2)), mat));
     return wptHostFinish(scenePtr, width, height, radians(40.0f), vec3(0.0f, 0.0f, 5.0f), vec3(0.0f, 0.0f, 0.0f), 0.0f, 1.0f);
 }
+
+/* Scenes with analytic spheres (hitable_sphere.hpp), the "next" row f2 of the scope table:
+ * variant 0  ground + Lambertian (checker texture, rotated frame) / GGX / glass / mirror spheres,
+ *            lit by a spherical light AND a quad light, both hot spots (mixed sphere and triangle
+ *            next-event estimation, as in wurblpt-mis-test)
+ * variant 1  the same objects without lights under a cube environment map (envmap.hpp:250-285)
+ * variant 2  wurblpt-furnace-test.cpp as written: analytic sphere, Lambertian 0.42, constant
+ *            equirect environment -- every pixel on the sphere is exactly 0.42
+ * variant 3  camera inside a large emitting sphere that is a hot spot (pdfValue's inside branch) */
+extern "C" wpt_host_scene* wpt_host_spheres(int variant, unsigned int width, unsigned int height)
+{
+    Scene* scenePtr = new Scene;
+    Scene& scene = *scenePtr;
+    if (variant == 2) {
+        Texture* tex = scene.take(new TextureConstant(vec4(1.0f)));
+        scene.take(new EnvironmentMapEquiRect(tex));
+        scene.take(new Sphere(vec3(0.0f), 1.0f, scene.take(new MaterialLambertian(vec3(0.42f)))));
+        return wptHostFinish(scenePtr, width, height, radians(40.0f), vec3(0.0f, 0.0f, 5.0f), vec3(0.0f, 0.0f, 0.0f), 0.0f, 1.0f);
+    }
+    Texture* checker = scene.take(new TextureChecker(vec3(0.8f, 0.2f, 0.2f), vec3(0.9f, 0.9f, 0.8f), 8, 4));
+    Texture* groundTex = scene.take(new TextureChecker(vec3(0.3f), vec3(0.7f), 10, 10));
+    Material* ground = scene.take(new MaterialLambertian(vec3(0.7f), groundTex));
+    Material* textured = scene.take(new MaterialLambertian(vec3(0.7f), checker));
+    Material* ggx = scene.take(new MaterialGGX(vec3(0.9f, 0.7f, 0.3f), vec2(0.2f, 0.2f)));
+    Material* glass = scene.take(new MaterialGlass(vec4(0.1f), vec4(1.5f), vec4(1.0f)));
+    Material* mirror = scene.take(new MaterialMirror(vec3(0.9f)));
+    const quat layFlat = toQuat(radians(-90.0f), vec3(1.0f, 0.0f, 0.0f));
+    scene.take(new MeshInstance(scene.take(generateQuad(Transformation(vec3(0.0f), layFlat, vec3(6.0f, 6.0f, 1.0f)), 4)), ground));
+    scene.take(new Sphere(textured, Transformation(vec3(-2.2f, 0.8f, 0.0f), toQuat(radians(35.0f), normalize(vec3(0.3f, 1.0f, 0.2f))), vec3(0.8f))));
+    scene.take(new Sphere(vec3(-0.5f, 0.6f, 0.8f), 0.6f, ggx));
+    scene.take(new Sphere(vec3(1.0f, 0.7f, 0.2f), 0.7f, glass));
+    scene.take(new Sphere(mirror, Transformation(vec3(2.6f, 0.5f, -0.6f), quat::null(), vec3(0.5f, 0.25f, 0.4f)))); /* radius = max(scaling) */
+    if (variant == 0) {
+        Material* light = scene.take(new LightDiffuse(vec3(12.0f, 11.0f, 9.0f)));
+        scene.take(new Sphere(vec3(0.0f, 4.0f, 0.5f), 0.4f, light), HotSpot);
+        Material* light2 = scene.take(new LightDiffuse(vec3(2.0f, 3.0f, 5.0f)));
+        scene.take(new MeshInstance(scene.take(generateQuad(Transformation(vec3(-4.0f, 2.0f, -2.0f), toQuat(radians(60.0f), vec3(0.0f, 1.0f, 0.0f)), vec3(0.8f, 0.8f, 1.0f)), 1)), light2), HotSpot);
+    } else if (variant == 1) {
+        Texture* side[6] = {
+            scene.take(new TextureConstant(vec4(0.9f, 0.3f, 0.2f, 0.5f))), scene.take(new TextureConstant(vec4(0.2f, 0.8f, 0.3f, 0.4f))),
+            scene.take(new TextureChecker(vec3(1.5f, 1.5f, 2.0f), vec3(0.4f, 0.5f, 0.9f), 6, 6)), scene.take(new TextureConstant(vec4(0.15f, 0.12f, 0.1f, 0.1f))),
+            scene.take(new TextureChecker(vec3(0.9f, 0.9f, 0.2f), vec3(0.2f, 0.2f, 0.9f), 3, 5)), scene.take(new TextureConstant(vec4(0.6f, 0.6f, 0.6f, 0.6f))) };
+        scene.take(new EnvironmentMapCube(side[0], side[1], side[2], side[3], side[4], side[5]));
+    } else {
+        Material* glow = scene.take(new LightDiffuse(vec3(0.8f, 0.9f, 1.0f)));
+        Material* glowTwoSided = scene.take(new MaterialTwoSided(glow, glow));
+        scene.take(new Sphere(vec3(0.0f, 1.0f, 0.0f), 9.0f, glowTwoSided), HotSpot);
+    }
+    return wptHostFinish(scenePtr, width, height, radians(45.0f), vec3(0.0f, 2.0f, 6.0f), vec3(0.0f, 0.7f, 0.0f), 0.0f, 1.0f);
+}
