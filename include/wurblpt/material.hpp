@@ -16,6 +16,7 @@
 #include "constants.hpp"
 #include "gvm.hpp"
 #include "scene_component.hpp"
+#include "rgl.hpp"
 #include "texture.hpp"
 
 namespace WurblPT {
@@ -136,6 +137,53 @@ public:
         out.flags = haveNIR ? WPT_MATF_HAVE_NIR : 0;
         wptSet(out.v[0], color);
         return setTex(out, 0, colorTex, ctx) && setNormalTex(out, ctx);
+    }
+};
+
+/* material_rgl.hpp:46-102: a measured BRDF of the RGL material database (RGB data set; the
+ * near-infrared channel is the average of RGB).  The file is read and the model's tables are built
+ * when the material is created; an unreadable file is reported when the scene is flattened. */
+class MaterialRGL final : public Material
+{
+private:
+    wpt_rgl_brdf _brdf;
+    std::vector<float> _pool;
+    std::string _error;
+
+public:
+    MaterialRGL(const std::string& filenameRgb) : Material(nullptr)
+    {
+        memset(&_brdf, 0, sizeof(_brdf));
+        buildRglBrdf(filenameRgb, _pool, _brdf, _error);
+    }
+    bool valid() const { return _error.empty(); }
+    const std::string& error() const { return _error; }
+    const wpt_rgl_brdf& brdf() const { return _brdf; }
+    const std::vector<float>& tables() const { return _pool; }
+    virtual bool describe(wpt_material& out, FlattenContext& ctx) const override
+    {
+        if (!valid()) {
+            ctx.error = _error;
+            return false;
+        }
+        out = wptEmptyMaterial(WPT_MAT_RGL);
+        /* the tables move into the scene's pool: rebase the offsets */
+        const uint32_t base = uint32_t(ctx.rglData.size());
+        ctx.rglData.insert(ctx.rglData.end(), _pool.begin(), _pool.end());
+        wpt_rgl_brdf b = _brdf;
+        wpt_rgl_warp* warps[5] = { &b.ndf, &b.sigma, &b.vndf, &b.luminance, &b.rgb };
+        for (wpt_rgl_warp* w : warps) {
+            for (int k = 0; k < 3; k++)
+                w->param_values[k] += base;
+            w->data += base;
+            if (w->marginal_cdf != WPT_RGL_NONE)
+                w->marginal_cdf += base;
+            if (w->conditional_cdf != WPT_RGL_NONE)
+                w->conditional_cdf += base;
+        }
+        out.tex[0] = int(ctx.rglBrdfs.size());
+        ctx.rglBrdfs.push_back(b);
+        return setNormalTex(out, ctx);
     }
 };
 

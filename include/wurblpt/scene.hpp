@@ -64,6 +64,8 @@ public:
     std::vector<unsigned char> texels;
     std::vector<wpt_hotspot> hotspots;
     std::vector<wpt_sphere> spheres;
+    std::vector<wpt_rgl_brdf> rglBrdfs;
+    std::vector<float> rglData;
     wpt_envmap envmap;
     size_t bvhLevels = 0;
 
@@ -90,6 +92,10 @@ public:
         d.hotspots = hotspots.data();
         d.envmap = envmap;
         d.spheres = spheres.data();
+        d.rgl_count = rglBrdfs.size();
+        d.rgl_data_count = rglData.size();
+        d.rgl_brdfs = rglBrdfs.data();
+        d.rgl_data = rglData.data();
         return d;
     }
 };
@@ -364,6 +370,8 @@ public:
                 return fail(ctx.error.empty() ? "an EnvironmentMap subclass that the device path does not know is used" : ctx.error);
         }
         out.materials = ctx.materials;
+        out.rglBrdfs = ctx.rglBrdfs;
+        out.rglData = ctx.rglData;
         out.textures = ctx.textures;
         out.texels = ctx.texels;
         return true;

@@ -34,6 +34,8 @@ public:
     std::vector<unsigned char> texels;
     std::map<const Material*, int> materialIndex;
     std::vector<wpt_material> materials;
+    std::vector<wpt_rgl_brdf> rglBrdfs; /* measured BRDFs (MaterialRGL) and their tables */
+    std::vector<float> rglData;
     std::string error;
 
     int indexOf(const Texture* tex);   /* -1 for nullptr; -2 on unsupported */

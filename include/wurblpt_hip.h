@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define WPT_ABI_VERSION 2u
+#define WPT_ABI_VERSION 3u
 
 typedef enum {
     WPT_OK = 0,
@@ -124,7 +124,8 @@ enum {
     WPT_MAT_GGX = 4,           /* material_ggx.hpp */
     WPT_MAT_GLASS = 5,         /* material_glass.hpp */
     WPT_MAT_MODPHONG = 6,      /* material_modphong.hpp */
-    WPT_MAT_TWOSIDED = 7       /* material.hpp:273-334 */
+    WPT_MAT_TWOSIDED = 7,      /* material.hpp:273-334 */
+    WPT_MAT_RGL = 8            /* material_rgl.hpp:46-102, measured BRDF (powitacq_rgb) */
 };
 enum {
     WPT_MATF_HAVE_NIR = 1,
@@ -142,6 +143,7 @@ enum {
  *                 f[0]=shininess f[1]=opacity f[2]=indexOfRefraction
  *                 tex[0]=diffuse tex[1]=specular tex[2]=shininess tex[3]=opacity tex[4]=emissive
  *  TWOSIDED       tex[0]=front material index, tex[1]=back material index
+ *  RGL            tex[0]=index into wpt_scene_desc::rgl_brdfs
  * Texture indices are -1 when absent. */
 typedef struct wpt_material {
     uint32_t type;
@@ -151,6 +153,29 @@ typedef struct wpt_material {
     float v[5][4];
     float f[4];
 } wpt_material;
+
+/* One interpolant / sample warp of the measured-BRDF model (Marginal2D<Dimension> of
+ * powitacq_rgb.inl:183-640): a size_x x size_y grid of bilinear patches per parameter slice.
+ * All arrays live in wpt_scene_desc::rgl_data at the given offsets (in floats) and hold what the
+ * model's constructor computes (powitacq_rgb.inl:213-310): `data` normalised, and for the warps
+ * that are sampled the marginal and conditional CDFs (WPT_RGL_NONE otherwise). */
+#define WPT_RGL_NONE 0xffffffffu
+typedef struct wpt_rgl_warp {
+    uint32_t size_x, size_y;
+    uint32_t dims;            /* 0, 2 or 3 parameters */
+    uint32_t param_size[3];
+    uint32_t param_stride[3];
+    uint32_t param_values[3]; /* offsets of the parameter grids */
+    uint32_t data, marginal_cdf, conditional_cdf;
+    float patch_size[2], inv_patch_size[2];
+} wpt_rgl_warp;
+
+/* powitacq_rgb::BRDF::Data (powitacq_rgb.inl:856-864) */
+typedef struct wpt_rgl_brdf {
+    wpt_rgl_warp ndf, sigma, vndf, luminance, rgb;
+    uint32_t isotropic;
+    uint32_t jacobian;
+} wpt_rgl_brdf;
 
 enum { WPT_TEX_CONSTANT = 0, WPT_TEX_CHECKER = 1, WPT_TEX_IMAGE = 2, WPT_TEX_TRANSFORMER = 3 };
 enum { WPT_TEXEL_U8 = 0, WPT_TEXEL_U16 = 1, WPT_TEXEL_F32 = 2 };
@@ -212,6 +237,11 @@ typedef struct wpt_scene_desc {
     const wpt_hotspot* hotspots;
     wpt_envmap envmap;
     const wpt_sphere* spheres;
+    uint32_t rgl_count;      /* measured BRDFs (WPT_MAT_RGL) */
+    uint32_t reserved;
+    uint64_t rgl_data_count; /* floats in rgl_data */
+    const wpt_rgl_brdf* rgl_brdfs;
+    const float* rgl_data;
 } wpt_scene_desc;
 
 /* ---- camera, parameters ---------------------------------------------- */

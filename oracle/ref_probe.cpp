@@ -34,6 +34,8 @@
 #include "camera.hpp"
 #include "geometryproc.hpp"
 #include "hitable_sphere.hpp"
+#define POWITACQ_IMPLEMENTATION
+#include "powitacq_rgb.h"
 
 using namespace WurblPT;
 
@@ -630,6 +632,54 @@ int main(int argc, char* argv[])
         floats("sampler_on_unit_sphere", onSphereOut);
         floats("sampler_to_sphere_in", toSphereIn); /* direction(3) cosThetaMax */
         floats("sampler_to_sphere", toSphereOut);
+    }
+
+    /* ---- powitacq_rgb::BRDF (powitacq_rgb.inl:856-1185), the model behind MaterialRGL, on the
+     * synthetic tensor files of tests/golden/ (argv[2] = that directory) ---- */
+    if (argc > 2) {
+        const char* files[2] = { "synthetic_iso.bsdf", "synthetic_aniso.bsdf" };
+        for (int f = 0; f < 2; f++) {
+            powitacq_rgb::BRDF brdf(std::string(argv[2]) + "/" + files[f]);
+            std::mt19937 brng(777 + f);
+            auto bu01 = [&brng]() { return float(brng() >> 8) * (1.0f / 16777216.0f); };
+            auto hemi = [&](bool allowBelow) {
+                for (;;) {
+                    vec3 d(bu01() * 2.0f - 1.0f, bu01() * 2.0f - 1.0f, allowBelow ? bu01() * 2.0f - 1.0f : bu01());
+                    float l = dot(d, d);
+                    if (l > 1e-4f && l <= 1.0f)
+                        return normalize(d);
+                }
+            };
+            std::vector<float> in, sampleOut, evalOut;
+            const int n = 1024;
+            for (int i = 0; i < n; i++) {
+                vec3 wi = hemi(i % 16 == 0);
+                if (i % 32 == 1)
+                    wi = vec3(0.0f, 0.0f, 1.0f);                 /* normal incidence */
+                if (i % 32 == 2)
+                    wi = normalize(vec3(1.0f, 0.0f, 1e-3f));     /* grazing */
+                vec3 wo = hemi(i % 16 == 8);
+                float u0 = bu01(), u1 = bu01();
+                if (i % 64 == 3) { u0 = 0.0f; u1 = 0.99999994f; }
+                push3(in, wi);
+                push3(in, wo);
+                in.push_back(u0);
+                in.push_back(u1);
+                powitacq_rgb::Vector3f pwo;
+                float pdf = 0.0f;
+                powitacq_rgb::Vector3f w = brdf.sample(powitacq_rgb::Vector2f(u0, u1), powitacq_rgb::Vector3f(wi.x(), wi.y(), wi.z()), &pwo, &pdf);
+                sampleOut.push_back(w.x()); sampleOut.push_back(w.y()); sampleOut.push_back(w.z());
+                sampleOut.push_back(pwo.x()); sampleOut.push_back(pwo.y()); sampleOut.push_back(pwo.z());
+                sampleOut.push_back(pdf);
+                powitacq_rgb::Vector3f e = brdf.eval(powitacq_rgb::Vector3f(wi.x(), wi.y(), wi.z()), powitacq_rgb::Vector3f(wo.x(), wo.y(), wo.z()));
+                evalOut.push_back(e.x()); evalOut.push_back(e.y()); evalOut.push_back(e.z());
+                evalOut.push_back(brdf.pdf(powitacq_rgb::Vector3f(wi.x(), wi.y(), wi.z()), powitacq_rgb::Vector3f(wo.x(), wo.y(), wo.z())));
+            }
+            std::string k = f == 0 ? "rgl_iso" : "rgl_aniso";
+            floats((k + "_in").c_str(), in);            /* wi(3) wo(3) u(2) */
+            floats((k + "_sample").c_str(), sampleOut); /* weight(3) wo(3) pdf */
+            floats((k + "_eval").c_str(), evalOut);     /* f*cos (3) pdf */
+        }
     }
 
     fprintf(out, "\n}\n");

@@ -32,6 +32,7 @@
 #include <omp.h>
 
 #include "../include/wurblpt_hip.h"
+#include "../wurblpt_amd/csrc/wpt_rgl.h"
 #include "../wurblpt_amd/csrc/wpt_math.h"
 
 namespace {
@@ -52,6 +53,18 @@ inline float m_pow(float x, float y) { return wptm::powf_(x, y); }
 inline float m_asin(float x) { return wptm::asinf_(x); }
 inline float m_atan2(float y, float x) { return wptm::atan2f_(y, x); }
 #endif
+
+/* the measured-BRDF model (written once, see the header); its transcendentals come from this back end */
+struct OracleMath {
+    static float sin(float x) { return m_sin(x); }
+    static float cos(float x) { return m_cos(x); }
+    static float atan2(float y, float x) { return m_atan2(y, x); }
+#ifdef WPT_ORACLE_LIBM
+    static float twiceAsin(float x) { return float(2.0 * ::asin(double(x))); }
+#else
+    static float twiceAsin(float x) { return float(2.0 * wptm::asin_d(double(x))); }
+#endif
+};
 
 constexpr float k_pi = 3.1415926535897932384626433832795029L;
 constexpr float k_pi_2 = 1.5707963267948966192313216916397514L;
@@ -1241,6 +1254,25 @@ ScatterRecord materialScatter(Ctx& c, uint32_t mat, const Ray& ray, const HitRec
         float p = mpPdfValue(n, -ray.direction, dir, s, cosTheta, specProb);
         return srRandom(dir, att, p, ray.refractiveIndex);
     }
+    case WPT_MAT_RGL: { /* material_rgl.hpp:59-80 */
+        if (hit.backside)
+            return ScatterRecord();
+        TangentSpace ts = tangentSpaceAt(c, m, hit);
+        V3 wi = ts.toTangentSpace(-ray.direction);
+        V2 u = prng.in01x2();
+        wptrgl::V3 pwo;
+        float p;
+        wptrgl::V3 a = wptrgl::rglSample<OracleMath>(c.sc->rgl_brdfs[m.tex[0]], c.sc->rgl_data, wptrgl::V2 { u.x, u.y },
+                wptrgl::V3 { wi.x, wi.y, wi.z }, pwo, p);
+        V3 attenuation = V3 { a.x, a.y, a.z };
+        V3 wo = V3 { pwo.x, pwo.y, pwo.z };
+        if (dot(wo, wo) <= 0.0f)
+            return ScatterRecord();
+        V4 att = V4 { attenuation.x, attenuation.y, attenuation.z, average3(attenuation) };
+        att = att * p; /* sample() returns f * cos / pdf; the division is undone here */
+        V3 dir = normalize(ts.toWorldSpace(wo));
+        return srRandom(dir, att, p, ray.refractiveIndex);
+    }
     case WPT_MAT_TWOSIDED: /* material.hpp:290-296 */
         return hit.backside ? materialScatter(c, uint32_t(m.tex[1]), ray, toFrontSide(hit), prng)
                             : materialScatter(c, uint32_t(m.tex[0]), ray, hit, prng);
@@ -1300,6 +1332,21 @@ ScatterRecord materialScatterToDirection(const Ctx& c, uint32_t mat, const Ray& 
             float specProb = mpSpecularProbability(kd, ks);
             att = mpAttenuation(n, -ray.direction, direction, kd, ks, s, cosTheta);
             p = mpPdfValue(n, -ray.direction, direction, s, cosTheta, specProb);
+        }
+        return srRandom(direction, att, p, ray.refractiveIndex);
+    }
+    case WPT_MAT_RGL: { /* material_rgl.hpp:82-98 */
+        V4 att = v4(0.0f);
+        float p = 0.0f;
+        TangentSpace ts = tangentSpaceAt(c, m, hit);
+        if (dot(ts.normal, direction) > 0.0f) {
+            V3 wo = ts.toTangentSpace(direction);
+            V3 wi = ts.toTangentSpace(-ray.direction);
+            const wpt_rgl_brdf& b = c.sc->rgl_brdfs[m.tex[0]];
+            wptrgl::V3 a = wptrgl::rglEval<OracleMath>(b, c.sc->rgl_data, wptrgl::V3 { wi.x, wi.y, wi.z }, wptrgl::V3 { wo.x, wo.y, wo.z });
+            V3 attenuation = V3 { a.x, a.y, a.z };
+            att = V4 { attenuation.x, attenuation.y, attenuation.z, average3(attenuation) };
+            p = wptrgl::rglPdf<OracleMath>(b, c.sc->rgl_data, wptrgl::V3 { wi.x, wi.y, wi.z }, wptrgl::V3 { wo.x, wo.y, wo.z });
         }
         return srRandom(direction, att, p, ray.refractiveIndex);
     }
@@ -1677,6 +1724,23 @@ void wpt_oracle_sphere(int n, const float* records, const float* rays, const int
         Prng prng(uint32_t(seeds[i]));
         V3 d = sphereDirection(c, 0, r.origin, prng);
         dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
+    }
+}
+
+/* powitacq_rgb::BRDF: in = wi(3) wo(3) u(2); sample_out = weight(3) wo(3) pdf; eval_out = f*cos(3) pdf */
+void wpt_oracle_rgl(const wpt_rgl_brdf* brdf, const float* pool, int n, const float* in, float* sample_out, float* eval_out)
+{
+    for (int i = 0; i < n; i++) {
+        const float* q = in + 8 * i;
+        wptrgl::V3 wi { q[0], q[1], q[2] }, wo { q[3], q[4], q[5] }, swo;
+        float pdf;
+        wptrgl::V3 w = wptrgl::rglSample<OracleMath>(*brdf, pool, wptrgl::V2 { q[6], q[7] }, wi, swo, pdf);
+        float* so = sample_out + 7 * i;
+        so[0] = w.x; so[1] = w.y; so[2] = w.z; so[3] = swo.x; so[4] = swo.y; so[5] = swo.z; so[6] = pdf;
+        wptrgl::V3 e = wptrgl::rglEval<OracleMath>(*brdf, pool, wi, wo);
+        float* eo = eval_out + 4 * i;
+        eo[0] = e.x; eo[1] = e.y; eo[2] = e.z;
+        eo[3] = wptrgl::rglPdf<OracleMath>(*brdf, pool, wi, wo);
     }
 }
 

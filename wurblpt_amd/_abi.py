@@ -5,11 +5,11 @@ against values compiled from the header.
 """
 import ctypes as C
 
-WPT_ABI_VERSION = 2
+WPT_ABI_VERSION = 3
 WPT_OK = 0
 
 NODE_INNER, NODE_TRIANGLE, NODE_SPHERE, NODE_EMPTY = 0, 1, 2, 3
-MAT_NONE, MAT_LAMBERTIAN, MAT_LIGHT_DIFFUSE, MAT_MIRROR, MAT_GGX, MAT_GLASS, MAT_MODPHONG, MAT_TWOSIDED = range(8)
+MAT_NONE, MAT_LAMBERTIAN, MAT_LIGHT_DIFFUSE, MAT_MIRROR, MAT_GGX, MAT_GLASS, MAT_MODPHONG, MAT_TWOSIDED, MAT_RGL = range(9)
 
 
 class BvhNode(C.Structure):
@@ -53,6 +53,18 @@ class Texture(C.Structure):
                 ("coord_offset", C.c_float * 2), ("a", C.c_float * 4), ("b", C.c_float * 4)]
 
 
+class RglWarp(C.Structure):
+    _fields_ = [("size_x", C.c_uint32), ("size_y", C.c_uint32), ("dims", C.c_uint32), ("param_size", C.c_uint32 * 3),
+                ("param_stride", C.c_uint32 * 3), ("param_values", C.c_uint32 * 3), ("data", C.c_uint32),
+                ("marginal_cdf", C.c_uint32), ("conditional_cdf", C.c_uint32), ("patch_size", C.c_float * 2),
+                ("inv_patch_size", C.c_float * 2)]
+
+
+class RglBrdf(C.Structure):
+    _fields_ = [("ndf", RglWarp), ("sigma", RglWarp), ("vndf", RglWarp), ("luminance", RglWarp), ("rgb", RglWarp),
+                ("isotropic", C.c_uint32), ("jacobian", C.c_uint32)]
+
+
 class Envmap(C.Structure):
     _fields_ = [("type", C.c_uint32), ("compat", C.c_uint32), ("tex", C.c_int32), ("N", C.c_int32),
                 ("M", C.c_void_p), ("Ms", C.c_void_p), ("Mcs", C.c_void_p), ("cube_tex", C.c_int32 * 6)]
@@ -65,7 +77,8 @@ class SceneDesc(C.Structure):
                 ("nodes", C.POINTER(BvhNode)), ("tri_geom", C.POINTER(TriGeom)), ("tri_attr", C.POINTER(TriAttr)),
                 ("instances", C.POINTER(Instance)), ("materials", C.POINTER(Material)),
                 ("textures", C.POINTER(Texture)), ("texels", C.c_void_p), ("hotspots", C.POINTER(Hotspot)),
-                ("envmap", Envmap), ("spheres", C.POINTER(Sphere))]
+                ("envmap", Envmap), ("spheres", C.POINTER(Sphere)), ("rgl_count", C.c_uint32), ("reserved", C.c_uint32),
+                ("rgl_data_count", C.c_uint64), ("rgl_brdfs", C.POINTER(RglBrdf)), ("rgl_data", C.POINTER(C.c_float))]
 
 
 class Camera(C.Structure):
@@ -91,6 +104,6 @@ class Counters(C.Structure):
 STRUCT_SIZES = {
     "wpt_bvh_node": (BvhNode, 32), "wpt_tri_geom": (TriGeom, 48), "wpt_tri_attr": (TriAttr, 96),
     "wpt_instance": (Instance, 48), "wpt_sphere": (Sphere, 48), "wpt_hotspot": (Hotspot, 116), "wpt_material": (Material, 128),
-    "wpt_texture": (Texture, 88), "wpt_camera": (Camera, 64), "wpt_params": (Params, 32),
+    "wpt_texture": (Texture, 88), "wpt_rgl_warp": (RglWarp, 76), "wpt_rgl_brdf": (RglBrdf, 388), "wpt_camera": (Camera, 64), "wpt_params": (Params, 32),
     "wpt_counters": (Counters, 48),
 }

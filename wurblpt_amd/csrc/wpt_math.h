@@ -406,6 +406,17 @@ WPT_HD float asinf_(float x)
     return (float)atan2_d(xd, c);
 }
 
+/* asin in double (for callers that round later); domain as asinf_ */
+WPT_HD double asin_d(double xd)
+{
+    if (xd != xd)
+        return xd;
+    if (xd > 1.0 || xd < -1.0)
+        return (double)bits_to_float(0x7fc00000u);
+    double c = __builtin_sqrt((1.0 - xd) * (1.0 + xd));
+    return atan2_d(xd, c);
+}
+
 WPT_HD float acosf_(float x)
 {
     if (x != x)

@@ -1,0 +1,404 @@
+/*
+ * wpt_rgl.h -- the measured-BRDF model behind MaterialRGL (material_rgl.hpp:46-102): Dupuy and
+ * Jakob's adaptive parameterisation as the reference evaluates it (powitacq_rgb.inl).
+ *
+ *   warpSample / warpInvert / warpEval   Marginal2D<Dimension>::sample / invert / eval
+ *                                        (powitacq_rgb.inl:322-560) over the flat tables that the
+ *                                        host builds (include/wurblpt/rgl.hpp)
+ *   rglSample / rglEval / rglPdf         BRDF::sample / eval / pdf (powitacq_rgb.inl:1010-1185)
+ *
+ * Operation order, the explicit fused multiply-adds of the bilinear look-ups and the comparison
+ * forms of min/max/clamp follow the reference line by line.  The code is written once and
+ * compiled for the device (math policy: wpt_math.h) and by the test oracle (math policy: its
+ * portable or libm back end), which is pinned against golden vectors produced by the reference's
+ * own implementation (oracle/ref_probe.cpp).
+ */
+#ifndef WPT_RGL_H
+#define WPT_RGL_H
+
+#include <stdint.h>
+
+#include "../../include/wurblpt_hip.h"
+
+#if defined(__HIPCC__)
+#define WPT_RGL_HD __host__ __device__ __forceinline__
+#else
+#define WPT_RGL_HD inline
+#endif
+
+namespace wptrgl {
+
+constexpr float k_rgl_pi = 3.1415926535897932384626433832795f;
+constexpr float k_oneMinusEpsilon = 0.999999940395355225f;
+
+struct V2 {
+    float x, y;
+};
+struct V3 {
+    float x, y, z;
+};
+
+/* std::min / std::max / clamp of the reference (powitacq_rgb.inl:66-68): comparison forms */
+WPT_RGL_HD float rmax(float a, float b) { return (a < b) ? b : a; }
+WPT_RGL_HD float rmin(float a, float b) { return (b < a) ? b : a; }
+WPT_RGL_HD float rclamp(float v, float lo, float hi) { return rmin(rmax(v, lo), hi); }
+WPT_RGL_HD uint32_t umin(uint32_t a, uint32_t b) { return (b < a) ? b : a; }
+WPT_RGL_HD float sqr(float v) { return v * v; }
+
+/* find_interval (powitacq_rgb.inl:139-158) */
+template<typename Predicate>
+WPT_RGL_HD uint32_t findInterval(uint32_t size_, const Predicate& pred)
+{
+    int64_t size = (int64_t)size_ - 2, first = 1;
+    while (size > 0) {
+        const int64_t half = size >> 1, middle = first + half;
+        const bool predResult = pred((uint32_t)middle);
+        first = predResult ? middle + 1 : first;
+        size = predResult ? size - (half + 1) : half;
+    }
+    int64_t r = first - 1;
+    const int64_t hi = (int64_t)size_ - 2;
+    r = r < 0 ? 0 : r; /* clamp: min(max(v, lo), hi) */
+    r = hi < r ? hi : r;
+    return (uint32_t)r;
+}
+
+/* lookup<Dim> (powitacq_rgb.inl:563-581): multilinear interpolation over the parameter slices */
+template<int Dim>
+struct Lookup {
+    static WPT_RGL_HD float at(const float* data, uint32_t i0, uint32_t size, const float* pw, const wpt_rgl_warp& w)
+    {
+        const uint32_t i1 = i0 + w.param_stride[Dim - 1] * size;
+        const float w0 = pw[2 * Dim - 2], w1 = pw[2 * Dim - 1];
+        const float v0 = Lookup<Dim - 1>::at(data, i0, size, pw, w);
+        const float v1 = Lookup<Dim - 1>::at(data, i1, size, pw, w);
+        return __builtin_fmaf(v0, w0, v1 * w1);
+    }
+};
+template<>
+struct Lookup<0> {
+    static WPT_RGL_HD float at(const float* data, uint32_t index, uint32_t, const float*, const wpt_rgl_warp&) { return data[index]; }
+};
+
+/* parameter-related indices and weights (the common head of sample / invert / eval) */
+template<int Dim>
+WPT_RGL_HD uint32_t paramWeights(const wpt_rgl_warp& w, const float* pool, const float* param, float* pw)
+{
+    uint32_t sliceOffset = 0;
+    for (int dim = 0; dim < Dim; ++dim) {
+        if (w.param_size[dim] == 1) {
+            pw[2 * dim] = 1.0f;
+            pw[2 * dim + 1] = 0.0f;
+            continue;
+        }
+        const float* values = pool + w.param_values[dim];
+        const float p = param[dim];
+        const uint32_t index = findInterval(w.param_size[dim], [&](uint32_t idx) { return values[idx] <= p; });
+        const float p0 = values[index], p1 = values[index + 1];
+        pw[2 * dim + 1] = rclamp((p - p0) / (p1 - p0), 0.0f, 1.0f);
+        pw[2 * dim] = 1.0f - pw[2 * dim + 1];
+        sliceOffset += w.param_stride[dim] * index;
+    }
+    return sliceOffset;
+}
+
+/* Marginal2D::sample (powitacq_rgb.inl:322-432) */
+template<int Dim>
+WPT_RGL_HD V2 warpSample(const wpt_rgl_warp& w, const float* pool, V2 sample, const float* param, float& pdf)
+{
+    sample.x = rclamp(sample.x, 1.0f - k_oneMinusEpsilon, k_oneMinusEpsilon);
+    sample.y = rclamp(sample.y, 1.0f - k_oneMinusEpsilon, k_oneMinusEpsilon);
+    float pw[2 * (Dim > 0 ? Dim : 1)];
+    const uint32_t sliceOffset = paramWeights<Dim>(w, pool, param, pw);
+    const float* marginal = pool + w.marginal_cdf;
+    const float* conditional = pool + w.conditional_cdf;
+    const float* data = pool + w.data;
+
+    /* the row first */
+    uint32_t offset = 0;
+    if (Dim != 0)
+        offset = sliceOffset * w.size_y;
+    auto fetchMarginal = [&](uint32_t idx) { return Lookup<Dim>::at(marginal, offset + idx, w.size_y, pw, w); };
+    const uint32_t row = findInterval(w.size_y, [&](uint32_t idx) { return fetchMarginal(idx) < sample.y; });
+    sample.y -= fetchMarginal(row);
+
+    const uint32_t sliceSize = w.size_x * w.size_y;
+    offset = row * w.size_x;
+    if (Dim != 0)
+        offset += sliceOffset * sliceSize;
+    const float r0 = Lookup<Dim>::at(conditional, offset + w.size_x - 1, sliceSize, pw, w);
+    const float r1 = Lookup<Dim>::at(conditional, offset + (w.size_x * 2 - 1), sliceSize, pw, w);
+    bool isConst = __builtin_fabsf(r0 - r1) < 1e-4f * (r0 + r1);
+    sample.y = isConst ? (2.0f * sample.y) : (r0 - __builtin_sqrtf(r0 * r0 - 2.0f * sample.y * (r0 - r1)));
+    sample.y /= isConst ? (r0 + r1) : (r0 - r1);
+
+    /* the column next */
+    sample.x *= (1.0f - sample.y) * r0 + sample.y * r1;
+    auto fetchConditional = [&](uint32_t idx) {
+        const float v0 = Lookup<Dim>::at(conditional, offset + idx, sliceSize, pw, w);
+        const float v1 = Lookup<Dim>::at(conditional + w.size_x, offset + idx, sliceSize, pw, w);
+        return (1.0f - sample.y) * v0 + sample.y * v1;
+    };
+    const uint32_t col = findInterval(w.size_x, [&](uint32_t idx) { return fetchConditional(idx) < sample.x; });
+    sample.x -= fetchConditional(col);
+    offset += col;
+
+    const float v00 = Lookup<Dim>::at(data, offset, sliceSize, pw, w);
+    const float v10 = Lookup<Dim>::at(data + 1, offset, sliceSize, pw, w);
+    const float v01 = Lookup<Dim>::at(data + w.size_x, offset, sliceSize, pw, w);
+    const float v11 = Lookup<Dim>::at(data + w.size_x + 1, offset, sliceSize, pw, w);
+    const float c0 = __builtin_fmaf((1.0f - sample.y), v00, sample.y * v01);
+    const float c1 = __builtin_fmaf((1.0f - sample.y), v10, sample.y * v11);
+    isConst = __builtin_fabsf(c0 - c1) < 1e-4f * (c0 + c1);
+    sample.x = isConst ? (2.0f * sample.x) : (c0 - __builtin_sqrtf(c0 * c0 - 2.0f * sample.x * (c0 - c1)));
+    sample.x /= isConst ? (c0 + c1) : (c0 - c1);
+
+    V2 r;
+    r.x = ((float)col + sample.x) * w.patch_size[0];
+    r.y = ((float)row + sample.y) * w.patch_size[1];
+    pdf = ((1.0f - sample.x) * c0 + sample.x * c1) * (w.inv_patch_size[0] * w.inv_patch_size[1]);
+    return r;
+}
+
+/* Marginal2D::invert (powitacq_rgb.inl:435-514) */
+template<int Dim>
+WPT_RGL_HD V2 warpInvert(const wpt_rgl_warp& w, const float* pool, V2 sample, const float* param, float& pdfOut)
+{
+    float pw[2 * (Dim > 0 ? Dim : 1)];
+    const uint32_t sliceOffset = paramWeights<Dim>(w, pool, param, pw);
+    const float* marginal = pool + w.marginal_cdf;
+    const float* conditional = pool + w.conditional_cdf;
+    const float* data = pool + w.data;
+
+    sample.x *= w.inv_patch_size[0];
+    sample.y *= w.inv_patch_size[1];
+    const uint32_t posX = umin((uint32_t)sample.x, w.size_x - 2u);
+    const uint32_t posY = umin((uint32_t)sample.y, w.size_y - 2u);
+    sample.x -= (float)(int32_t)posX;
+    sample.y -= (float)(int32_t)posY;
+
+    uint32_t offset = posX + posY * w.size_x;
+    const uint32_t sliceSize = w.size_x * w.size_y;
+    if (Dim != 0)
+        offset += sliceOffset * sliceSize;
+
+    const float v00 = Lookup<Dim>::at(data, offset, sliceSize, pw, w);
+    const float v10 = Lookup<Dim>::at(data + 1, offset, sliceSize, pw, w);
+    const float v01 = Lookup<Dim>::at(data + w.size_x, offset, sliceSize, pw, w);
+    const float v11 = Lookup<Dim>::at(data + w.size_x + 1, offset, sliceSize, pw, w);
+    const float w1x = sample.x, w1y = sample.y, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    const float c0 = __builtin_fmaf(w0y, v00, w1y * v01);
+    const float c1 = __builtin_fmaf(w0y, v10, w1y * v11);
+    const float pdf = __builtin_fmaf(w0x, c0, w1x * c1);
+
+    sample.x *= c0 + 0.5f * sample.x * (c1 - c0);
+    const float v0 = Lookup<Dim>::at(conditional, offset, sliceSize, pw, w);
+    const float v1 = Lookup<Dim>::at(conditional + w.size_x, offset, sliceSize, pw, w);
+    sample.x += (1.0f - sample.y) * v0 + sample.y * v1;
+
+    offset = posY * w.size_x;
+    if (Dim != 0)
+        offset += sliceOffset * sliceSize;
+    const float r0 = Lookup<Dim>::at(conditional, offset + w.size_x - 1, sliceSize, pw, w);
+    const float r1 = Lookup<Dim>::at(conditional, offset + (w.size_x * 2 - 1), sliceSize, pw, w);
+    sample.x /= (1.0f - sample.y) * r0 + sample.y * r1;
+
+    sample.y *= r0 + 0.5f * sample.y * (r1 - r0);
+    offset = posY;
+    if (Dim != 0)
+        offset += sliceOffset * w.size_y;
+    sample.y += Lookup<Dim>::at(marginal, offset, w.size_y, pw, w);
+
+    pdfOut = pdf * (w.inv_patch_size[0] * w.inv_patch_size[1]);
+    return sample;
+}
+
+/* Marginal2D::eval (powitacq_rgb.inl:520-560) */
+template<int Dim>
+WPT_RGL_HD float warpEval(const wpt_rgl_warp& w, const float* pool, V2 pos, const float* param)
+{
+    float pw[2 * (Dim > 0 ? Dim : 1)];
+    const uint32_t sliceOffset = paramWeights<Dim>(w, pool, param, pw);
+    const float* data = pool + w.data;
+    pos.x *= w.inv_patch_size[0];
+    pos.y *= w.inv_patch_size[1];
+    const uint32_t ox = umin((uint32_t)pos.x, w.size_x - 2u);
+    const uint32_t oy = umin((uint32_t)pos.y, w.size_y - 2u);
+    const float w1x = pos.x - (float)(int32_t)ox, w1y = pos.y - (float)(int32_t)oy;
+    const float w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    uint32_t index = ox + oy * w.size_x;
+    const uint32_t size = w.size_x * w.size_y;
+    if (Dim != 0)
+        index += sliceOffset * size;
+    const float v00 = Lookup<Dim>::at(data, index, size, pw, w);
+    const float v10 = Lookup<Dim>::at(data + 1, index, size, pw, w);
+    const float v01 = Lookup<Dim>::at(data + w.size_x, index, size, pw, w);
+    const float v11 = Lookup<Dim>::at(data + w.size_x + 1, index, size, pw, w);
+    return __builtin_fmaf(w0y, __builtin_fmaf(w0x, v00, w1x * v10), w1y * __builtin_fmaf(w0x, v01, w1x * v11))
+        * (w.inv_patch_size[0] * w.inv_patch_size[1]);
+}
+
+/* BRDF convenience functions (powitacq_rgb.inl:870-884) */
+WPT_RGL_HD float u2theta(float u) { return sqr(u) * (k_rgl_pi / 2.0f); }
+WPT_RGL_HD float u2phi(float u) { return (2.0f * u - 1.0f) * k_rgl_pi; }
+WPT_RGL_HD float phi2u(float phi) { return (phi + k_rgl_pi) / (2.0f * k_rgl_pi); }
+template<class M> WPT_RGL_HD float theta2u(float theta) { return __builtin_sqrtf(theta * (2.0f / k_rgl_pi)); }
+/* elevation (powitacq_rgb.inl:1012-1014).  The reference calls the unqualified `asin`, which for
+ * a float argument is the C library's double function there, and multiplies by 2.f in double
+ * before the result is rounded to float once: M::twiceAsin(x) = float(2.0 * asin(double(x))). */
+template<class M> WPT_RGL_HD float elevation(V3 d)
+{
+    return M::twiceAsin(0.5f * __builtin_sqrtf(sqr(d.x) + sqr(d.y) + sqr(d.z - 1.0f)));
+}
+WPT_RGL_HD float dot3(V3 a, V3 b)
+{
+    float r = 0.0f;
+    r += a.x * b.x;
+    r += a.y * b.y;
+    r += a.z * b.z;
+    return r;
+}
+WPT_RGL_HD V3 normalize3(V3 v)
+{
+    const float l = __builtin_sqrtf(dot3(v, v));
+    V3 r;
+    r.x = v.x / l;
+    r.y = v.y / l;
+    r.z = v.z / l;
+    return r;
+}
+
+/* the three colour channels of the spectral interpolant, clipped (POWITACQ_CLIP_RGB) */
+WPT_RGL_HD V3 rglColour(const wpt_rgl_brdf& b, const float* pool, V2 sample, float phi_i, float theta_i)
+{
+    float fr[3];
+    for (int i = 0; i < 3; ++i) {
+        const float paramsFr[3] = { phi_i, theta_i, (float)i };
+        fr[i] = warpEval<3>(b.rgb, pool, sample, paramsFr);
+        fr[i] = rmax(0.0f, fr[i]);
+    }
+    V3 r;
+    r.x = fr[0];
+    r.y = fr[1];
+    r.z = fr[2];
+    return r;
+}
+
+/* BRDF::pdf (powitacq_rgb.inl:1016-1050) */
+template<class M>
+WPT_RGL_HD float rglPdf(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
+{
+    if (wi.z <= 0 || wo.z <= 0)
+        return 0.0f;
+    V3 s;
+    s.x = wi.x + wo.x;
+    s.y = wi.y + wo.y;
+    s.z = wi.z + wo.z;
+    const V3 wm = normalize3(s);
+    const float theta_i = elevation<M>(wi), phi_i = M::atan2(wi.y, wi.x);
+    const float theta_m = elevation<M>(wm), phi_m = M::atan2(wm.y, wm.x);
+    V2 u_wm;
+    u_wm.x = theta2u<M>(theta_m);
+    u_wm.y = phi2u(b.isotropic ? (phi_m - phi_i) : phi_m);
+    u_wm.y = u_wm.y - __builtin_floorf(u_wm.y);
+    float vndfPdf;
+    const float params[2] = { phi_i, theta_i };
+    const V2 sample = warpInvert<2>(b.vndf, pool, u_wm, params, vndfPdf);
+    const float pdf = warpEval<2>(b.luminance, pool, sample, params);
+    const float sinThetaM = __builtin_sqrtf(sqr(wm.x) + sqr(wm.y));
+    const float jacobian = rmax(2.0f * sqr(k_rgl_pi) * u_wm.x * sinThetaM, 1e-6f) * 4.0f * dot3(wi, wm);
+    return vndfPdf * pdf / jacobian;
+}
+
+/* BRDF::eval (powitacq_rgb.inl:1056-1100): f_r * cos */
+template<class M>
+WPT_RGL_HD V3 rglEval(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
+{
+    V3 zero;
+    zero.x = zero.y = zero.z = 0.0f;
+    if (wi.z <= 0 || wo.z <= 0)
+        return zero;
+    V3 s;
+    s.x = wi.x + wo.x;
+    s.y = wi.y + wo.y;
+    s.z = wi.z + wo.z;
+    const V3 wm = normalize3(s);
+    const float theta_i = elevation<M>(wi), phi_i = M::atan2(wi.y, wi.x);
+    const float theta_m = elevation<M>(wm), phi_m = M::atan2(wm.y, wm.x);
+    V2 u_wi;
+    u_wi.x = theta2u<M>(theta_i);
+    u_wi.y = phi2u(phi_i);
+    V2 u_wm;
+    u_wm.x = theta2u<M>(theta_m);
+    u_wm.y = phi2u(b.isotropic ? (phi_m - phi_i) : phi_m);
+    u_wm.y = u_wm.y - __builtin_floorf(u_wm.y);
+    float vndfPdf;
+    const float params[2] = { phi_i, theta_i };
+    const V2 sample = warpInvert<2>(b.vndf, pool, u_wm, params, vndfPdf);
+    V3 fr = rglColour(b, pool, sample, phi_i, theta_i);
+    const float n = warpEval<0>(b.ndf, pool, u_wm, params);
+    const float d = 4 * warpEval<0>(b.sigma, pool, u_wi, params);
+    fr.x = fr.x * n / d;
+    fr.y = fr.y * n / d;
+    fr.z = fr.z * n / d;
+    return fr;
+}
+
+/* BRDF::sample (powitacq_rgb.inl:1106-1183): returns f_r * cos / pdf, the outgoing direction
+ * (zero when the sample fails) and the pdf */
+template<class M>
+WPT_RGL_HD V3 rglSample(const wpt_rgl_brdf& b, const float* pool, V2 u, V3 wi, V3& woOut, float& pdfOut)
+{
+    V3 zero;
+    zero.x = zero.y = zero.z = 0.0f;
+    woOut = zero;
+    pdfOut = 0.0f;
+    if (wi.z <= 0)
+        return zero;
+    const float theta_i = elevation<M>(wi), phi_i = M::atan2(wi.y, wi.x);
+    const float params[2] = { phi_i, theta_i };
+    V2 u_wi;
+    u_wi.x = theta2u<M>(theta_i);
+    u_wi.y = phi2u(phi_i);
+    V2 sample;
+    sample.x = u.y;
+    sample.y = u.x;
+    float lumPdf;
+    sample = warpSample<2>(b.luminance, pool, sample, params, lumPdf);
+    float ndfPdf;
+    const V2 u_wm = warpSample<2>(b.vndf, pool, sample, params, ndfPdf);
+    float phi_m = u2phi(u_wm.y);
+    const float theta_m = u2theta(u_wm.x);
+    if (b.isotropic)
+        phi_m += phi_i;
+    const float sinPhiM = M::sin(phi_m), cosPhiM = M::cos(phi_m), sinThetaM = M::sin(theta_m), cosThetaM = M::cos(theta_m);
+    V3 wm;
+    wm.x = cosPhiM * sinThetaM;
+    wm.y = sinPhiM * sinThetaM;
+    wm.z = cosThetaM;
+    const float dwm = dot3(wm, wi);
+    V3 wo;
+    wo.x = wm.x * 2.0f * dwm - wi.x;
+    wo.y = wm.y * 2.0f * dwm - wi.y;
+    wo.z = wm.z * 2.0f * dwm - wi.z;
+    if (wo.z <= 0)
+        return zero;
+    V3 fr = rglColour(b, pool, sample, phi_i, theta_i);
+    const float n = warpEval<0>(b.ndf, pool, u_wm, params);
+    const float d = 4 * warpEval<0>(b.sigma, pool, u_wi, params);
+    fr.x = fr.x * n / d;
+    fr.y = fr.y * n / d;
+    fr.z = fr.z * n / d;
+    const float jacobian = rmax(2.0f * sqr(k_rgl_pi) * u_wm.x * sinThetaM, 1e-6f) * 4.0f * dot3(wi, wm);
+    const float pdf = ndfPdf * lumPdf / jacobian;
+    woOut = wo;
+    pdfOut = pdf;
+    fr.x /= pdf;
+    fr.y /= pdf;
+    fr.z /= pdf;
+    return fr;
+}
+
+} /* namespace wptrgl */
+
+#endif

@@ -33,6 +33,10 @@ def lib():
         L.wpt_host_furnace.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_uint]
         L.wpt_host_spheres.restype = C.c_void_p
         L.wpt_host_spheres.argtypes = [C.c_int, C.c_uint, C.c_uint]
+        L.wpt_host_rgl_scene.restype = C.c_void_p
+        L.wpt_host_rgl_scene.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_uint, C.c_uint]
+        L.wpt_host_rgl_build.restype = C.c_ulonglong
+        L.wpt_host_rgl_build.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_ulonglong]
         L.wpt_host_courtyard_like.restype = C.c_void_p
         L.wpt_host_courtyard_like.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
         L.wpt_host_scene_desc.restype = C.POINTER(_abi.SceneDesc)
@@ -132,6 +136,30 @@ def spheres(width, height, variant=0):
     emitting sphere that is a hot spot."""
     h = lib().wpt_host_spheres(variant, width, height)
     return HostScene(h, width, height, "spheres(variant=%d)" % variant)
+
+
+def rgl_fixture(name):
+    """path of a synthetic measured-BRDF file committed under tests/golden (iso / aniso)"""
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "synthetic_%s.bsdf" % name)
+
+
+def rgl_build(filename):
+    """The model's tables for a BRDF file, as MaterialRGL builds them: (_abi.RglBrdf, float32 pool)."""
+    n = lib().wpt_host_rgl_build(filename.encode(), None, None, 0)
+    if n == 0:
+        raise RuntimeError("cannot read %s as a measured BRDF" % filename)
+    brdf = _abi.RglBrdf()
+    pool = np.zeros(n, np.float32)
+    lib().wpt_host_rgl_build(filename.encode(), C.byref(brdf), C.c_void_p(pool.ctypes.data), n)
+    return brdf, pool
+
+
+def rgl_scene(width, height, variant=0, file0=None, file1=None):
+    """Scenes with MaterialRGL: 0 = furnace test, 1 = two measured spheres under a quad light."""
+    f0 = file0 or rgl_fixture("iso")
+    f1 = file1 or rgl_fixture("aniso")
+    h = lib().wpt_host_rgl_scene(variant, f0.encode(), f1.encode(), width, height)
+    return HostScene(h, width, height, "rgl_scene(variant=%d)" % variant)
 
 
 def bvh_build(boxes):

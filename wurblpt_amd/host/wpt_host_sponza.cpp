@@ -412,7 +412,8 @@ extern "C" wpt_host_scene* wpt_host_furnace(int material, int slices, unsigned i
     case 2: mat = scene.take(new MaterialModPhong(vec3(1.0f), vec3(0.0f))); break;
     case 3: mat = scene.take(new MaterialModPhong(vec3(0.0f), vec3(1.0f))); break;
     case 4: mat = scene.take(new MaterialModPhong(vec3(0.5f), vec3(0.5f))); break;
-    default: mat = scene.take(new MaterialGGX(vec3(1.0f), vec2(0.5f, 0.5f))); break;
+    case 5: mat = scene.take(new MaterialGGX(vec3(1.0f), vec2(0.5f, 0.5f))); break;
+    default: mat = nullptr; break;
     }
     scene.take(new MeshInstance(scene.take(generateSphere(Transformation(), slices, slices / 2)), mat));
     return wptHostFinish(scenePtr, width, height, radians(40.0f), vec3(0.0f, 0.0f, 5.0f), vec3(0.0f, 0.0f, 0.0f), 0.0f, 1.0f);
@@ -465,5 +466,58 @@ extern "C" wpt_host_scene* wpt_host_spheres(int variant, unsigned int width, uns
         Material* glowTwoSided = scene.take(new MaterialTwoSided(glow, glow));
         scene.take(new Sphere(vec3(0.0f, 1.0f, 0.0f), 9.0f, glowTwoSided), HotSpot);
     }
+    return wptHostFinish(scenePtr, width, height, radians(45.0f), vec3(0.0f, 2.0f, 6.0f), vec3(0.0f, 0.7f, 0.0f), 0.0f, 1.0f);
+}
+
+/* Builds the tables of a measured BRDF file as MaterialRGL does (include/wurblpt/rgl.hpp).
+ * Returns the number of floats of the table pool (0 on error, message on stderr); copies at most
+ * `capacity` of them. */
+extern "C" unsigned long long wpt_host_rgl_build(const char* filename, wpt_rgl_brdf* brdf, float* pool, unsigned long long capacity)
+{
+    std::vector<float> p;
+    std::string error;
+    wpt_rgl_brdf b;
+    if (!buildRglBrdf(filename, p, b, error)) {
+        fprintf(stderr, "wpt_host: %s\n", error.c_str());
+        return 0;
+    }
+    if (brdf)
+        *brdf = b;
+    if (pool)
+        memcpy(pool, p.data(), sizeof(float) * (p.size() < capacity ? p.size() : capacity));
+    return p.size();
+}
+
+/* Measured-BRDF scenes (material_rgl.hpp): variant 0 = the furnace test with its RGL option
+ * (wurblpt-furnace-test.cpp:67) on a tessellated sphere in a constant environment; variant 1 =
+ * a ground plane with a quad light (hot spot, so next-event estimation evaluates the BRDF with
+ * scatterToDirection), one sphere of the first file, one analytic sphere of the second file with
+ * a normal map, under a constant environment of low radiance */
+extern "C" wpt_host_scene* wpt_host_rgl_scene(int variant, const char* file0, const char* file1, unsigned int width, unsigned int height)
+{
+    Scene* scenePtr = new Scene;
+    Scene& scene = *scenePtr;
+    MaterialRGL* m0 = new MaterialRGL(file0);
+    scene.take(m0, "rgl0");
+    if (variant == 0) {
+        Texture* tex = scene.take(new TextureConstant(vec4(1.0f)));
+        scene.take(new EnvironmentMapEquiRect(tex));
+        scene.take(new MeshInstance(scene.take(generateSphere(Transformation(), 48, 24)), m0));
+        return wptHostFinish(scenePtr, width, height, radians(40.0f), vec3(0.0f, 0.0f, 5.0f), vec3(0.0f, 0.0f, 0.0f), 0.0f, 1.0f);
+    }
+    MaterialRGL* m1 = new MaterialRGL(file1);
+    Rng rng(5);
+    m1->normalTex = makeNormalMap(scene, rng, 32, 4.0f);
+    scene.take(m1, "rgl1");
+    Texture* envTex = scene.take(new TextureConstant(vec4(0.05f, 0.06f, 0.08f, 0.06f)));
+    scene.take(new EnvironmentMapEquiRect(envTex));
+    Texture* groundTex = scene.take(new TextureChecker(vec3(0.3f), vec3(0.7f), 10, 10));
+    Material* ground = scene.take(new MaterialLambertian(vec3(0.7f), groundTex));
+    const quat layFlat = toQuat(radians(-90.0f), vec3(1.0f, 0.0f, 0.0f));
+    scene.take(new MeshInstance(scene.take(generateQuad(Transformation(vec3(0.0f), layFlat, vec3(6.0f, 6.0f, 1.0f)), 4)), ground));
+    scene.take(new MeshInstance(scene.take(generateSphere(Transformation(vec3(-1.1f, 0.8f, 0.0f), quat::null(), vec3(0.8f)), 32, 16)), m0));
+    scene.take(new Sphere(vec3(1.1f, 0.8f, 0.2f), 0.8f, m1));
+    Material* light = scene.take(new LightDiffuse(vec3(14.0f, 13.0f, 12.0f)));
+    scene.take(new MeshInstance(scene.take(generateQuad(Transformation(vec3(0.0f, 4.0f, 1.0f), toQuat(radians(90.0f), vec3(1.0f, 0.0f, 0.0f)), vec3(0.7f, 0.7f, 1.0f)), 1)), light), HotSpot);
     return wptHostFinish(scenePtr, width, height, radians(45.0f), vec3(0.0f, 2.0f, 6.0f), vec3(0.0f, 0.7f, 0.0f), 0.0f, 1.0f);
 }
