@@ -158,6 +158,9 @@ uint32_t sceneFeatures(const wpt_scene_desc* d)
         f |= FEAT_ENVMAP | FEAT_TEXTURES;
     if (d->sphere_count > 0)
         f |= FEAT_SPHERES;
+    for (uint32_t i = 0; i < d->material_count; i++)
+        if (d->materials[i].type == WPT_MAT_RGL)
+            f |= FEAT_RGL;
     return f;
 }
 
@@ -192,8 +195,15 @@ wpt_status validate(const wpt_scene_desc* d)
     }
     for (uint32_t i = 0; i < d->material_count; i++) {
         const wpt_material& m = d->materials[i];
-        if (m.type > WPT_MAT_TWOSIDED)
+        if (m.type > WPT_MAT_RGL)
             return fail(WPT_ERR_UNSUPPORTED, "material type is not known to the kernel");
+        if (m.type == WPT_MAT_RGL) {
+            if (m.tex[0] < 0 || uint32_t(m.tex[0]) >= d->rgl_count)
+                return fail(WPT_ERR_INVALID_ARGUMENT, "material references a measured BRDF outside the array");
+            if (m.normal_tex >= int32_t(d->texture_count))
+                return fail(WPT_ERR_INVALID_ARGUMENT, "material references a normal map outside the array");
+            continue;
+        }
         if (m.type == WPT_MAT_TWOSIDED) {
             if (m.tex[0] < 0 || m.tex[1] < 0 || uint32_t(m.tex[0]) >= d->material_count || uint32_t(m.tex[1]) >= d->material_count)
                 return fail(WPT_ERR_INVALID_ARGUMENT, "two-sided material references a material outside the array");
@@ -216,6 +226,32 @@ wpt_status validate(const wpt_scene_desc* d)
             if (t.width == 0 || t.height == 0 || t.comps < 1 || t.comps > 4 || t.texel_type > WPT_TEXEL_F32
                     || t.texel_offset + size_t(t.width) * t.height * t.comps * cs > d->texel_bytes)
                 return fail(WPT_ERR_INVALID_ARGUMENT, "image texture lies outside the texel pool");
+        }
+    }
+    if (d->rgl_count > 0 && (!d->rgl_brdfs || !d->rgl_data))
+        return fail(WPT_ERR_INVALID_ARGUMENT, "measured BRDF arrays are NULL");
+    for (uint32_t i = 0; i < d->rgl_count; i++) {
+        /* every table of the model must lie inside the pool (the kernel indexes it with data-dependent offsets) */
+        const wpt_rgl_brdf& b = d->rgl_brdfs[i];
+        const wpt_rgl_warp* warps[5] = { &b.ndf, &b.sigma, &b.vndf, &b.luminance, &b.rgb };
+        const uint32_t wantDims[5] = { 0, 0, 2, 2, 3 };
+        for (int k = 0; k < 5; k++) {
+            const wpt_rgl_warp& w = *warps[k];
+            if (w.dims != wantDims[k] || w.size_x < 2 || w.size_y < 2)
+                return fail(WPT_ERR_INVALID_ARGUMENT, "measured BRDF table has an unexpected shape");
+            uint64_t slices = 1;
+            for (uint32_t dim = 0; dim < w.dims; dim++) {
+                if (w.param_size[dim] < 1 || uint64_t(w.param_values[dim]) + w.param_size[dim] > d->rgl_data_count)
+                    return fail(WPT_ERR_INVALID_ARGUMENT, "measured BRDF parameter grid lies outside the pool");
+                slices *= w.param_size[dim];
+            }
+            const uint64_t n = uint64_t(w.size_x) * w.size_y;
+            const bool cdf = k == 2 || k == 3;
+            if (uint64_t(w.data) + slices * n > d->rgl_data_count
+                    || (cdf && (w.marginal_cdf == WPT_RGL_NONE || w.conditional_cdf == WPT_RGL_NONE
+                            || uint64_t(w.marginal_cdf) + slices * w.size_y > d->rgl_data_count
+                            || uint64_t(w.conditional_cdf) + slices * n > d->rgl_data_count)))
+                return fail(WPT_ERR_INVALID_ARGUMENT, "measured BRDF table lies outside the pool");
         }
     }
     if (d->sphere_count > 0 && !d->spheres)
@@ -401,6 +437,8 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     }
     UP(uploadArray(s, desc->hotspots, desc->hotspot_count, &s->view.hotspots));
     UP(uploadArray(s, desc->spheres, desc->sphere_count, &s->view.spheres));
+    UP(uploadArray(s, desc->rgl_brdfs, desc->rgl_count, &s->view.rglBrdfs));
+    UP(uploadArray(s, desc->rgl_data, size_t(desc->rgl_data_count), &s->view.rglData));
     s->view.sphereCount = desc->sphere_count;
     for (int k = 0; k < 6; k++)
         s->view.envCube[k] = desc->envmap.cube_tex[k];
@@ -551,11 +589,16 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     args.travWaves = 8;
     args.heavyWaves = 4;
     args.pixelCounter = nullptr;
+    const bool rgl = (need & FEAT_RGL) != 0; /* measured BRDFs have their own instantiation of the product kernel */
     if (count) {
         if (basic)
             launchBasicCount(args, grid, stream);
+        else if (rgl)
+            launchFullRglCount(args, grid, stream);
         else
             launchFullCount(args, grid, stream);
+    } else if (rgl) {
+        launchFullRgl(args, grid, stream);
     } else if (ldsState) {
         /* variant bit 0x40: pixel states in LDS, persistent workgroups (wpt_pathtrace_wf.inc.h);
          * byte 1 of the variant word, if set, is the number of traversal waves per workgroup */

@@ -24,6 +24,7 @@
 
 #include "../../include/wurblpt_hip.h"
 #include "wpt_math.h"
+#include "wpt_rgl.h"
 
 namespace wptd {
 
@@ -412,7 +413,8 @@ enum {
     FEAT_TWOSIDED = 16,  /* MaterialTwoSided */
     FEAT_GGX = 32,       /* MaterialGGX */
     FEAT_GLASS = 64,     /* MaterialGlass, MaterialMirror */
-    FEAT_SPHERES = 128   /* HitableSphere leaves and sphere hot spots */
+    FEAT_SPHERES = 128,  /* HitableSphere leaves and sphere hot spots */
+    FEAT_RGL = 256       /* MaterialRGL, measured BRDFs (wpt_rgl.h) */
 };
 
 /* a primitive index with this bit is a sphere (index in the low bits), otherwise a triangle */
@@ -439,6 +441,8 @@ struct SceneView {
     const float4* texels4; /* decoded RGBA texels of all image textures */
     const wpt_hotspot* hotspots;
     const wpt_sphere* spheres;
+    const wpt_rgl_brdf* rglBrdfs; /* measured BRDFs and the pool their tables live in */
+    const float* rglData;
     const float* envM;
     const int32_t* envMs;
     const float* envMcs;
@@ -791,6 +795,14 @@ WPT_D f3 envD(const SceneView& sv, Prng& prng)
 }
 
 /* ---- materials ---- */
+/* transcendentals of the measured-BRDF model on the device (wpt_rgl.h) */
+struct DeviceRglMath {
+    static WPT_D float sin(float x) { return wptm::sinf_(x); }
+    static WPT_D float cos(float x) { return wptm::cosf_(x); }
+    static WPT_D float atan2(float y, float x) { return wptm::atan2f_(y, x); }
+    static WPT_D float twiceAsin(float x) { return (float)(2.0 * wptm::asin_d((double)x)); }
+};
+
 enum { SCATTER_NONE = 0, SCATTER_EXPLICIT = 1, SCATTER_RANDOM = 2 };
 struct Scatter {
     int type;
@@ -980,6 +992,30 @@ template<uint32_t F> WPT_D Scatter materialScatter(const SceneView& sv, const wp
         f4 att = sclr(withNir<F>(m, texOrConst<F>(sv, m.tex[0], m.v[0], h.tc)), p);
         return scatterMake(SCATTER_RANDOM, dir, att, p, ray.ri);
     }
+    case WPT_MAT_RGL: { /* material_rgl.hpp:59-80 */
+        if (!(F & FEAT_RGL) || h.backside)
+            return scatterNone();
+        Frame ts = tangentSpaceAt<F>(sv, m, h);
+        const f3 wi = toTangent(ts, neg(ray.d));
+        const f2 u = in01x2(prng);
+        wptrgl::V3 pwo;
+        float p;
+        wptrgl::V2 uu;
+        uu.x = u.x;
+        uu.y = u.y;
+        wptrgl::V3 wwi;
+        wwi.x = wi.x;
+        wwi.y = wi.y;
+        wwi.z = wi.z;
+        const wptrgl::V3 a = wptrgl::rglSample<DeviceRglMath>(sv.rglBrdfs[m.tex[0]], sv.rglData, uu, wwi, pwo, p);
+        const f3 wo = mk3(pwo.x, pwo.y, pwo.z);
+        if (dot(wo, wo) <= 0.0f)
+            return scatterNone();
+        const f3 attenuation = mk3(a.x, a.y, a.z);
+        f4 att = sclr(mk4(attenuation.x, attenuation.y, attenuation.z, average3(attenuation)), p); /* undo the division by the pdf */
+        const f3 dir = normalize(toWorld(ts, wo));
+        return scatterMake(SCATTER_RANDOM, dir, att, p, ray.ri);
+    }
     case WPT_MAT_GGX: { /* material_ggx.hpp:173-225 */
         if (!(F & FEAT_GGX) || h.backside)
             return scatterNone();
@@ -1151,6 +1187,28 @@ template<uint32_t F> WPT_D void materialEval(const SceneView& sv, const wpt_mate
         if (cosTheta > 0.0f) {
             p = cosTheta * k_inv_pi;
             att = sclr(withNir<F>(m, texOrConst<F>(sv, m.tex[0], m.v[0], h.tc)), p);
+        }
+        break;
+    }
+    case WPT_MAT_RGL: { /* material_rgl.hpp:82-98 */
+        if (!(F & FEAT_RGL))
+            break;
+        Frame ts = tangentSpaceAt<F>(sv, m, h);
+        if (dot(ts.n, direction) > 0.0f) {
+            const f3 wo = toTangent(ts, direction);
+            const f3 wi = toTangent(ts, neg(ray.d));
+            wptrgl::V3 wwi, wwo;
+            wwi.x = wi.x;
+            wwi.y = wi.y;
+            wwi.z = wi.z;
+            wwo.x = wo.x;
+            wwo.y = wo.y;
+            wwo.z = wo.z;
+            const wpt_rgl_brdf& b = sv.rglBrdfs[m.tex[0]];
+            const wptrgl::V3 a = wptrgl::rglEval<DeviceRglMath>(b, sv.rglData, wwi, wwo);
+            const f3 attenuation = mk3(a.x, a.y, a.z);
+            att = mk4(attenuation.x, attenuation.y, attenuation.z, average3(attenuation));
+            p = wptrgl::rglPdf<DeviceRglMath>(b, sv.rglData, wwi, wwo);
         }
         break;
     }

@@ -1,0 +1,11 @@
+/* wpt_k_full_rgl_count.hip -- instantiates wpt_pathtrace<FEAT_ALL | FEAT_RGL, true, false> (work counters) */
+#include "wpt_pathtrace.inc.h"
+
+namespace wptk {
+
+void launchFullRglCount(const KernelArgs& args, dim3 grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL | FEAT_RGL, true, false, 2, false>), grid, dim3(WG), 0, stream, args);
+}
+
+}

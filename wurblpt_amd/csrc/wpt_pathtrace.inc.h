@@ -396,6 +396,8 @@ void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFullCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
+void launchFullRgl(const KernelArgs& args, dim3 grid, hipStream_t stream);
+void launchFullRglCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 
 } /* namespace wptk */
 
