@@ -36,6 +36,9 @@ WORKLOADS = {
     # BASELINE configs[3]: procedural San-Miguel-class stand-in, ~10 M triangles; 128 spp is not a perfect
     # square (spp = samplesSqrt^2, wurblpt.hpp:304), so 11^2 = 121 spp as SURVEY.md section 8(d) says
     "courtyard_like_10M_1920x1080_121spp": dict(kind="courtyard", triangles=10_000_000, width=1920, height=1080, samples_sqrt=11),
+    # BASELINE configs[4]: Bistro-class stand-in: the Sponza-class architecture with measured BRDFs (MaterialRGL on
+    # synthetic tensor files of the database's usual resolution) + normal maps; 512 spp is not a perfect square: 23^2 = 529
+    "measured_like_3840x2160_529spp_rgl": dict(kind="measured", width=3840, height=2160, samples_sqrt=23),
 }
 
 
@@ -45,6 +48,17 @@ def build_scene(w):
         return host.cornell(w["width"], w["height"], w["tall"], w["short"])
     if w["kind"] == "sponza":
         return host.sponza_like(w["width"], w["height"], seed=1, detail=w.get("detail", 1.0))
+    if w["kind"] == "measured":
+        import importlib.util
+        import tempfile
+        spec = importlib.util.spec_from_file_location("make_rgl_fixture", os.path.join(ROOT, "tests", "golden", "make_rgl_fixture.py"))
+        fx = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(fx)
+        d = tempfile.mkdtemp(prefix="wpt_rgl_")
+        f0, f1 = os.path.join(d, "iso.bsdf"), os.path.join(d, "aniso.bsdf")
+        fx.make(f0, 21, 1, 8, 32, 64, 1)   # isotropic: 8 elevations, 32x32 warps, 64x64 NDF
+        fx.make(f1, 22, 8, 8, 32, 64, 1)   # anisotropic: 8 azimuths x 8 elevations
+        return host.measured_like(w["width"], w["height"], f0, f1, seed=3, detail=w.get("detail", 1.0))
     if w["kind"] == "courtyard":
         return host.courtyard_like(w["width"], w["height"], seed=2, triangles=w["triangles"])
     raise ValueError(w["kind"])

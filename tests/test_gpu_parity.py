@@ -352,3 +352,16 @@ def test_measured_brdf_scenes_bit_exact(dev, oracle, variant):
     assert gc == rc
     got2, _ = ds.render(4, params=p)  # the product kernel
     assert bits_equal(got2, ref)
+
+
+def test_measured_like_scene_bit_exact(dev, oracle):
+    """BASELINE config 5 stand-in at test size: MaterialRGL (isotropic and anisotropic files) with normal
+    maps beside textured Lambertian / ModPhong / two-sided materials, environment importance sampling."""
+    sc = host.measured_like(64, 36, host.rgl_fixture("iso"), host.rgl_fixture("aniso"), detail=0.05, tex_size=32, env_width=64, importance_n=16)
+    assert sc.d.rgl_count == 4
+    M, Ms, Mcs = oracle.envmap_tables(sc)
+    sc.set_envmap_tables(M, Ms, Mcs)
+    ref, rc = oracle.render(sc, 4)
+    got, gc = dev.DeviceScene(sc).render(4, with_counters=True)
+    assert np.isfinite(got).all() and got.sum() > 0
+    assert bits_equal(got, ref) and gc == rc

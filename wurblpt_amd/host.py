@@ -37,6 +37,8 @@ def lib():
         L.wpt_host_rgl_scene.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_uint, C.c_uint]
         L.wpt_host_rgl_build.restype = C.c_ulonglong
         L.wpt_host_rgl_build.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_ulonglong]
+        L.wpt_host_measured_like.restype = C.c_void_p
+        L.wpt_host_measured_like.argtypes = [C.c_uint, C.c_float, C.c_uint, C.c_uint, C.c_int, C.c_char_p, C.c_char_p, C.c_uint, C.c_uint]
         L.wpt_host_courtyard_like.restype = C.c_void_p
         L.wpt_host_courtyard_like.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
         L.wpt_host_scene_desc.restype = C.POINTER(_abi.SceneDesc)
@@ -160,6 +162,13 @@ def rgl_scene(width, height, variant=0, file0=None, file1=None):
     f1 = file1 or rgl_fixture("aniso")
     h = lib().wpt_host_rgl_scene(variant, f0.encode(), f1.encode(), width, height)
     return HostScene(h, width, height, "rgl_scene(variant=%d)" % variant)
+
+
+def measured_like(width, height, rgl0, rgl1, seed=3, detail=1.0, tex_size=1024, env_width=2048, importance_n=512):
+    """BASELINE config 5 stand-in: the Sponza-class architecture with measured BRDFs (MaterialRGL, two
+    tensor files) and normal maps on walls, columns, beams and vases; environment importance sampling."""
+    h = lib().wpt_host_measured_like(seed, detail, tex_size, env_width, importance_n, rgl0.encode(), rgl1.encode(), width, height)
+    return HostScene(h, width, height, "measured_like(seed=%d,detail=%g)" % (seed, detail))
 
 
 def bvh_build(boxes):

@@ -153,8 +153,8 @@ int scaled(float detail, int full, int least)
 
 }
 
-extern "C" wpt_host_scene* wpt_host_sponza_like(unsigned int seed, float detail, unsigned int texSize, unsigned int envWidth,
-        int importanceN, unsigned int width, unsigned int height)
+static wpt_host_scene* sponzaLike(unsigned int seed, float detail, unsigned int texSize, unsigned int envWidth,
+        int importanceN, unsigned int width, unsigned int height, const char* rgl0, const char* rgl1)
 {
     Scene* scenePtr = new Scene;
     Scene& scene = *scenePtr;
@@ -208,6 +208,19 @@ extern "C" wpt_host_scene* wpt_host_sponza_like(unsigned int seed, float detail,
     }
     Material* beamMat = scene.take(new MaterialModPhong(vec3(0.45f, 0.3f, 0.2f), vec3(0.1f), 30.0f), "wood");
     Material* vaseMat = scene.take(new MaterialGGX(vec3(0.95f, 0.75f, 0.4f), vec2(0.15f, 0.25f)), "brass");
+    Material* columnUse = columnMat;
+    Material* wallUse = wallMat;
+    if (rgl0 && rgl1) {
+        /* BASELINE config 5 flavour: measured BRDFs with normal maps on the large surfaces */
+        MaterialRGL* r0 = new MaterialRGL(rgl0);
+        r0->normalTex = wallNrm;
+        wallUse = scene.take(r0, "measured-wall");
+        MaterialRGL* r1 = new MaterialRGL(rgl1);
+        r1->normalTex = floorNrm;
+        columnUse = scene.take(r1, "measured-column");
+        beamMat = scene.take(new MaterialRGL(rgl0), "measured-beam");
+        vaseMat = scene.take(new MaterialRGL(rgl1), "measured-vase");
+    }
     Material* mirrorMat = scene.take(new MaterialMirror(vec3(0.9f)), "mirror");
 
     auto T = [&](const vec3& t, const vec3& s, const quat& r = quat::null()) { return objToWorld * Transformation(t, r, s); };
@@ -218,14 +231,14 @@ extern "C" wpt_host_scene* wpt_host_sponza_like(unsigned int seed, float detail,
     scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f), vec3(halfL, halfW, 1.0f), layFlat), scaled(detail, 270, 2))), floorMat));
     /* four walls */
     const int ws = scaled(detail, 64, 1);
-    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH * 0.5f, -halfW), vec3(halfL, wallH * 0.5f, 1.0f)), ws)), wallMat));
-    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH * 0.5f, halfW), vec3(halfL, wallH * 0.5f, 1.0f), toQuat(radians(180.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), wallMat));
-    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(-halfL, wallH * 0.5f, 0.0f), vec3(halfW, wallH * 0.5f, 1.0f), toQuat(radians(90.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), wallMat));
-    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(halfL, wallH * 0.5f, 0.0f), vec3(halfW, wallH * 0.5f, 1.0f), toQuat(radians(-90.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), wallMat));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH * 0.5f, -halfW), vec3(halfL, wallH * 0.5f, 1.0f)), ws)), wallUse));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH * 0.5f, halfW), vec3(halfL, wallH * 0.5f, 1.0f), toQuat(radians(180.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), wallUse));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(-halfL, wallH * 0.5f, 0.0f), vec3(halfW, wallH * 0.5f, 1.0f), toQuat(radians(90.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), wallUse));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(halfL, wallH * 0.5f, 0.0f), vec3(halfW, wallH * 0.5f, 1.0f), toQuat(radians(-90.0f), vec3(0.0f, 1.0f, 0.0f))), ws)), wallUse));
     /* a partial roof: two side strips, the middle is open to the sky */
     const quat faceDown = toQuat(radians(90.0f), vec3(1.0f, 0.0f, 0.0f));
-    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH, -halfW * 0.7f), vec3(halfL, halfW * 0.3f, 1.0f), faceDown), scaled(detail, 24, 1))), wallMat));
-    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH, halfW * 0.7f), vec3(halfL, halfW * 0.3f, 1.0f), faceDown), scaled(detail, 24, 1))), wallMat));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH, -halfW * 0.7f), vec3(halfL, halfW * 0.3f, 1.0f), faceDown), scaled(detail, 24, 1))), wallUse));
+    scene.take(new MeshInstance(scene.take(generateQuad(T(vec3(0.0f, wallH, halfW * 0.7f), vec3(halfL, halfW * 0.3f, 1.0f), faceDown), scaled(detail, 24, 1))), wallUse));
     /* two rows of columns with base and capital, beams on top */
     const int columns = 12;
     const int cylSlices = scaled(detail, 96, 6);
@@ -233,9 +246,9 @@ extern "C" wpt_host_scene* wpt_host_sponza_like(unsigned int seed, float detail,
         float z = (row == 0 ? -1.0f : 1.0f) * halfW * 0.45f;
         for (int i = 0; i < columns; i++) {
             float x = -halfL * 0.85f + i * (2.0f * halfL * 0.85f / (columns - 1));
-            scene.take(new MeshInstance(scene.take(generateClosedCylinder(T(vec3(x, 330.0f, z), vec3(42.0f, 300.0f, 42.0f)), cylSlices)), columnMat));
-            scene.take(new MeshInstance(scene.take(generateCube(T(vec3(x, 15.0f, z), vec3(60.0f, 15.0f, 60.0f)), scaled(detail, 4, 1))), columnMat));
-            scene.take(new MeshInstance(scene.take(generateCube(T(vec3(x, 645.0f, z), vec3(58.0f, 15.0f, 58.0f)), scaled(detail, 4, 1))), columnMat));
+            scene.take(new MeshInstance(scene.take(generateClosedCylinder(T(vec3(x, 330.0f, z), vec3(42.0f, 300.0f, 42.0f)), cylSlices)), columnUse));
+            scene.take(new MeshInstance(scene.take(generateCube(T(vec3(x, 15.0f, z), vec3(60.0f, 15.0f, 60.0f)), scaled(detail, 4, 1))), columnUse));
+            scene.take(new MeshInstance(scene.take(generateCube(T(vec3(x, 645.0f, z), vec3(58.0f, 15.0f, 58.0f)), scaled(detail, 4, 1))), columnUse));
         }
         scene.take(new MeshInstance(scene.take(generateCube(T(vec3(0.0f, 690.0f, z), vec3(halfL * 0.9f, 30.0f, 40.0f)), scaled(detail, 8, 1))), beamMat));
     }
@@ -263,6 +276,20 @@ extern "C" wpt_host_scene* wpt_host_sponza_like(unsigned int seed, float detail,
 
     /* camera of wurblpt-sponza.cpp:145-148 */
     return wptHostFinish(scenePtr, width, height, radians(70.0f), vec3(0.0f, 1.7f, 0.0f), vec3(0.0f, 1.7f, -1.0f), 0.0f, 1.0f);
+}
+
+extern "C" wpt_host_scene* wpt_host_sponza_like(unsigned int seed, float detail, unsigned int texSize, unsigned int envWidth,
+        int importanceN, unsigned int width, unsigned int height)
+{
+    return sponzaLike(seed, detail, texSize, envWidth, importanceN, width, height, nullptr, nullptr);
+}
+
+/* BASELINE config 5 stand-in ("Bistro-class": measured BRDFs + normal maps, environment importance
+ * sampling): the Sponza-class architecture with MaterialRGL on walls, columns, beams and vases */
+extern "C" wpt_host_scene* wpt_host_measured_like(unsigned int seed, float detail, unsigned int texSize, unsigned int envWidth,
+        int importanceN, const char* rgl0, const char* rgl1, unsigned int width, unsigned int height)
+{
+    return sponzaLike(seed, detail, texSize, envWidth, importanceN, width, height, rgl0, rgl1);
 }
 
 /* BASELINE config 4 stand-in ("San-Miguel-class", wurblpt-san-miguel.cpp:36-44,58-70): a
