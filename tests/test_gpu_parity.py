@@ -94,12 +94,13 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 0x20, 0x22, 0x10, 0x11, 0x12, 0x40, 0x41, 0x42])
+@pytest.mark.parametrize("variant", [0, 1, 2, 0x20, 0x22, 0x10, 0x11, 0x12, 0x40, 0x41, 0x42, 0x48, 0x4a])
 def test_kernel_variants_agree_bit_for_bit(dev, oracle, variant):
     """0 = scene in LDS, 1 = scene fetched from HBM/L2, 2 = the all-features kernel;
     +0x20 = separate SHADE / NEE-END / NEW rounds instead of the fused long round;
     +0x10 = the same three instantiations of the workgroup ray-pool kernel;
-    +0x40 = the same three of the kernel that keeps the pixel states in LDS"""
+    +0x40 = the same three of the kernel that keeps the pixel states in LDS;
+    0x48 / 0x4a = that kernel with the pixel states in global memory (scene in LDS / all features)"""
     sc = host.cornell(64, 48, 1, 2)
     ref, _ = oracle.render(sc, 5)
     dev.lib().wpt_set_launch_config(0, variant)

@@ -106,6 +106,8 @@ struct wpt_scene {
     uint32_t* pixelCounters; /* LDS-state kernel: one "next pixel" word per launch in flight (64 of them) */
     uint32_t launchSeq;
     int cuCount;
+    float4* wfState;       /* state-in-memory kernel: records of 4 launches in flight, allocated on first use */
+    size_t wfStateRecords; /* records per launch region */
     std::vector<float> envM, envMcs;
     std::vector<int32_t> envMs;
 };
@@ -449,6 +451,8 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
         s->status = const_cast<uint32_t*>(statusWord);
         s->pixelCounters = s->status + 1;
         s->launchSeq = 0;
+        s->wfState = nullptr;
+        s->wfStateRecords = 0;
         hipDeviceProp_t prop;
         s->cuCount = hipGetDeviceProperties(&prop, s->device) == hipSuccess ? prop.multiProcessorCount : 256;
     }
@@ -579,7 +583,7 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
      * one with work counters.  Variant bit 0x10 selects the workgroup ray-pool kernel
      * (wpt_pathtrace_pc.inc.h), kept as a measured experiment: same results, slower.
      * Low nibble: 1 = keep the scene in HBM, 2 = all features. */
-    const uint32_t force = g_variant & 0xfu;
+    const uint32_t force = g_variant & 0x7u;
     const bool singleRole = (g_variant & 0x10u) == 0 || (scene->features & FEAT_SPHERES) != 0;
     const bool basic = (need & ~FEAT_BASIC) == 0 && force != 2;
     const bool lds = smallScene && force != 1;
@@ -589,6 +593,8 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     args.travWaves = 8;
     args.heavyWaves = 4;
     args.pixelCounter = nullptr;
+    args.wfState = nullptr;
+    args.wfSlots = 0;
     const bool rgl = (need & FEAT_RGL) != 0; /* measured BRDFs have their own instantiation of the product kernel */
     if (count) {
         if (basic)
@@ -599,6 +605,41 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
             launchFullCount(args, grid, stream);
     } else if (rgl) {
         launchFullRgl(args, grid, stream);
+    } else if (ldsState && (g_variant & 0x08u)) {
+        /* variant bits 0x48: the same persistent kernel with the pixel states in global memory
+         * (byte 1 = traversal waves, byte 2 = heavy waves, byte 3 = slots per workgroup / 64) */
+        args.travWaves = g_leaveEighths ? g_leaveEighths : 6u;
+        args.heavyWaves = g_heavyMin ? g_heavyMin : 10u;
+        if (args.travWaves + args.heavyWaves > uint32_t(WF_WAVES))
+            return fail(WPT_ERR_INVALID_ARGUMENT, "more traversal + heavy waves than the workgroup has");
+        args.wfSlots = g_leafBias ? g_leafBias * 64u : 2048u;
+        if (args.wfSlots > uint32_t(WF_GRING))
+            args.wfSlots = WF_GRING;
+        args.leafBias = smallScene ? 16u : 32u;
+        args.heavyMin = 16;
+        args.patience = 8;
+        const uint32_t groups = (block_size + args.wfSlots - 1) / args.wfSlots;
+        dim3 wfGrid(groups < uint32_t(scene->cuCount) ? groups : uint32_t(scene->cuCount));
+        const size_t records = size_t(scene->cuCount) * WF_GRING;
+        if (!scene->wfState) {
+            void* p = nullptr;
+            hipError_t e = hipMalloc(&p, records * 4 * WF_GRECORD4 * sizeof(float4));
+            if (e != hipSuccess)
+                return fail(e == hipErrorOutOfMemory ? WPT_ERR_OUT_OF_MEMORY : WPT_ERR_HIP, std::string("hipMalloc for the pixel states: ") + hipGetErrorString(e));
+            scene->allocations.push_back(p);
+            scene->wfState = static_cast<float4*>(p);
+            scene->wfStateRecords = records;
+        }
+        args.pixelCounter = scene->pixelCounters + (scene->launchSeq & 63u);
+        args.wfState = scene->wfState + size_t(scene->launchSeq & 3u) * scene->wfStateRecords * WF_GRECORD4;
+        scene->launchSeq++;
+        HIP_TRY(hipMemsetAsync(args.pixelCounter, 0, sizeof(uint32_t), stream));
+        const bool wfLds = basic && force != 1 && ldsBytes <= WF_LDS_SCENE_MAX_BYTES;
+        const size_t bytes = wfgLdsBytes(wfLds ? uint32_t(ldsBytes) : 0u);
+        if (wfLds)
+            launchWfgBasicLds(args, wfGrid, bytes, stream);
+        else
+            launchWfgFull(args, wfGrid, bytes, stream);
     } else if (ldsState) {
         /* variant bit 0x40: pixel states in LDS, persistent workgroups (wpt_pathtrace_wf.inc.h);
          * byte 1 of the variant word, if set, is the number of traversal waves per workgroup */

@@ -66,6 +66,8 @@ struct KernelArgs {
     uint32_t travWaves;    /* LDS-state kernel: waves of a workgroup that hold traversal contexts */
     uint32_t heavyWaves;   /* LDS-state kernel: waves of a workgroup that run heavy batches */
     uint32_t* pixelCounter; /* LDS-state kernel: next unassigned pixel of the block (zero at launch) */
+    float4* wfState;        /* state-in-memory kernel: 12 float4 per slot, wfSlots slots per workgroup */
+    uint32_t wfSlots;
     float* frame;
     wpt_counters* counters;
     unsigned long long* schedStats; /* COUNT builds: 16 scheduler statistics, or NULL */

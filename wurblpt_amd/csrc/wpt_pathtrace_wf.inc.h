@@ -85,7 +85,7 @@ WPT_D uint32_t wfCount(uint32_t* head, uint32_t* tail)
 
 /* Appends the slots of the lanes with `posting` to a ring: one reservation per wave, then
  * every lane waits (bounded) until its entry has been reset by its previous consumer. */
-WPT_D void wfPush(uint32_t* ring, uint32_t* tail, uint32_t* abortFlag, bool posting, uint32_t slot, uint32_t lane)
+WPT_D void wfPush(uint32_t* ring, uint32_t* tail, uint32_t* abortFlag, bool posting, uint32_t slot, uint32_t lane, uint32_t ringMask = WF_RING - 1)
 {
     const unsigned long long mask = __ballot(posting);
     const uint32_t n = __popcll(mask);
@@ -97,7 +97,7 @@ WPT_D void wfPush(uint32_t* ring, uint32_t* tail, uint32_t* abortFlag, bool post
     base = __builtin_amdgcn_readfirstlane(base);
     if (posting) {
         const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-        uint32_t* entry = &ring[(base + rank) & (WF_RING - 1)];
+        uint32_t* entry = &ring[(base + rank) & ringMask];
         uint32_t spins = 0;
         while (wfLoad(entry) != WF_EMPTY) {
             if (++spins > WF_SPIN_LIMIT || wfLoad(abortFlag)) {
@@ -111,7 +111,7 @@ WPT_D void wfPush(uint32_t* ring, uint32_t* tail, uint32_t* abortFlag, bool post
 
 /* Claims up to `want` entries of a ring for the lanes with `taker` (in lane order).  Returns the
  * slot for a lane that got one, WF_EMPTY otherwise. */
-WPT_D uint32_t wfPop(uint32_t* ring, uint32_t* head, uint32_t* tail, uint32_t* abortFlag, bool taker, uint32_t want, uint32_t lane)
+WPT_D uint32_t wfPop(uint32_t* ring, uint32_t* head, uint32_t* tail, uint32_t* abortFlag, bool taker, uint32_t want, uint32_t lane, uint32_t ringMask = WF_RING - 1)
 {
     uint32_t base = 0, take = 0;
     if (lane == 0) {
@@ -136,7 +136,7 @@ WPT_D uint32_t wfPop(uint32_t* ring, uint32_t* head, uint32_t* tail, uint32_t* a
         const unsigned long long takers = __ballot(taker);
         const uint32_t rank = __popcll(takers & ((1ull << lane) - 1ull));
         if (taker && rank < take) {
-            uint32_t* entry = &ring[(base + rank) & (WF_RING - 1)];
+            uint32_t* entry = &ring[(base + rank) & ringMask];
             uint32_t s = wfLoad(entry);
             uint32_t spins = 0;
             while (s == WF_EMPTY) { /* reserved by its producer but not written yet */
@@ -155,9 +155,16 @@ WPT_D uint32_t wfPop(uint32_t* ring, uint32_t* head, uint32_t* tail, uint32_t* a
     return got;
 }
 
-template<uint32_t F, bool LDSSCENE>
+/* GSTATE: the pixel states live in global memory (one 192-byte record per slot, read and written
+ * with 16-byte accesses; args.wfState, args.wfSlots per workgroup) instead of LDS, so that a
+ * workgroup can hold several times more pixels than traversal contexts */
+constexpr int WF_GRING = 4096;      /* ring size with GSTATE = most slots a workgroup may have */
+constexpr int WF_GRECORD4 = 12;     /* float4 per slot record */
+
+template<uint32_t F, bool LDSSCENE, bool GSTATE = false>
 __global__ __launch_bounds__(WF_WG) void wpt_pathtrace_wf(const KernelArgs args)
 {
+    constexpr uint32_t RING = GSTATE ? (uint32_t)WF_GRING : (uint32_t)WF_RING;
     extern __shared__ float4 ldsRaw[];
 
     const SceneView& sv = args.sv;
@@ -171,20 +178,28 @@ __global__ __launch_bounds__(WF_WG) void wpt_pathtrace_wf(const KernelArgs args)
     const uint32_t scene4 = LDSSCENE ? 2 * nodeCount + 3 * sv.triCount : 0u;
     float4* ldsScene = ldsRaw;
     uint32_t* words = reinterpret_cast<uint32_t*>(ldsRaw + scene4);
-    uint32_t* state = words + WF_OFF_STATE;
-    uint32_t* ringT = words + WF_OFF_RING_T;
-    uint32_t* ringH = words + WF_OFF_RING_H;
-    uint32_t* ctl = words + WF_OFF_CTL;
+    uint32_t* state = words + WF_OFF_STATE;                      /* !GSTATE only */
+    uint32_t* ringT = words + (GSTATE ? 0u : WF_OFF_RING_T);
+    uint32_t* ringH = ringT + RING;
+    uint32_t* ctl = ringH + RING;
     uint32_t* abortFlag = ctl + WF_ABORT;
+    const uint32_t slots = GSTATE ? (args.wfSlots < 64u ? 64u : (args.wfSlots > RING ? RING : args.wfSlots)) : (uint32_t)WF_SLOTS;
+    float4* grec = GSTATE ? args.wfState + (size_t)blockIdx.x * slots * WF_GRECORD4 : nullptr;
 
-    for (uint32_t i = tid; i < WF_RING; i += WF_WG) {
+    for (uint32_t i = tid; i < RING; i += WF_WG) {
         ringT[i] = WF_EMPTY;
-        ringH[i] = i < WF_SLOTS ? i : WF_EMPTY; /* every slot starts in the HEAVY queue, asking for a pixel */
+        ringH[i] = i < slots ? i : WF_EMPTY; /* every slot starts in the HEAVY queue, asking for a pixel */
     }
-    for (uint32_t i = tid; i < WF_SLOTS; i += WF_WG)
-        state[WF_F_META * WF_SLOTS + i] = WF_META_INIT;
+    for (uint32_t i = tid; i < slots; i += WF_WG) {
+        if constexpr (GSTATE)
+            reinterpret_cast<uint32_t*>(grec + (size_t)i * WF_GRECORD4 + 1)[2] = WF_META_INIT;
+        else
+            state[WF_F_META * WF_SLOTS + i] = WF_META_INIT;
+    }
     if (tid < 16)
-        ctl[tid] = tid == WF_H_TAIL ? (uint32_t)WF_SLOTS : 0u;
+        ctl[tid] = tid == WF_H_TAIL ? slots : 0u;
+    if (GSTATE)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (LDSSCENE) {
         const uint32_t n4 = 2 * nodeCount, t4 = 3 * sv.triCount;
         for (uint32_t i = tid; i < n4; i += WF_WG)
@@ -251,16 +266,23 @@ __global__ __launch_bounds__(WF_WG) void wpt_pathtrace_wf(const KernelArgs args)
         if (nFin > 0 && (nFin >= 16 || nAct == 0)) {
             const bool fin = tst == T_FIN;
             if (fin) {
-                fld(WF_F_BEST + 0, tslot) = best.prim;
-                fldF(WF_F_BEST + 1, tslot) = best.a;
-                fldF(WF_F_BEST + 2, tslot) = best.invDet;
-                fldF(WF_F_BEST + 3, tslot) = best.U;
-                fldF(WF_F_BEST + 4, tslot) = best.V;
-                fldF(WF_F_BEST + 5, tslot) = best.W;
+                if constexpr (GSTATE) {
+                    /* record: q2 = prim a invDet U, q3.xy = V W */
+                    float4* rp = grec + (size_t)tslot * WF_GRECORD4;
+                    rp[2] = make_float4(__uint_as_float(best.prim), best.a, best.invDet, best.U);
+                    *reinterpret_cast<float2*>(rp + 3) = make_float2(best.V, best.W);
+                } else {
+                    fld(WF_F_BEST + 0, tslot) = best.prim;
+                    fldF(WF_F_BEST + 1, tslot) = best.a;
+                    fldF(WF_F_BEST + 2, tslot) = best.invDet;
+                    fldF(WF_F_BEST + 3, tslot) = best.U;
+                    fldF(WF_F_BEST + 4, tslot) = best.V;
+                    fldF(WF_F_BEST + 5, tslot) = best.W;
+                }
                 tst = T_IDLE;
             }
             wfRelease();
-            wfPush(ringH, ctl + WF_H_TAIL, abortFlag, fin, tslot, lane);
+            wfPush(ringH, ctl + WF_H_TAIL, abortFlag, fin, tslot, lane, RING - 1);
             if (lane == 0)
                 __hip_atomic_fetch_sub(ctl + WF_ACTIVE, (uint32_t)nFin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -278,7 +300,7 @@ __global__ __launch_bounds__(WF_WG) void wpt_pathtrace_wf(const KernelArgs args)
                 heavy = true;
         }
         if (heavy) {
-            const uint32_t s = wfPop(ringH, ctl + WF_H_HEAD, ctl + WF_H_TAIL, abortFlag, true, 64u, lane);
+            const uint32_t s = wfPop(ringH, ctl + WF_H_HEAD, ctl + WF_H_TAIL, abortFlag, true, 64u, lane, RING - 1);
             const bool mine = s != WF_EMPTY;
             if (__ballot(mine) == 0)
                 continue; /* another wave was faster */
@@ -298,36 +320,76 @@ __global__ __launch_bounds__(WF_WG) void wpt_pathtrace_wf(const KernelArgs args)
             res.prim = NO_HIT;
             res.a = res.invDet = res.U = res.V = res.W = 0.0f;
             if (mine) {
-                meta = fld(WF_F_META, s);
-                if (!(meta & WF_META_INIT)) {
-                    ps.prng.s0 = fld(WF_F_PRNG + 0, s);
-                    ps.prng.s1 = fld(WF_F_PRNG + 1, s);
-                    ps.prng.s2 = fld(WF_F_PRNG + 2, s);
-                    ps.prng.s3 = fld(WF_F_PRNG + 3, s);
-                    ps.acc0 = fldF(WF_F_ACC + 0, s);
-                    ps.acc1 = fldF(WF_F_ACC + 1, s);
-                    ps.acc2 = fldF(WF_F_ACC + 2, s);
-                    pixel = fld(WF_F_PIXEL, s);
-                    ps.px = pixel % args.width;
-                    ps.py = pixel / args.width;
-                    ps.sampleIndex = fld(WF_F_SAMPLE, s);
-                    ps.pathComponent = meta & 0xffffu;
-                    ps.rayKind = (int)((meta >> 16) & 3u);
-                    ps.ray.o = mk3(fldF(WF_F_ORG + 0, s), fldF(WF_F_ORG + 1, s), fldF(WF_F_ORG + 2, s));
-                    ps.ray.d = mk3(fldF(WF_F_DIR + 0, s), fldF(WF_F_DIR + 1, s), fldF(WF_F_DIR + 2, s));
-                    ps.ray.ri = mk4(fldF(WF_F_RI + 0, s), fldF(WF_F_RI + 1, s), fldF(WF_F_RI + 2, s), fldF(WF_F_RI + 3, s));
-                    ps.att = mk4(fldF(WF_F_ATT + 0, s), fldF(WF_F_ATT + 1, s), fldF(WF_F_ATT + 2, s), fldF(WF_F_ATT + 3, s));
-                    ps.opl = mk3(fldF(WF_F_OPL + 0, s), fldF(WF_F_OPL + 1, s), fldF(WF_F_OPL + 2, s));
-                    ps.nextAtt = mk4(fldF(WF_F_NEXTATT + 0, s), fldF(WF_F_NEXTATT + 1, s), fldF(WF_F_NEXTATT + 2, s), fldF(WF_F_NEXTATT + 3, s));
-                    ps.neeFactor = mk4(fldF(WF_F_NEEFACTOR + 0, s), fldF(WF_F_NEEFACTOR + 1, s), fldF(WF_F_NEEFACTOR + 2, s), fldF(WF_F_NEEFACTOR + 3, s));
-                    ps.srDir = mk3(fldF(WF_F_SRDIR + 0, s), fldF(WF_F_SRDIR + 1, s), fldF(WF_F_SRDIR + 2, s));
-                    ps.chosenPrim = fld(WF_F_CHOSEN, s);
-                    res.prim = fld(WF_F_BEST + 0, s);
-                    res.a = fldF(WF_F_BEST + 1, s);
-                    res.invDet = fldF(WF_F_BEST + 2, s);
-                    res.U = fldF(WF_F_BEST + 3, s);
-                    res.V = fldF(WF_F_BEST + 4, s);
-                    res.W = fldF(WF_F_BEST + 5, s);
+                if constexpr (GSTATE) {
+                    /* record layout (12 x float4): q0 org.xyz dir.x | q1 dir.yz meta pixel | q2 best.prim a invDet U |
+                     * q3 best.V W sample chosen | q4 prng | q5 acc | q6 ri | q7 att | q8 opl | q9 nextAtt | q10 neeFactor | q11 srDir */
+                    const float4* rp = grec + (size_t)s * WF_GRECORD4;
+                    const float4 q1 = rp[1];
+                    meta = __float_as_uint(q1.z);
+                    if (!(meta & WF_META_INIT)) {
+                        const float4 q0 = rp[0], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5], q6 = rp[6], q7 = rp[7], q8 = rp[8],
+                                     q9 = rp[9], q10 = rp[10], q11 = rp[11];
+                        ps.ray.o = mk3(q0.x, q0.y, q0.z);
+                        ps.ray.d = mk3(q0.w, q1.x, q1.y);
+                        pixel = __float_as_uint(q1.w);
+                        ps.px = pixel % args.width;
+                        ps.py = pixel / args.width;
+                        ps.pathComponent = meta & 0xffffu;
+                        ps.rayKind = (int)((meta >> 16) & 3u);
+                        res.prim = __float_as_uint(q2.x);
+                        res.a = q2.y;
+                        res.invDet = q2.z;
+                        res.U = q2.w;
+                        res.V = q3.x;
+                        res.W = q3.y;
+                        ps.sampleIndex = __float_as_uint(q3.z);
+                        ps.chosenPrim = __float_as_uint(q3.w);
+                        ps.prng.s0 = __float_as_uint(q4.x);
+                        ps.prng.s1 = __float_as_uint(q4.y);
+                        ps.prng.s2 = __float_as_uint(q4.z);
+                        ps.prng.s3 = __float_as_uint(q4.w);
+                        ps.acc0 = q5.x;
+                        ps.acc1 = q5.y;
+                        ps.acc2 = q5.z;
+                        ps.ray.ri = mk4(q6.x, q6.y, q6.z, q6.w);
+                        ps.att = mk4(q7.x, q7.y, q7.z, q7.w);
+                        ps.opl = mk3(q8.x, q8.y, q8.z);
+                        ps.nextAtt = mk4(q9.x, q9.y, q9.z, q9.w);
+                        ps.neeFactor = mk4(q10.x, q10.y, q10.z, q10.w);
+                        ps.srDir = mk3(q11.x, q11.y, q11.z);
+                    }
+                } else {
+                    meta = fld(WF_F_META, s);
+                    if (!(meta & WF_META_INIT)) {
+                        ps.prng.s0 = fld(WF_F_PRNG + 0, s);
+                        ps.prng.s1 = fld(WF_F_PRNG + 1, s);
+                        ps.prng.s2 = fld(WF_F_PRNG + 2, s);
+                        ps.prng.s3 = fld(WF_F_PRNG + 3, s);
+                        ps.acc0 = fldF(WF_F_ACC + 0, s);
+                        ps.acc1 = fldF(WF_F_ACC + 1, s);
+                        ps.acc2 = fldF(WF_F_ACC + 2, s);
+                        pixel = fld(WF_F_PIXEL, s);
+                        ps.px = pixel % args.width;
+                        ps.py = pixel / args.width;
+                        ps.sampleIndex = fld(WF_F_SAMPLE, s);
+                        ps.pathComponent = meta & 0xffffu;
+                        ps.rayKind = (int)((meta >> 16) & 3u);
+                        ps.ray.o = mk3(fldF(WF_F_ORG + 0, s), fldF(WF_F_ORG + 1, s), fldF(WF_F_ORG + 2, s));
+                        ps.ray.d = mk3(fldF(WF_F_DIR + 0, s), fldF(WF_F_DIR + 1, s), fldF(WF_F_DIR + 2, s));
+                        ps.ray.ri = mk4(fldF(WF_F_RI + 0, s), fldF(WF_F_RI + 1, s), fldF(WF_F_RI + 2, s), fldF(WF_F_RI + 3, s));
+                        ps.att = mk4(fldF(WF_F_ATT + 0, s), fldF(WF_F_ATT + 1, s), fldF(WF_F_ATT + 2, s), fldF(WF_F_ATT + 3, s));
+                        ps.opl = mk3(fldF(WF_F_OPL + 0, s), fldF(WF_F_OPL + 1, s), fldF(WF_F_OPL + 2, s));
+                        ps.nextAtt = mk4(fldF(WF_F_NEXTATT + 0, s), fldF(WF_F_NEXTATT + 1, s), fldF(WF_F_NEXTATT + 2, s), fldF(WF_F_NEXTATT + 3, s));
+                        ps.neeFactor = mk4(fldF(WF_F_NEEFACTOR + 0, s), fldF(WF_F_NEEFACTOR + 1, s), fldF(WF_F_NEEFACTOR + 2, s), fldF(WF_F_NEEFACTOR + 3, s));
+                        ps.srDir = mk3(fldF(WF_F_SRDIR + 0, s), fldF(WF_F_SRDIR + 1, s), fldF(WF_F_SRDIR + 2, s));
+                        ps.chosenPrim = fld(WF_F_CHOSEN, s);
+                        res.prim = fld(WF_F_BEST + 0, s);
+                        res.a = fldF(WF_F_BEST + 1, s);
+                        res.invDet = fldF(WF_F_BEST + 2, s);
+                        res.U = fldF(WF_F_BEST + 3, s);
+                        res.V = fldF(WF_F_BEST + 4, s);
+                        res.W = fldF(WF_F_BEST + 5, s);
+                    }
                 }
             }
             const bool init = mine && (meta & WF_META_INIT) != 0;
@@ -391,63 +453,88 @@ __global__ __launch_bounds__(WF_WG) void wpt_pathtrace_wf(const KernelArgs args)
             }
             const bool posting = mine && !dead && next == NEXT_TRACE;
             if (posting) {
-                fld(WF_F_PRNG + 0, s) = ps.prng.s0;
-                fld(WF_F_PRNG + 1, s) = ps.prng.s1;
-                fld(WF_F_PRNG + 2, s) = ps.prng.s2;
-                fld(WF_F_PRNG + 3, s) = ps.prng.s3;
-                fldF(WF_F_ACC + 0, s) = ps.acc0;
-                fldF(WF_F_ACC + 1, s) = ps.acc1;
-                fldF(WF_F_ACC + 2, s) = ps.acc2;
-                fld(WF_F_PIXEL, s) = pixel;
-                fld(WF_F_SAMPLE, s) = ps.sampleIndex;
-                fld(WF_F_META, s) = (ps.pathComponent & 0xffffu) | ((uint32_t)ps.rayKind << 16);
-                fldF(WF_F_ORG + 0, s) = ps.ray.o.x;
-                fldF(WF_F_ORG + 1, s) = ps.ray.o.y;
-                fldF(WF_F_ORG + 2, s) = ps.ray.o.z;
-                fldF(WF_F_DIR + 0, s) = ps.ray.d.x;
-                fldF(WF_F_DIR + 1, s) = ps.ray.d.y;
-                fldF(WF_F_DIR + 2, s) = ps.ray.d.z;
-                fldF(WF_F_RI + 0, s) = ps.ray.ri.x;
-                fldF(WF_F_RI + 1, s) = ps.ray.ri.y;
-                fldF(WF_F_RI + 2, s) = ps.ray.ri.z;
-                fldF(WF_F_RI + 3, s) = ps.ray.ri.w;
-                fldF(WF_F_ATT + 0, s) = ps.att.x;
-                fldF(WF_F_ATT + 1, s) = ps.att.y;
-                fldF(WF_F_ATT + 2, s) = ps.att.z;
-                fldF(WF_F_ATT + 3, s) = ps.att.w;
-                fldF(WF_F_OPL + 0, s) = ps.opl.x;
-                fldF(WF_F_OPL + 1, s) = ps.opl.y;
-                fldF(WF_F_OPL + 2, s) = ps.opl.z;
-                fldF(WF_F_NEXTATT + 0, s) = ps.nextAtt.x;
-                fldF(WF_F_NEXTATT + 1, s) = ps.nextAtt.y;
-                fldF(WF_F_NEXTATT + 2, s) = ps.nextAtt.z;
-                fldF(WF_F_NEXTATT + 3, s) = ps.nextAtt.w;
-                fldF(WF_F_NEEFACTOR + 0, s) = ps.neeFactor.x;
-                fldF(WF_F_NEEFACTOR + 1, s) = ps.neeFactor.y;
-                fldF(WF_F_NEEFACTOR + 2, s) = ps.neeFactor.z;
-                fldF(WF_F_NEEFACTOR + 3, s) = ps.neeFactor.w;
-                fldF(WF_F_SRDIR + 0, s) = ps.srDir.x;
-                fldF(WF_F_SRDIR + 1, s) = ps.srDir.y;
-                fldF(WF_F_SRDIR + 2, s) = ps.srDir.z;
-                fld(WF_F_CHOSEN, s) = ps.chosenPrim;
+                if constexpr (GSTATE) {
+                    float4* rp = grec + (size_t)s * WF_GRECORD4;
+                    const uint32_t newMeta = (ps.pathComponent & 0xffffu) | ((uint32_t)ps.rayKind << 16);
+                    rp[0] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.d.x);
+                    rp[1] = make_float4(ps.ray.d.y, ps.ray.d.z, __uint_as_float(newMeta), __uint_as_float(pixel));
+                    /* q2 and q3.xy are the traversal's to write */
+                    reinterpret_cast<float2*>(rp + 3)[1] = make_float2(__uint_as_float(ps.sampleIndex), __uint_as_float(ps.chosenPrim));
+                    rp[4] = make_float4(__uint_as_float(ps.prng.s0), __uint_as_float(ps.prng.s1), __uint_as_float(ps.prng.s2), __uint_as_float(ps.prng.s3));
+                    rp[5] = make_float4(ps.acc0, ps.acc1, ps.acc2, 0.0f);
+                    rp[6] = make_float4(ps.ray.ri.x, ps.ray.ri.y, ps.ray.ri.z, ps.ray.ri.w);
+                    rp[7] = make_float4(ps.att.x, ps.att.y, ps.att.z, ps.att.w);
+                    rp[8] = make_float4(ps.opl.x, ps.opl.y, ps.opl.z, 0.0f);
+                    rp[9] = make_float4(ps.nextAtt.x, ps.nextAtt.y, ps.nextAtt.z, ps.nextAtt.w);
+                    rp[10] = make_float4(ps.neeFactor.x, ps.neeFactor.y, ps.neeFactor.z, ps.neeFactor.w);
+                    rp[11] = make_float4(ps.srDir.x, ps.srDir.y, ps.srDir.z, 0.0f);
+                } else {
+                    fld(WF_F_PRNG + 0, s) = ps.prng.s0;
+                    fld(WF_F_PRNG + 1, s) = ps.prng.s1;
+                    fld(WF_F_PRNG + 2, s) = ps.prng.s2;
+                    fld(WF_F_PRNG + 3, s) = ps.prng.s3;
+                    fldF(WF_F_ACC + 0, s) = ps.acc0;
+                    fldF(WF_F_ACC + 1, s) = ps.acc1;
+                    fldF(WF_F_ACC + 2, s) = ps.acc2;
+                    fld(WF_F_PIXEL, s) = pixel;
+                    fld(WF_F_SAMPLE, s) = ps.sampleIndex;
+                    fld(WF_F_META, s) = (ps.pathComponent & 0xffffu) | ((uint32_t)ps.rayKind << 16);
+                    fldF(WF_F_ORG + 0, s) = ps.ray.o.x;
+                    fldF(WF_F_ORG + 1, s) = ps.ray.o.y;
+                    fldF(WF_F_ORG + 2, s) = ps.ray.o.z;
+                    fldF(WF_F_DIR + 0, s) = ps.ray.d.x;
+                    fldF(WF_F_DIR + 1, s) = ps.ray.d.y;
+                    fldF(WF_F_DIR + 2, s) = ps.ray.d.z;
+                    fldF(WF_F_RI + 0, s) = ps.ray.ri.x;
+                    fldF(WF_F_RI + 1, s) = ps.ray.ri.y;
+                    fldF(WF_F_RI + 2, s) = ps.ray.ri.z;
+                    fldF(WF_F_RI + 3, s) = ps.ray.ri.w;
+                    fldF(WF_F_ATT + 0, s) = ps.att.x;
+                    fldF(WF_F_ATT + 1, s) = ps.att.y;
+                    fldF(WF_F_ATT + 2, s) = ps.att.z;
+                    fldF(WF_F_ATT + 3, s) = ps.att.w;
+                    fldF(WF_F_OPL + 0, s) = ps.opl.x;
+                    fldF(WF_F_OPL + 1, s) = ps.opl.y;
+                    fldF(WF_F_OPL + 2, s) = ps.opl.z;
+                    fldF(WF_F_NEXTATT + 0, s) = ps.nextAtt.x;
+                    fldF(WF_F_NEXTATT + 1, s) = ps.nextAtt.y;
+                    fldF(WF_F_NEXTATT + 2, s) = ps.nextAtt.z;
+                    fldF(WF_F_NEXTATT + 3, s) = ps.nextAtt.w;
+                    fldF(WF_F_NEEFACTOR + 0, s) = ps.neeFactor.x;
+                    fldF(WF_F_NEEFACTOR + 1, s) = ps.neeFactor.y;
+                    fldF(WF_F_NEEFACTOR + 2, s) = ps.neeFactor.z;
+                    fldF(WF_F_NEEFACTOR + 3, s) = ps.neeFactor.w;
+                    fldF(WF_F_SRDIR + 0, s) = ps.srDir.x;
+                    fldF(WF_F_SRDIR + 1, s) = ps.srDir.y;
+                    fldF(WF_F_SRDIR + 2, s) = ps.srDir.z;
+                    fld(WF_F_CHOSEN, s) = ps.chosenPrim;
+                }
             }
             wfRelease();
-            wfPush(ringT, ctl + WF_T_TAIL, abortFlag, posting, s, lane);
+            wfPush(ringT, ctl + WF_T_TAIL, abortFlag, posting, s, lane, RING - 1);
             continue;
         }
 
         /* ---- traversal: refill idle contexts, a quarter of the wave at a time ---- */
         if (travWave && tr > 0u && (nAct == 0 || 64 - nAct >= 16)) {
             const bool idle = tst == T_IDLE;
-            const uint32_t s = wfPop(ringT, ctl + WF_T_HEAD, ctl + WF_T_TAIL, abortFlag, idle, (uint32_t)__popcll(__ballot(idle)), lane);
+            const uint32_t s = wfPop(ringT, ctl + WF_T_HEAD, ctl + WF_T_TAIL, abortFlag, idle, (uint32_t)__popcll(__ballot(idle)), lane, RING - 1);
             const uint32_t nGot = __popcll(__ballot(s != WF_EMPTY));
             if (nGot > 0 && lane == 0)
                 __hip_atomic_fetch_add(ctl + WF_ACTIVE, nGot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (s != WF_EMPTY) {
                 wfAcquire();
                 tslot = s;
-                org = mk3(fldF(WF_F_ORG + 0, s), fldF(WF_F_ORG + 1, s), fldF(WF_F_ORG + 2, s));
-                aux = rayAux(mk3(fldF(WF_F_DIR + 0, s), fldF(WF_F_DIR + 1, s), fldF(WF_F_DIR + 2, s)));
+                if constexpr (GSTATE) {
+                    const float4* rp = grec + (size_t)s * WF_GRECORD4;
+                    const float4 q0 = rp[0];
+                    const float2 q1 = *reinterpret_cast<const float2*>(rp + 1);
+                    org = mk3(q0.x, q0.y, q0.z);
+                    aux = rayAux(mk3(q0.w, q1.x, q1.y));
+                } else {
+                    org = mk3(fldF(WF_F_ORG + 0, s), fldF(WF_F_ORG + 1, s), fldF(WF_F_ORG + 2, s));
+                    aux = rayAux(mk3(fldF(WF_F_DIR + 0, s), fldF(WF_F_DIR + 1, s), fldF(WF_F_DIR + 2, s)));
+                }
                 node = 0;
                 amax = k_maxval;
                 best.prim = NO_HIT;
@@ -457,7 +544,7 @@ __global__ __launch_bounds__(WF_WG) void wpt_pathtrace_wf(const KernelArgs args)
         const int nWalk = __popcll(__ballot(tst == T_NODE || tst == T_LEAF));
         if (nWalk == 0) {
             /* nothing to traverse and no batch worth taking */
-            if (wfLoad(ctl + WF_DONE_SLOTS) >= (uint32_t)WF_SLOTS)
+            if (wfLoad(ctl + WF_DONE_SLOTS) >= slots)
                 break;
             __builtin_amdgcn_s_sleep(8);
             patience++;
@@ -530,6 +617,10 @@ __global__ __launch_bounds__(WF_WG) void wpt_pathtrace_wf(const KernelArgs args)
 void launchWfBasicLds(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream);
 void launchWfBasic(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream);
 void launchWfFull(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream);
+void launchWfgBasicLds(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream);
+void launchWfgFull(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream);
+
+inline size_t wfgLdsBytes(uint32_t sceneBytes) { return size_t(sceneBytes) + size_t(2 * WF_GRING + 16) * 4; }
 
 } /* namespace wptk */
 
