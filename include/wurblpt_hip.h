@@ -313,11 +313,13 @@ wpt_status wpt_scene_check(wpt_scene* scene);
 /* Kernel launch geometry knobs (0 = default); for benchmarking only, results do not change. */
 wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant);
 
-/* Profiling hook: `stats_device` (device pointer to 16 uint64, or NULL to switch off) receives
+/* Profiling hook: `stats_device` (device pointer to 24 uint64, or NULL to switch off) receives
  * the wave scheduler's statistics of launches that also count work (counters_device != NULL):
  * [0] NODE rounds [1] NODE loop iterations [2] sum of lanes active in them, then (rounds, lanes)
  * for LEAF [3,4], SHADE [5,6], NEE-END [7,8], NEW [9,10]; shader-clock ticks a wave spent in
- * traversal [11], SHADE [12], NEE-END [13], NEW [14]; [15] unused. */
+ * traversal [11], SHADE [12], NEE-END [13], NEW [14]; [15] unused; [16..23] shader-clock ticks summed
+ * over lanes per section of the SHADE block (hit record, scatter, emission, light pdf 1, light sample,
+ * light pdf 2, evaluation towards the light, environment sampling / continuation). */
 wpt_status wpt_set_scheduler_stats(unsigned long long* stats_device);
 
 /* Name of the GPU kernel that wpt_render_block_device launches (for profile matching). */

@@ -12,7 +12,7 @@ if var:
     device.lib().wpt_set_launch_config(0, var)
 sc = host.sponza_like(1920, 1080) if (len(sys.argv) > 2 and sys.argv[2] == "sponza") else host.cornell(1024, 1024, 1, 2)
 ds = device.DeviceScene(sc)
-stats = torch.zeros(16, dtype=torch.int64, device="cuda")
+stats = torch.zeros(24, dtype=torch.int64, device="cuda")
 device.lib().wpt_set_scheduler_stats.argtypes = [C.c_void_p]
 device.lib().wpt_set_scheduler_stats(C.c_void_p(stats.data_ptr()))
 spp_sqrt = 2 if len(sys.argv) > 2 else 4
@@ -38,3 +38,9 @@ if sum(s[11:15]) > 0:
         100 * s[11] / tot, 100 * s[12] / tot, 100 * s[13] / tot, 100 * s[14] / tot, tot * 64 / n))
     print("ticks per round: node-iter %.0f (incl. leaf iters)  shade %.0f  nee-end %.0f  new %.0f" % (
         s[11] / max(1, s[1] + s[3]), s[12] / max(1, s[5]), s[13] / max(1, s[7]), s[14] / max(1, s[9])))
+if sum(s[16:24]) > 0:
+    tot = float(sum(s[16:24]))
+    names = ["hit record + material", "scatter", "emission", "light pdf (scattered dir)", "light sample", "light pdf (light dir)", "evaluation towards light", "env sampling / continuation"]
+    print("SHADE block, lane-weighted clock per section:")
+    for k, nm in enumerate(names):
+        print("  %-28s %5.1f%%" % (nm, 100 * s[16 + k] / tot))

@@ -27,6 +27,11 @@ enum { NEXT_TRACE = 0, NEXT_NEW = 1, NEXT_DONE = 2 };
 
 struct LaneCounters {
     uint32_t rays, nodes, leaves, pdfs, scatters;
+    /* COUNT builds: shader clock this lane spent in the sections of blockShade (profiling only):
+     * [0] hit record + material, [1] scatter, [2] emission, [3] light pdf of the scattered direction,
+     * [4] light sample, [5] light pdf of the light direction, [6] evaluation towards the light,
+     * [7] environment sampling / continuation */
+    unsigned long long shadeClock[8];
 };
 
 /* everything a pixel's path carries between blocks (registers) */
@@ -232,15 +237,28 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
     ps.opl = add(ps.opl, scl(best.a, mk3(ps.ray.ri.x, ps.ray.ri.y, ps.ray.ri.z)));
     if (!(ps.pathComponent + 1 < par.max_path_components))
         return NEXT_NEW;
+    long long tSection = 0;
+    auto section = [&](int k) { /* COUNT builds: close section k */
+        if (COUNT) {
+            const long long now = clock64();
+            lc.shadeClock[k] += (unsigned long long)(now - tSection);
+            tSection = now;
+        }
+    };
+    if (COUNT)
+        tSection = clock64();
     Hit h = finishHit<F>(sv, best, ps.ray.o, ps.ray.d);
     const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
     if (COUNT)
         lc.scatters++;
+    section(0);
     const Scatter sr = materialScatter<F>(sv, m, ps.ray, h, ps.prng);
+    section(1);
     {
         f4 rad = mul(ps.att, materialEmitted<F>(sv, m, h));
         accumulateRadiance(par, ps.opl, (ps.pathComponent == 0 ? 0.0f : h.a), rad, ps);
     }
+    section(2);
     if (sr.type == SCATTER_NONE)
         return NEXT_NEW;
     ps.nextAtt = mul(ps.att, sr.att);
@@ -255,6 +273,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
         /* light sampling with MIS (wurblpt.hpp:179-220) */
         const float hotSpotsPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, sr.dir, lc);
         ps.nextAtt = sclr(ps.nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
+        section(3);
         uint32_t idx = (uint32_t)(in01(ps.prng) * (float)sv.hotspotCount);
         idx = idx < sv.hotspotCount - 1 ? idx : sv.hotspotCount - 1;
         const wpt_hotspot& hs = sv.hotspots[idx];
@@ -271,7 +290,9 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
                 p = mat4mulPoint(hs.M, p);
             directDir = normalize(sub(p, h.p));
         }
+        section(4);
         const float directPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, directDir, lc);
+        section(5);
         if (directPdf > 0.0f) {
             float dpdf;
             f4 directAtt;
@@ -282,6 +303,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
                 ps.ray.o = h.p;
                 ps.ray.d = directDir;
                 ps.rayKind = RAY_NEE_LIGHT;
+                section(6);
                 return NEXT_TRACE;
             }
         }
@@ -299,6 +321,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
             ps.ray.o = h.p;
             ps.ray.d = lightDir;
             ps.rayKind = RAY_NEE_ENV;
+            section(7);
             return NEXT_TRACE;
         }
     }
@@ -308,7 +331,9 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
      * value to continue with; only explicit scattering (glass, transparent ModPhong) changes it. */
     ps.ray.o = h.p;
     ps.ray.ri = sr.ri;
-    return advancePath(par, ps);
+    const int next = advancePath(par, ps);
+    section(7);
+    return next;
 }
 
 /* the next-event ray's result (wurblpt.hpp:208-218: only the CHOSEN hot spot as nearest hit

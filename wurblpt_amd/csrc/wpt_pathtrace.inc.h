@@ -133,7 +133,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     /* ---- per-lane state: the pixel's path (wpt_blocks.h) and the traversal registers ---- */
     PathState ps;
     pathStateInit(ps, pixel, args.width);
-    LaneCounters lc = { 0, 0, 0, 0, 0 };
+    LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
     /* wave-level scheduler statistics (COUNT builds): rounds and lane counts per state */
     unsigned long long sched[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int state = inBlock ? S_NEW : S_DONE;
@@ -385,6 +385,10 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     if (COUNT && args.schedStats && (threadIdx.x & 63) == 0) {
         for (int i = 0; i < 16; i++)
             atomicAdd(args.schedStats + i, sched[i]);
+    }
+    if (COUNT && args.schedStats && inBlock) { /* [16..23]: lane-weighted clock per section of the SHADE block */
+        for (int i = 0; i < 8; i++)
+            atomicAdd(args.schedStats + 16 + i, lc.shadeClock[i]);
     }
 }
 

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(PC_WG, 3) void wpt_pathtrace_pc(const KernelArgs ar
     fa.samplesSqrt = args.samplesSqrt;
     PathState ps;
     pathStateInit(ps, pixel, args.width);
-    LaneCounters lc = { 0, 0, 0, 0, 0 };
+    LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
     enum { O_NEW = 0, O_WAIT = 1, O_READY = 2, O_DONE = 3 };
     int ost = inBlock ? O_NEW : O_DONE;
 

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(WF_WG) void wpt_pathtrace_wf(const KernelArgs args)
     if (wave >= travWaves + heavyWaves)
         return;
     const uint32_t capacity = travWaves * 64u;
-    LaneCounters lc = { 0, 0, 0, 0, 0 };
+    LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
 
     /* ---- traversal contexts (waves below travWaves) ---- */
     enum { T_IDLE = 0, T_NODE = 1, T_LEAF = 2, T_FIN = 3 };
