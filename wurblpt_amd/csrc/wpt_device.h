@@ -1082,8 +1082,14 @@ template<uint32_t F> WPT_D Scatter materialScatter(const SceneView& sv, const wp
             ourRI = theirRI;
             theirRI = tmp;
             float dist = h.a;
-            f4 e = mk4(wptm::expf_(-m.v[0][0] * dist), wptm::expf_(-m.v[0][1] * dist), wptm::expf_(-m.v[0][2] * dist),
-                    wptm::expf_(-m.v[0][3] * dist));
+            /* exp(-absorption * dist) per channel; channels with equal absorption (the usual grey glass)
+             * share one evaluation: same argument, same value */
+            const float a0 = m.v[0][0], a1 = m.v[0][1], a2 = m.v[0][2], a3 = m.v[0][3];
+            f4 e;
+            e.x = wptm::expf_(-a0 * dist);
+            e.y = a1 == a0 ? e.x : wptm::expf_(-a1 * dist);
+            e.z = a2 == a0 ? e.x : (a2 == a1 ? e.y : wptm::expf_(-a2 * dist));
+            e.w = a3 == a0 ? e.x : (a3 == a1 ? e.y : (a3 == a2 ? e.z : wptm::expf_(-a3 * dist)));
             att = mul(att, e);
         }
         f3 n = normalAt<F>(sv, m, h);
