@@ -508,6 +508,28 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
         UP(uploadArray(s, s->envM.data(), bins, &s->view.envM));
         UP(uploadArray(s, s->envMs.data(), bins, &s->view.envMs));
         UP(uploadArray(s, s->envMcs.data(), bins, &s->view.envMcs));
+        {
+            /* start table for the sampling search (envD in wpt_device.h); only for a non-decreasing
+             * cumulative table, which is what the construction gives -- a caller's own table that is
+             * not gets the plain bisection */
+            bool monotone = true;
+            for (size_t i = 1; i < bins && monotone; i++)
+                monotone = !(s->envMcs[i] < s->envMcs[i - 1]);
+            if (monotone) {
+                const uint32_t K = 65536;
+                std::vector<int32_t> lut(K + 1);
+                size_t i = 0;
+                for (uint32_t k = 0; k < K; k++) {
+                    const float t = float(k) / float(K);
+                    while (i < bins && s->envMcs[i] < t)
+                        i++;
+                    lut[k] = int32_t(i < bins ? i : bins - 1);
+                }
+                lut[K] = int32_t(bins - 1);
+                UP(uploadArray(s, lut.data(), lut.size(), &s->view.envLut));
+                s->view.envLutSize = K;
+            }
+        }
         s->view.envN = N;
     }
 #undef UP

@@ -451,6 +451,8 @@ struct SceneView {
     uint32_t envType, envCompat;
     int32_t envTex, envN;
     int32_t envCube[6]; /* WPT_ENV_CUBE: textures +x -x +y -y +z -z */
+    const int32_t* envLut; /* envLutSize + 1 entries: first bin whose cumulative importance reaches k / envLutSize, or NULL */
+    uint32_t envLutSize;   /* a power of two */
     uint32_t sphereCount;
 };
 
@@ -775,16 +777,34 @@ WPT_D f3 envD(const SceneView& sv, Prng& prng)
 {
     const int N = sv.envN;
     float r = in01(prng);
-    int a = 0;
-    int b = N * N - 1;
-    while (b > a + 1) {
-        int c = (a + b) / 2;
-        if (sv.envMcs[c] < r)
-            a = c;
-        else
-            b = c;
+    int bin;
+    if (sv.envLut) {
+        /* The reference's bisection over all N*N cumulative values (envmap.hpp:171-183) ends at the first
+         * bin whose cumulative importance is >= r (the last bin if there is none).  The table is
+         * non-decreasing, so that bin lies between the answers for k/K and (k+1)/K with k = floor(r*K),
+         * which are tabulated: 2-3 dependent loads instead of 2*log2(N). */
+        const uint32_t k = (uint32_t)(r * (float)sv.envLutSize);
+        int lo = sv.envLut[k], hi = sv.envLut[k + 1];
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sv.envMcs[mid] < r)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        bin = lo;
+    } else {
+        int a = 0;
+        int b = N * N - 1;
+        while (b > a + 1) {
+            int c = (a + b) / 2;
+            if (sv.envMcs[c] < r)
+                a = c;
+            else
+                b = c;
+        }
+        bin = (sv.envMcs[a] >= r ? a : b);
     }
-    int bin = (sv.envMcs[a] >= r ? a : b);
     bin = sv.envMs[bin];
     int x = bin % N;
     int y = bin / N;
