@@ -366,3 +366,38 @@ def test_measured_like_scene_bit_exact(dev, oracle):
     got, gc = dev.DeviceScene(sc).render(4, with_counters=True)
     assert np.isfinite(got).all() and got.sum() > 0
     assert bits_equal(got, ref) and gc == rc
+
+
+def test_full_size_config_2_rows_bit_exact(dev, oracle):
+    """BASELINE config 2 at its full size (1024 x 1024 x 1024 spp, one launch): pixels are seeded by
+    their index, so the CPU restatement can render any rows of the same frame exactly -- four rows
+    spread over the image (4 M samples) must agree bit for bit with the frame of the GPU."""
+    w = h = 1024
+    s = 32
+    sc = host.cornell(w, h, 1, 2)
+    got, _ = dev.DeviceScene(sc).render(s)
+    assert np.isfinite(got).all()
+    for row in (0, 317, 640, 1023):
+        ref, _ = oracle.render(sc, s, block=(row * w, w))
+        assert bits_equal(got[row], ref[row]), "row %d" % row
+
+
+def test_full_size_config_3_rows_bit_exact(dev, oracle):
+    """BASELINE config 3 stand-in at its full size (268 k triangles, 1920 x 1080 x 256 spp, environment
+    importance sampling with N = 512): two rows of the frame against the CPU restatement, bit for bit;
+    the importance tables the device builds at upload are the oracle's."""
+    import ctypes as C
+    w, h, s = 1920, 1080, 16
+    sc = host.sponza_like(w, h)
+    ds = dev.DeviceScene(sc)
+    n2 = 512 * 512
+    M = np.zeros(n2, np.float32); Ms = np.zeros(n2, np.int32); Mcs = np.zeros(n2, np.float32)
+    assert dev.lib().wpt_scene_get_envmap_tables(ds._handle, C.c_void_p(M.ctypes.data), C.c_void_p(Ms.ctypes.data), C.c_void_p(Mcs.ctypes.data)) == 0
+    oM, oMs, oMcs = oracle.envmap_tables(sc)
+    assert bits_equal(M, oM) and np.array_equal(Ms, oMs) and bits_equal(Mcs, oMcs)
+    sc.set_envmap_tables(oM, oMs, oMcs)
+    got, _ = ds.render(s)
+    assert np.isfinite(got).all()
+    for row in (200, 871):
+        ref, _ = oracle.render(sc, s, block=(row * w, w))
+        assert bits_equal(got[row], ref[row]), "row %d" % row
