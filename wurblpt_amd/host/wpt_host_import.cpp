@@ -1,0 +1,101 @@
+/*
+ * wpt_host_import.cpp -- test and tool entry points around the importer (include/wurblpt/import.hpp,
+ * objreader.hpp, imageio.hpp): what the parity tests need to look inside.
+ */
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wurblpt/objreader.hpp"
+
+using namespace WurblPT;
+
+namespace {
+
+void hexFloats(FILE* f, const char* key, const std::vector<float>& v, bool comma = true)
+{
+    fprintf(f, "\"%s\": [", key);
+    for (size_t i = 0; i < v.size(); i++) {
+        uint32_t u;
+        memcpy(&u, &v[i], 4);
+        fprintf(f, "%s\"%08x\"", i ? "," : "", u);
+    }
+    fprintf(f, "]%s\n", comma ? "," : "");
+}
+
+void ints(FILE* f, const char* key, const std::vector<long long>& v, bool comma = true)
+{
+    fprintf(f, "\"%s\": [", key);
+    for (size_t i = 0; i < v.size(); i++)
+        fprintf(f, "%s%lld", i ? "," : "", v[i]);
+    fprintf(f, "]%s\n", comma ? "," : "");
+}
+
+void chars(std::vector<long long>& dst, const std::string& s)
+{
+    dst.push_back((long long)s.size());
+    for (char c : s)
+        dst.push_back((unsigned char)c);
+}
+
+}
+
+/* Parses an OBJ file with include/wurblpt/objreader.hpp and writes what it produced as JSON with
+ * the keys and layouts of the obj_* entries of tests/golden/ref_golden.json (which hold what the
+ * reference's vendored tinyobjloader produces for the same file).  Returns 0 on success. */
+extern "C" int wpt_host_obj_dump(const char* objFile, const char* jsonFile)
+{
+    ObjData d;
+    bool ok = loadObj(objFile, d);
+    FILE* f = fopen(jsonFile, "w");
+    if (!f)
+        return 2;
+    fprintf(f, "{\n");
+    ints(f, "obj_valid", std::vector<long long>(1, ok ? 1 : 0));
+    hexFloats(f, "obj_vertices", d.vertices);
+    hexFloats(f, "obj_normals", d.normals);
+    hexFloats(f, "obj_texcoords", d.texcoords);
+    std::vector<long long> shapeNames, shapeSizes, indices, materialIds, matStrings;
+    std::vector<float> matFloats;
+    for (const ObjShape& sh : d.shapes) {
+        chars(shapeNames, sh.name);
+        shapeSizes.push_back((long long)sh.indices.size());
+        for (const ObjIndex& ix : sh.indices) {
+            indices.push_back(ix.vertex);
+            indices.push_back(ix.normal);
+            indices.push_back(ix.texcoord);
+        }
+        for (int id : sh.materialIds)
+            materialIds.push_back(id);
+    }
+    for (const ObjMaterial& M : d.materials) {
+        chars(matStrings, M.name);
+        const std::string* names[7] = { &M.diffuseTex, &M.specularTex, &M.shininessTex, &M.bumpTex, &M.alphaTex, &M.emissiveTex, &M.normalTex };
+        const ObjTexOpt* opts[7] = { &M.diffuseOpt, &M.specularOpt, &M.shininessOpt, &M.bumpOpt, &M.alphaOpt, &M.emissiveOpt, &M.normalOpt };
+        for (int k = 0; k < 3; k++) matFloats.push_back(M.diffuse[k]);
+        for (int k = 0; k < 3; k++) matFloats.push_back(M.specular[k]);
+        for (int k = 0; k < 3; k++) matFloats.push_back(M.emission[k]);
+        for (int k = 0; k < 3; k++) matFloats.push_back(M.transmittance[k]);
+        matFloats.push_back(M.shininess);
+        matFloats.push_back(M.dissolve);
+        matFloats.push_back(M.ior);
+        for (int t = 0; t < 7; t++) {
+            chars(matStrings, *names[t]);
+            for (int k = 0; k < 3; k++) matFloats.push_back(opts[t]->scale[k]);
+            for (int k = 0; k < 3; k++) matFloats.push_back(opts[t]->originOffset[k]);
+            matFloats.push_back(opts[t]->bumpMultiplier);
+        }
+    }
+    ints(f, "obj_shape_names", shapeNames);
+    ints(f, "obj_shape_index_counts", shapeSizes);
+    ints(f, "obj_indices", indices);
+    ints(f, "obj_material_ids", materialIds);
+    ints(f, "obj_material_strings", matStrings);
+    hexFloats(f, "obj_material_floats", matFloats, false);
+    fprintf(f, "}\n");
+    fclose(f);
+    if (!ok)
+        fprintf(stderr, "wpt_host: %s", d.error.c_str());
+    return ok ? 0 : 1;
+}
