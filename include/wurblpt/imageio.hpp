@@ -1,0 +1,578 @@
+/*
+ * imageio.hpp -- image file decoders for the importer: what the reference gets from libtgd's
+ * TGD::load() (import.hpp:288-299, texture_image.hpp:352-372), an external library that is not
+ * part of this build.  Decoded are the formats the scenes of the reference's examples use for
+ * textures and environment maps and that need no further library: PNG (8 and 16 bit, grey, grey +
+ * alpha, RGB, RGBA, palette; not interlaced), TGA (types 2, 3, 10, 11; 8/24/32 bit), binary PNM
+ * (P5, P6; 8 and 16 bit), PFM (Pf, PF) and Radiance HDR (RLE and flat).  JPEG is not decoded: such
+ * a file is reported and the importer substitutes its dummy texture, as the reference does for any
+ * file libtgd cannot load (import.hpp:131-134).
+ *
+ * Convention: the returned array has row 0 at the BOTTOM of the picture (texture coordinate
+ * v = 0, texture_image.hpp:85-212), i.e. formats that store the top row first are flipped.
+ */
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "array.hpp"
+
+namespace WurblPT {
+
+namespace imagedetail {
+
+inline bool readFile(const std::string& filename, std::vector<unsigned char>& bytes)
+{
+    FILE* f = fopen(filename.c_str(), "rb");
+    if (!f)
+        return false;
+    unsigned char buf[65536];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof(buf), f)) > 0)
+        bytes.insert(bytes.end(), buf, buf + got);
+    fclose(f);
+    return true;
+}
+
+/* ---- zlib / deflate (RFC 1950, 1951) ---- */
+struct BitReader {
+    const unsigned char* p;
+    size_t n, pos = 0;
+    uint32_t bitBuf = 0;
+    int bitCount = 0;
+    bool bad = false;
+    uint32_t bits(int count)
+    {
+        while (bitCount < count) {
+            if (pos >= n) {
+                bad = true;
+                return 0;
+            }
+            bitBuf |= uint32_t(p[pos++]) << bitCount;
+            bitCount += 8;
+        }
+        uint32_t v = bitBuf & ((count == 32) ? 0xffffffffu : ((1u << count) - 1u));
+        bitBuf >>= count;
+        bitCount -= count;
+        return v;
+    }
+};
+
+struct Huffman {
+    uint16_t count[16], symbol[288];
+    void build(const uint8_t* lengths, int n)
+    {
+        memset(count, 0, sizeof(count));
+        for (int i = 0; i < n; i++)
+            count[lengths[i]]++;
+        count[0] = 0;
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int i = 1; i < 15; i++)
+            offs[i + 1] = offs[i] + count[i];
+        for (int i = 0; i < n; i++)
+            if (lengths[i] != 0)
+                symbol[offs[lengths[i]]++] = uint16_t(i);
+    }
+    int decode(BitReader& br) const
+    {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len <= 15; len++) {
+            code |= int(br.bits(1));
+            if (br.bad)
+                return -1;
+            int c = count[len];
+            if (code - c < first)
+                return symbol[index + (code - first)];
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        return -1;
+    }
+};
+
+inline bool inflate(const unsigned char* src, size_t n, std::vector<unsigned char>& out)
+{
+    if (n < 2 || (src[0] & 0x0f) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 0x20))
+        return false;
+    BitReader br { src + 2, n - 2 };
+    static const uint16_t lenBase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+    static const uint16_t lenExtra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+    static const uint16_t distBase[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+    static const uint16_t distExtra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+    for (;;) {
+        const uint32_t last = br.bits(1), type = br.bits(2);
+        if (br.bad)
+            return false;
+        if (type == 0) {
+            br.bitBuf = 0;
+            br.bitCount = 0;
+            if (br.pos + 4 > br.n)
+                return false;
+            const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
+            br.pos += 4;
+            if ((len ^ 0xffffu) != nlen || br.pos + len > br.n)
+                return false;
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+        } else if (type == 1 || type == 2) {
+            Huffman lit, dist;
+            uint8_t lengths[320];
+            if (type == 1) {
+                for (int i = 0; i < 288; i++)
+                    lengths[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+                lit.build(lengths, 288);
+                for (int i = 0; i < 30; i++)
+                    lengths[i] = 5;
+                dist.build(lengths, 30);
+            } else {
+                const int nlen = int(br.bits(5)) + 257, ndist = int(br.bits(5)) + 1, ncode = int(br.bits(4)) + 4;
+                static const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+                if (br.bad || nlen > 286 || ndist > 30)
+                    return false;
+                memset(lengths, 0, sizeof(lengths));
+                for (int i = 0; i < ncode; i++)
+                    lengths[order[i]] = uint8_t(br.bits(3));
+                Huffman lencode;
+                lencode.build(lengths, 19);
+                int index = 0;
+                while (index < nlen + ndist) {
+                    int sym = lencode.decode(br);
+                    if (sym < 0)
+                        return false;
+                    if (sym < 16) {
+                        lengths[index++] = uint8_t(sym);
+                    } else {
+                        int prev = 0, rep;
+                        if (sym == 16) {
+                            if (index == 0)
+                                return false;
+                            prev = lengths[index - 1];
+                            rep = 3 + int(br.bits(2));
+                        } else if (sym == 17) {
+                            rep = 3 + int(br.bits(3));
+                        } else {
+                            rep = 11 + int(br.bits(7));
+                        }
+                        if (br.bad || index + rep > nlen + ndist)
+                            return false;
+                        while (rep--)
+                            lengths[index++] = uint8_t(prev);
+                    }
+                }
+                lit.build(lengths, nlen);
+                dist.build(lengths + nlen, ndist);
+            }
+            for (;;) {
+                int sym = lit.decode(br);
+                if (sym < 0)
+                    return false;
+                if (sym < 256) {
+                    out.push_back((unsigned char)sym);
+                } else if (sym == 256) {
+                    break;
+                } else {
+                    sym -= 257;
+                    if (sym >= 29)
+                        return false;
+                    const size_t len = lenBase[sym] + br.bits(lenExtra[sym]);
+                    const int ds = dist.decode(br);
+                    if (ds < 0 || ds >= 30)
+                        return false;
+                    const size_t d = distBase[ds] + br.bits(distExtra[ds]);
+                    if (br.bad || d > out.size())
+                        return false;
+                    const size_t start = out.size() - d;
+                    for (size_t i = 0; i < len; i++)
+                        out.push_back(out[start + i]);
+                }
+            }
+        } else {
+            return false;
+        }
+        if (last)
+            return true;
+    }
+}
+
+inline uint32_t be32(const unsigned char* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
+
+/* ---- PNG ---- */
+inline bool loadPng(const std::vector<unsigned char>& b, ArrayContainer& img, std::string& error)
+{
+    size_t pos = 8;
+    uint32_t w = 0, h = 0;
+    int depth = 0, colorType = 0, interlace = 0;
+    std::vector<unsigned char> idat, palette, trns;
+    while (pos + 12 <= b.size()) {
+        const uint32_t len = be32(b.data() + pos);
+        const unsigned char* type = b.data() + pos + 4;
+        const unsigned char* data = b.data() + pos + 8;
+        if (pos + 12 + len > b.size()) {
+            error = "truncated PNG chunk";
+            return false;
+        }
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = be32(data);
+            h = be32(data + 4);
+            depth = data[8];
+            colorType = data[9];
+            interlace = data[12];
+        } else if (!memcmp(type, "PLTE", 4)) {
+            palette.assign(data, data + len);
+        } else if (!memcmp(type, "tRNS", 4)) {
+            trns.assign(data, data + len);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + len;
+    }
+    if (w == 0 || h == 0 || interlace != 0 || !(depth == 8 || depth == 16 || (colorType == 3 && depth <= 8) || (colorType == 0 && depth < 8))) {
+        error = "PNG variant not handled (interlaced or unusual bit depth)";
+        return false;
+    }
+    const int channels = colorType == 0 ? 1 : colorType == 2 ? 3 : colorType == 3 ? 1 : colorType == 4 ? 2 : colorType == 6 ? 4 : 0;
+    if (channels == 0) {
+        error = "PNG colour type not handled";
+        return false;
+    }
+    std::vector<unsigned char> raw;
+    if (!inflate(idat.data(), idat.size(), raw)) {
+        error = "PNG data cannot be inflated";
+        return false;
+    }
+    const size_t bpp = size_t(channels * depth + 7) / 8;          /* filter unit in bytes, at least 1 */
+    const size_t stride = (size_t(w) * channels * depth + 7) / 8; /* bytes per scanline */
+    if (raw.size() < (stride + 1) * h) {
+        error = "PNG data too short";
+        return false;
+    }
+    std::vector<unsigned char> prev(stride, 0), cur(stride);
+    const bool sixteen = depth == 16;
+    const int outComps = colorType == 3 ? (trns.empty() ? 3 : 4) : channels;
+    img = ArrayContainer(w, h, outComps, sixteen ? uint16 : uint8);
+    for (uint32_t y = 0; y < h; y++) {
+        const unsigned char* line = raw.data() + (stride + 1) * y;
+        const int filter = line[0];
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, bb = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int pred = 0;
+            switch (filter) {
+            case 1: pred = a; break;
+            case 2: pred = bb; break;
+            case 3: pred = (a + bb) >> 1; break;
+            case 4: {
+                const int p = a + bb - c, pa = std::abs(p - a), pb = std::abs(p - bb), pc = std::abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c);
+                break;
+            }
+            default: break;
+            }
+            cur[i] = (unsigned char)(line[1 + i] + pred);
+        }
+        const size_t dstRow = h - 1 - y; /* PNG stores the top row first */
+        for (uint32_t x = 0; x < w; x++) {
+            if (sixteen) {
+                uint16_t* dst = img.get<uint16_t>(x, dstRow);
+                for (int c = 0; c < channels; c++)
+                    dst[c] = uint16_t((cur[(size_t(x) * channels + c) * 2] << 8) | cur[(size_t(x) * channels + c) * 2 + 1]);
+            } else if (colorType == 3) {
+                const unsigned int index = depth == 8 ? cur[x] : (cur[(size_t(x) * depth) / 8] >> (8 - depth - (x * depth) % 8)) & ((1u << depth) - 1u);
+                uint8_t* dst = img.get<uint8_t>(x, dstRow);
+                for (int c = 0; c < 3; c++)
+                    dst[c] = 3 * index + c < palette.size() ? palette[3 * index + c] : 0;
+                if (outComps == 4)
+                    dst[3] = index < trns.size() ? trns[index] : 255;
+            } else if (depth < 8) {
+                const unsigned int v = (cur[(size_t(x) * depth) / 8] >> (8 - depth - (x * depth) % 8)) & ((1u << depth) - 1u);
+                img.get<uint8_t>(x, dstRow)[0] = uint8_t(v * 255u / ((1u << depth) - 1u));
+            } else {
+                memcpy(img.get<uint8_t>(x, dstRow), cur.data() + size_t(x) * channels, channels);
+            }
+        }
+        prev.swap(cur);
+    }
+    return true;
+}
+
+/* ---- TGA ---- */
+inline bool loadTga(const std::vector<unsigned char>& b, ArrayContainer& img, std::string& error)
+{
+    if (b.size() < 18) {
+        error = "truncated TGA header";
+        return false;
+    }
+    const int idLen = b[0], cmapType = b[1], type = b[2], bits = b[16], desc = b[17];
+    const uint32_t w = b[12] | (b[13] << 8), h = b[14] | (b[15] << 8);
+    if (cmapType != 0 || !(type == 2 || type == 3 || type == 10 || type == 11) || !(bits == 8 || bits == 24 || bits == 32) || w == 0 || h == 0) {
+        error = "TGA variant not handled";
+        return false;
+    }
+    const int bytes = bits / 8;
+    std::vector<unsigned char> px(size_t(w) * h * bytes);
+    size_t pos = 18 + size_t(idLen);
+    if (type == 2 || type == 3) {
+        if (pos + px.size() > b.size()) {
+            error = "truncated TGA data";
+            return false;
+        }
+        memcpy(px.data(), b.data() + pos, px.size());
+    } else {
+        size_t o = 0;
+        while (o < px.size()) {
+            if (pos >= b.size()) {
+                error = "truncated TGA data";
+                return false;
+            }
+            const int head = b[pos++];
+            const size_t count = size_t(head & 0x7f) + 1;
+            if (head & 0x80) {
+                if (pos + bytes > b.size() || o + count * bytes > px.size()) {
+                    error = "bad TGA run";
+                    return false;
+                }
+                for (size_t i = 0; i < count; i++, o += bytes)
+                    memcpy(px.data() + o, b.data() + pos, bytes);
+                pos += bytes;
+            } else {
+                if (pos + count * bytes > b.size() || o + count * bytes > px.size()) {
+                    error = "bad TGA packet";
+                    return false;
+                }
+                memcpy(px.data() + o, b.data() + pos, count * bytes);
+                pos += count * bytes;
+                o += count * bytes;
+            }
+        }
+    }
+    const bool topFirst = (desc & 0x20) != 0, rightFirst = (desc & 0x10) != 0;
+    img = ArrayContainer(w, h, bytes, uint8);
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            const unsigned char* s = px.data() + (size_t(y) * w + x) * bytes;
+            uint8_t* d = img.get<uint8_t>(rightFirst ? w - 1 - x : x, topFirst ? h - 1 - y : y);
+            if (bytes == 1) {
+                d[0] = s[0];
+            } else { /* stored blue, green, red[, alpha] */
+                d[0] = s[2];
+                d[1] = s[1];
+                d[2] = s[0];
+                if (bytes == 4)
+                    d[3] = s[3];
+            }
+        }
+    return true;
+}
+
+/* token of a PNM / PFM header: skips white space and # comments */
+inline bool headerToken(const std::vector<unsigned char>& b, size_t& pos, std::string& tok)
+{
+    tok.clear();
+    for (;;) {
+        while (pos < b.size() && (b[pos] == ' ' || b[pos] == '\t' || b[pos] == '\n' || b[pos] == '\r'))
+            pos++;
+        if (pos < b.size() && b[pos] == '#') {
+            while (pos < b.size() && b[pos] != '\n')
+                pos++;
+            continue;
+        }
+        break;
+    }
+    while (pos < b.size() && !(b[pos] == ' ' || b[pos] == '\t' || b[pos] == '\n' || b[pos] == '\r'))
+        tok += char(b[pos++]);
+    return !tok.empty();
+}
+
+/* ---- binary PGM / PPM and PFM ---- */
+inline bool loadPnm(const std::vector<unsigned char>& b, ArrayContainer& img, std::string& error)
+{
+    size_t pos = 0;
+    std::string magic, sw, sh, smax;
+    if (!headerToken(b, pos, magic) || !headerToken(b, pos, sw) || !headerToken(b, pos, sh) || !headerToken(b, pos, smax)) {
+        error = "bad PNM header";
+        return false;
+    }
+    pos++; /* the single white space after the header */
+    const long w = atol(sw.c_str()), h = atol(sh.c_str());
+    if (w <= 0 || h <= 0) {
+        error = "bad PNM size";
+        return false;
+    }
+    if (magic == "P5" || magic == "P6") {
+        const int comps = magic == "P5" ? 1 : 3;
+        const long maxval = atol(smax.c_str());
+        const bool sixteen = maxval > 255;
+        const size_t need = size_t(w) * h * comps * (sixteen ? 2 : 1);
+        if (maxval <= 0 || maxval > 65535 || pos + need > b.size()) {
+            error = "truncated PNM data";
+            return false;
+        }
+        img = ArrayContainer(w, h, comps, sixteen ? uint16 : uint8);
+        for (long y = 0; y < h; y++) {
+            const unsigned char* s = b.data() + pos + size_t(y) * w * comps * (sixteen ? 2 : 1);
+            const size_t dstRow = h - 1 - y; /* top row first in the file */
+            if (sixteen) {
+                uint16_t* d = img.get<uint16_t>(0, dstRow);
+                for (long i = 0; i < w * comps; i++)
+                    d[i] = uint16_t((s[2 * i] << 8) | s[2 * i + 1]);
+            } else {
+                memcpy(img.get<uint8_t>(0, dstRow), s, size_t(w) * comps);
+            }
+        }
+        return true;
+    }
+    if (magic == "Pf" || magic == "PF") {
+        const int comps = magic == "Pf" ? 1 : 3;
+        const double scale = atof(smax.c_str());
+        const size_t need = size_t(w) * h * comps * 4;
+        if (scale == 0.0 || pos + need > b.size()) {
+            error = "truncated PFM data";
+            return false;
+        }
+        const bool little = scale < 0.0;
+        img = ArrayContainer(w, h, comps, float32);
+        float* d = img.get<float>(0); /* PFM stores the bottom row first */
+        for (size_t i = 0; i < size_t(w) * h * comps; i++) {
+            const unsigned char* s = b.data() + pos + 4 * i;
+            uint32_t u = little ? (uint32_t(s[0]) | (uint32_t(s[1]) << 8) | (uint32_t(s[2]) << 16) | (uint32_t(s[3]) << 24)) : be32(s);
+            memcpy(d + i, &u, 4);
+        }
+        return true;
+    }
+    error = "PNM variant not handled (only the binary P5, P6 and Pf, PF)";
+    return false;
+}
+
+/* ---- Radiance HDR (RGBE) ---- */
+inline bool loadHdr(const std::vector<unsigned char>& b, ArrayContainer& img, std::string& error)
+{
+    size_t pos = 0;
+    auto line = [&](std::string& s) {
+        s.clear();
+        while (pos < b.size() && b[pos] != '\n')
+            s += char(b[pos++]);
+        pos++;
+        return pos <= b.size();
+    };
+    std::string s;
+    line(s);
+    if (s.compare(0, 2, "#?") != 0) {
+        error = "not a Radiance HDR file";
+        return false;
+    }
+    while (line(s) && !s.empty())
+        ;
+    line(s);
+    int w = 0, h = 0;
+    if (sscanf(s.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) {
+        error = "HDR orientation not handled";
+        return false;
+    }
+    img = ArrayContainer(w, h, 3, float32);
+    std::vector<unsigned char> scan(size_t(w) * 4);
+    for (int y = 0; y < h; y++) {
+        if (pos + 4 > b.size()) {
+            error = "truncated HDR data";
+            return false;
+        }
+        if (w >= 8 && w < 32768 && b[pos] == 2 && b[pos + 1] == 2 && (b[pos + 2] & 0x80) == 0) {
+            pos += 4;
+            for (int c = 0; c < 4; c++) {
+                int x = 0;
+                while (x < w) {
+                    if (pos >= b.size()) {
+                        error = "truncated HDR data";
+                        return false;
+                    }
+                    int count = b[pos++];
+                    if (count > 128) {
+                        count -= 128;
+                        if (pos >= b.size() || x + count > w) {
+                            error = "bad HDR run";
+                            return false;
+                        }
+                        const unsigned char v = b[pos++];
+                        while (count--)
+                            scan[size_t(x++) * 4 + c] = v;
+                    } else {
+                        if (count == 0 || pos + count > b.size() || x + count > w) {
+                            error = "bad HDR packet";
+                            return false;
+                        }
+                        while (count--)
+                            scan[size_t(x++) * 4 + c] = b[pos++];
+                    }
+                }
+            }
+        } else {
+            if (pos + size_t(w) * 4 > b.size()) {
+                error = "truncated HDR data";
+                return false;
+            }
+            memcpy(scan.data(), b.data() + pos, size_t(w) * 4);
+            pos += size_t(w) * 4;
+        }
+        float* d = img.get<float>(0, size_t(h - 1 - y)); /* top scanline first in the file */
+        for (int x = 0; x < w; x++) {
+            const unsigned char* p = scan.data() + size_t(x) * 4;
+            if (p[3] == 0) {
+                d[3 * x] = d[3 * x + 1] = d[3 * x + 2] = 0.0f;
+            } else {
+                const float f = std::ldexp(1.0f, int(p[3]) - (128 + 8));
+                d[3 * x] = (p[0] + 0.5f) * f;
+                d[3 * x + 1] = (p[1] + 0.5f) * f;
+                d[3 * x + 2] = (p[2] + 0.5f) * f;
+            }
+        }
+    }
+    return true;
+}
+
+}
+
+/* Loads an image file; an empty array (elementCount() == 0) and a message on failure. */
+inline ArrayContainer loadImage(const std::string& filename, std::string* error = nullptr)
+{
+    using namespace imagedetail;
+    std::string err;
+    ArrayContainer img;
+    std::vector<unsigned char> b;
+    bool ok = false;
+    if (!readFile(filename, b)) {
+        err = "cannot open file";
+    } else if (b.size() >= 8 && !memcmp(b.data(), "\x89PNG\r\n\x1a\n", 8)) {
+        ok = loadPng(b, img, err);
+    } else if (b.size() >= 2 && b[0] == 'P' && (b[1] == '5' || b[1] == '6' || b[1] == 'f' || b[1] == 'F')) {
+        ok = loadPnm(b, img, err);
+    } else if (b.size() >= 2 && b[0] == '#' && b[1] == '?') {
+        ok = loadHdr(b, img, err);
+    } else if (b.size() >= 3 && b[0] == 0xff && b[1] == 0xd8) {
+        err = "JPEG files are not decoded by this build";
+    } else {
+        const size_t dot = filename.find_last_of('.');
+        std::string ext = dot == std::string::npos ? "" : filename.substr(dot + 1);
+        for (char& c : ext)
+            c = char(tolower(c));
+        if (ext == "tga")
+            ok = loadTga(b, img, err);
+        else
+            err = "unknown image format";
+    }
+    if (!ok) {
+        if (error)
+            *error = filename + ": " + err;
+        return ArrayContainer();
+    }
+    return img;
+}
+
+}

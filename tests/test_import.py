@@ -25,3 +25,163 @@ def test_obj_reader_matches_the_vendored_tinyobjloader(golden, tmp_path):
     for key, value in mine.items():
         assert value == golden.raw[key], key
     assert golden.raw["obj_shape_index_counts"] == [21, 12, 9, 15, 18, 3]
+
+
+# ---- image decoders: files written here with numpy / zlib, decoded by include/wurblpt/imageio.hpp ----
+
+def _png_bytes(img, depth, palette=None, trns=None):
+    """img: [h, w, c] top row first; a random filter type per scanline exercises all five predictors"""
+    import struct
+    import zlib
+    h, w, c = img.shape
+    color_type = {1: 0, 2: 4, 3: 2, 4: 6}[c] if palette is None else 3
+    rng = np.random.RandomState(w * 131 + h)
+    bpp = max(1, c * depth // 8)
+    rows = []
+    prev = np.zeros(w * c * depth // 8, np.int32)
+    for y in range(h):
+        if depth == 16:
+            cur = np.stack([img[y].astype(np.uint16) >> 8, img[y].astype(np.uint16) & 255], axis=-1).reshape(-1).astype(np.int32)
+        else:
+            cur = img[y].reshape(-1).astype(np.int32)
+        f = int(rng.randint(0, 5))
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        cc = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if f == 0:
+            pred = np.zeros_like(cur)
+        elif f == 1:
+            pred = a
+        elif f == 2:
+            pred = prev
+        elif f == 3:
+            pred = (a + prev) >> 1
+        else:
+            p = a + prev - cc
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - cc)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, cc))
+        rows.append(bytes([f]) + ((cur - pred) & 255).astype(np.uint8).tobytes())
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 0))
+    if palette is not None:
+        out += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+        if trns is not None:
+            out += chunk(b"tRNS", trns.astype(np.uint8).tobytes())
+    data = zlib.compress(b"".join(rows), 6)
+    out += chunk(b"IDAT", data[:len(data) // 2]) + chunk(b"IDAT", data[len(data) // 2:]) + chunk(b"IEND", b"")
+    return out
+
+
+def test_png_decoder(tmp_path):
+    rng = np.random.RandomState(1)
+    for comps in (1, 2, 3, 4):
+        for depth in (8, 16):
+            img = rng.randint(0, 256 if depth == 8 else 65536, (13, 17, comps)).astype(np.uint16 if depth == 16 else np.uint8)
+            img[3:9, 2:12] = img[3, 2]  # runs, so that deflate emits matches
+            f = tmp_path / ("t_%d_%d.png" % (comps, depth))
+            f.write_bytes(_png_bytes(img, depth))
+            got = host.image_load(str(f))
+            assert got is not None and got.dtype == img.dtype and np.array_equal(got, img[::-1]), (comps, depth)
+    pal = rng.randint(0, 256, (16, 3))
+    idx = rng.randint(0, 16, (9, 11, 1)).astype(np.uint8)
+    f = tmp_path / "pal.png"
+    f.write_bytes(_png_bytes(idx, 8, palette=pal, trns=np.arange(10) * 20))
+    got = host.image_load(str(f))
+    want = np.concatenate([pal[idx[..., 0]], np.where(idx < 10, idx * 20, 255)], axis=-1).astype(np.uint8)
+    assert np.array_equal(got, want[::-1])
+
+
+def test_tga_pnm_pfm_hdr_decoders(tmp_path):
+    import struct
+    rng = np.random.RandomState(2)
+    # TGA: flat and run-length encoded, bottom-up and top-down, grey / BGR / BGRA
+    for comps in (1, 3, 4):
+        img = rng.randint(0, 256, (10, 12, comps)).astype(np.uint8)
+        img[2:6, 1:9] = img[2, 1]
+        stored = img if comps == 1 else img[..., [2, 1, 0] + ([3] if comps == 4 else [])]
+        for rle in (False, True):
+            for top in (False, True):
+                rows = stored[::-1] if top else stored  # file order; array row 0 = bottom
+                if rle:
+                    body = bytearray()
+                    flat = rows.reshape(-1, comps)
+                    i = 0
+                    while i < len(flat):
+                        run = 1
+                        while i + run < len(flat) and run < 128 and np.array_equal(flat[i + run], flat[i]):
+                            run += 1
+                        if run > 1:
+                            body += bytes([0x80 | (run - 1)]) + flat[i].tobytes()
+                            i += run
+                        else:
+                            n = 1
+                            while i + n < len(flat) and n < 128 and not np.array_equal(flat[i + n], flat[i + n - 1]):
+                                n += 1
+                            body += bytes([n - 1]) + flat[i:i + n].tobytes()
+                            i += n
+                    body = bytes(body)
+                else:
+                    body = rows.tobytes()
+                hdr = struct.pack("<BBBHHBHHHHBB", 0, 0, (11 if comps == 1 else 10) if rle else (3 if comps == 1 else 2), 0, 0, 0, 0, 0, 12, 10,
+                                  8 * comps, 0x20 if top else 0)
+                f = tmp_path / ("t_%d_%d_%d.tga" % (comps, rle, top))
+                f.write_bytes(hdr + body)
+                got = host.image_load(str(f))
+                assert got is not None and np.array_equal(got, img), (comps, rle, top)
+    # PGM / PPM, 8 and 16 bit (top row first in the file), with a comment in the header
+    for comps, magic in ((1, b"P5"), (3, b"P6")):
+        for maxval in (255, 65535):
+            img = rng.randint(0, maxval + 1, (7, 9, comps)).astype(np.uint16 if maxval > 255 else np.uint8)
+            data = img.astype(">u2").tobytes() if maxval > 255 else img.tobytes()
+            f = tmp_path / ("t_%d_%d.pnm" % (comps, maxval))
+            f.write_bytes(magic + b"\n# a comment\n9 7\n%d\n" % maxval + data)
+            got = host.image_load(str(f))
+            assert got is not None and got.dtype == img.dtype and np.array_equal(got, img[::-1])
+    # PFM (bottom row first), both byte orders
+    for comps, magic in ((1, b"Pf"), (3, b"PF")):
+        for little in (True, False):
+            img = rng.uniform(-2, 50, (6, 5, comps)).astype(np.float32)
+            f = tmp_path / ("t_%d_%d.pfm" % (comps, little))
+            f.write_bytes(magic + b"\n5 6\n" + (b"-1.0" if little else b"1.0") + b"\n" + img.astype("<f4" if little else ">f4").tobytes())
+            got = host.image_load(str(f))
+            assert got is not None and np.array_equal(got.view(np.uint32), img.view(np.uint32))
+    # Radiance HDR: flat and new-style run-length encoded scanlines
+    w, h = 16, 5
+    rgbe = rng.randint(0, 256, (h, w, 4)).astype(np.uint8)
+    rgbe[:, :, 3] = rng.randint(120, 136, (h, w))
+    rgbe[1, :, :] = rgbe[1, 0, :]
+    rgbe[2, 3, 3] = 0
+    expect = np.where(rgbe[..., 3:4] == 0, 0.0, (rgbe[..., :3].astype(np.float32) + 0.5) * np.ldexp(np.float32(1.0), rgbe[..., 3:4].astype(np.int32) - 136)).astype(np.float32)
+    for rle in (False, True):
+        body = bytearray()
+        for y in range(h):
+            if not rle:
+                body += rgbe[y].tobytes()
+                continue
+            body += bytes([2, 2, w >> 8, w & 255])
+            for c in range(4):
+                line = rgbe[y, :, c]
+                x = 0
+                while x < w:
+                    run = 1
+                    while x + run < w and run < 127 and line[x + run] == line[x]:
+                        run += 1
+                    if run >= 3:
+                        body += bytes([128 + run, int(line[x])])
+                        x += run
+                    else:
+                        n = 1
+                        while x + n < w and n < 128 and not (x + n + 2 < w and line[x + n] == line[x + n + 1] == line[x + n + 2]):
+                            n += 1
+                        body += bytes([n]) + line[x:x + n].tobytes()
+                        x += n
+        f = tmp_path / ("t_%d.hdr" % rle)
+        f.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + bytes(body))
+        got = host.image_load(str(f))
+        assert got is not None and np.array_equal(got.view(np.uint32), expect[::-1].copy().view(np.uint32)), rle
+    # what is not decoded is reported, not guessed
+    f = tmp_path / "x.jpg"
+    f.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
+    assert host.image_load(str(f)) is None

@@ -171,6 +171,21 @@ def measured_like(width, height, rgl0, rgl1, seed=3, detail=1.0, tex_size=1024, 
     return HostScene(h, width, height, "measured_like(seed=%d,detail=%g)" % (seed, detail))
 
 
+def image_load(filename):
+    """Decodes an image file with the importer's decoders: numpy array [h, w, comps], row 0 = bottom."""
+    L = lib()
+    L.wpt_host_image_load.restype = C.c_ulonglong
+    L.wpt_host_image_load.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_ulonglong]
+    info = (C.c_uint * 4)()
+    n = L.wpt_host_image_load(filename.encode(), info, None, 0)
+    if n == 0:
+        return None
+    dtype = [np.uint8, np.uint16, np.float32][info[3]]
+    out = np.zeros((info[1], info[0], info[2]), dtype=dtype)
+    L.wpt_host_image_load(filename.encode(), info, C.c_void_p(out.ctypes.data), n)
+    return out
+
+
 def bvh_build(boxes):
     """boxes: float32 [n, 6] (lo, hi) -> (uint32 [nodes, 8] raw node words, levels)."""
     boxes = np.ascontiguousarray(boxes, dtype=np.float32)

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/wurblpt/imageio.hpp"
 #include "../../include/wurblpt/objreader.hpp"
 
 using namespace WurblPT;
@@ -98,4 +99,26 @@ extern "C" int wpt_host_obj_dump(const char* objFile, const char* jsonFile)
     if (!ok)
         fprintf(stderr, "wpt_host: %s", d.error.c_str());
     return ok ? 0 : 1;
+}
+
+/* Decodes an image file with include/wurblpt/imageio.hpp.  info = width, height, components,
+ * component type (0 uint8, 1 uint16, 2 float32); copies at most `capacity` bytes of the array
+ * (row 0 = bottom).  Returns the array size in bytes, 0 on failure (message on stderr). */
+extern "C" unsigned long long wpt_host_image_load(const char* filename, unsigned int* info, void* data, unsigned long long capacity)
+{
+    std::string error;
+    ArrayContainer img = loadImage(filename, &error);
+    if (img.elementCount() == 0) {
+        fprintf(stderr, "wpt_host: %s\n", error.c_str());
+        return 0;
+    }
+    if (info) {
+        info[0] = img.dimension(0);
+        info[1] = img.dimension(1);
+        info[2] = img.componentCount();
+        info[3] = img.componentType();
+    }
+    if (data)
+        memcpy(data, img.data(), img.dataSize() < capacity ? img.dataSize() : capacity);
+    return img.dataSize();
 }
