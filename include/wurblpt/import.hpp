@@ -1,0 +1,315 @@
+/*
+ * import.hpp -- importIntoScene(): Wavefront OBJ + MTL -> Scene, with the reference's material
+ * mapping and flags (import.hpp:64-504).
+ *
+ * What the result depends on is kept: the material rules (Lambertian when nothing else is needed,
+ * glass on request, ModPhong otherwise; the Tf / d fix-ups; two-sided wrappers; which materials
+ * become hot spots), one MeshInstance per (material, shape) with vertices de-duplicated by their
+ * (position, normal, texcoord) index triple in order of first use, normals normalised or recomputed,
+ * tangents only for normal-mapped materials, bump maps converted to normal maps.
+ * Two things differ on purpose:
+ *  - the reference imports the materials' geometry in an OpenMP loop whose order of completion
+ *    decides the hitable order; here the loop is serial (no material first, then the materials in
+ *    MTL order, shapes in file order inside each), so an import is reproducible;
+ *  - images come from imageio.hpp (row 0 = bottom) instead of libtgd; files it cannot decode become
+ *    the dummy textures the reference uses for load failures.
+ */
+#pragma once
+
+#include <cstdio>
+#include <map>
+#include <set>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "geometryproc.hpp"
+#include "imageio.hpp"
+#include "material.hpp"
+#include "mesh.hpp"
+#include "objreader.hpp"
+#include "scene.hpp"
+#include "texture.hpp"
+#include "transformation.hpp"
+
+namespace WurblPT {
+
+/* color.hpp:280-294 */
+inline float byte_to_float(uint8_t x) { return x / 255.0f; }
+inline uint8_t float_to_byte(float x) { return uint8_t(std::round(x * 255.0f)); }
+
+/* import.hpp:64-90: normal map from a bump (height) map by central differences */
+inline ArrayContainer toNormalMap(const ArrayContainer& bumpMap, float bumpScaling = 8.0f)
+{
+    Array<uint8_t> normalMap(bumpMap.dimension(0), bumpMap.dimension(1), 3);
+    const int w = int(normalMap.dimension(0)), h = int(normalMap.dimension(1));
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            const uint8_t height_r = bumpMap.get<uint8_t>(size_t(y) * w + std::min(x + 1, w - 1))[0];
+            const uint8_t height_l = bumpMap.get<uint8_t>(size_t(y) * w + std::max(x - 1, 0))[0];
+            const uint8_t height_t = bumpMap.get<uint8_t>(size_t(std::min(y + 1, h - 1)) * w + x)[0];
+            const uint8_t height_b = bumpMap.get<uint8_t>(size_t(std::max(y - 1, 0)) * w + x)[0];
+            const vec3 tx = vec3(2.0f, 0.0f, bumpScaling * (byte_to_float(height_r) - byte_to_float(height_l)));
+            const vec3 ty = vec3(0.0f, 2.0f, bumpScaling * (byte_to_float(height_t) - byte_to_float(height_b)));
+            const vec3 n = normalize(cross(tx, ty));
+            uint8_t* rgb = normalMap.get<uint8_t>(size_t(y) * w + x);
+            rgb[0] = float_to_byte(0.5f * (n.x() + 1.0f));
+            rgb[1] = float_to_byte(0.5f * (n.y() + 1.0f));
+            rgb[2] = float_to_byte(0.5f * (n.z() + 1.0f));
+        }
+    }
+    return normalMap;
+}
+
+/* import.hpp:93-169: one Texture per (file, factor, offset, linearisation, bump scaling) */
+inline Texture* importTexture(std::map<std::string, Texture*>& textureMap, const std::map<std::string, ArrayContainer>& textureFileMap,
+        const std::string& name, const float factor[3], const float offset[3], int* componentCount = nullptr,
+        LinearizeSRGBType linearizeSRGBType = LinearizeSRGB_Auto, float bumpScaling = -1.0f /* < 0: not a bump map */)
+{
+    const char* lin = linearizeSRGBType == LinearizeSRGB_On ? "on" : linearizeSRGBType == LinearizeSRGB_Off ? "off" : "auto";
+    const std::string cacheName = name + "_factor=" + std::to_string(factor[0]) + ',' + std::to_string(factor[1])
+        + "_offset=" + std::to_string(offset[0]) + ',' + std::to_string(offset[1]) + "_linsrgb=" + lin
+        + "_bumpscal=" + std::to_string(bumpScaling);
+    auto it = textureMap.find(cacheName);
+    if (it != textureMap.end())
+        return it->second;
+    ArrayContainer img = textureFileMap.at(name);
+    Texture* tex;
+    if (img.elementCount() == 0) {
+        tex = new TextureConstant(vec4(0.5f));
+        fprintf(stderr, "    texture %s: replaced with dummy texture\n", cacheName.c_str());
+    } else {
+        if (componentCount)
+            *componentCount = int(img.componentCount());
+        if (bumpScaling > 0.0f) {
+            if (img.componentType() != uint8) {
+                tex = new TextureConstant(vec4(0.5f, 0.5f, 1.0f, 0.0f));
+                fprintf(stderr, "    texture %s: cannot handle a bump/normal map that is not uint8, replaced with dummy texture\n", cacheName.c_str());
+            } else {
+                /* grey bump maps are sometimes stored as RGB: a map is a bump map unless a texel has colour */
+                bool imageIsBumpMap = true;
+                if (img.componentCount() >= 3) {
+                    for (size_t e = 0; e < img.elementCount(); e++) {
+                        const uint8_t* elem = img.get<uint8_t>(e);
+                        if (elem[0] != elem[1] || elem[0] != elem[2] || elem[1] != elem[2]) {
+                            imageIsBumpMap = false;
+                            break;
+                        }
+                    }
+                }
+                if (imageIsBumpMap)
+                    img = toNormalMap(img, bumpScaling);
+                tex = createTextureImage(img, linearizeSRGBType, vec2(factor[0], factor[1]), vec2(offset[0], offset[1]));
+            }
+        } else {
+            tex = createTextureImage(img, linearizeSRGBType, vec2(factor[0], factor[1]), vec2(offset[0], offset[1]));
+        }
+    }
+    textureMap.insert(std::pair<std::string, Texture*>(cacheName, tex));
+    return tex;
+}
+
+constexpr unsigned int ImportBitDisableLightSources = (1 << 0); /* import.hpp:187-196 */
+constexpr unsigned int ImportBitDisableHotSpots = (1 << 1);
+constexpr unsigned int ImportBitTwoSidedMaterials = (1 << 2);
+constexpr unsigned int ImportBitInvertedTf = (1 << 3);
+constexpr unsigned int ImportBitWithGlass = (1 << 4);
+
+/* MaterialGlass::transparentColorToAbsorption (material_glass.hpp:154-165) */
+inline vec3 transparentColorToAbsorption(const vec3& c, float targetDistance = 0.01f)
+{
+    auto one = [&](float t) { return max(-std::log(t) / targetDistance, 0.0f); };
+    return vec3(one(c.r()), one(c.g()), one(c.b()));
+}
+
+/* import.hpp:198-504 */
+inline bool importIntoScene(Scene& scene, const std::string& filename, const Transformation& transformation = Transformation(),
+        unsigned int importBits = 0)
+{
+    fprintf(stderr, "%s: importing...\n", filename.c_str());
+    ObjData obj;
+    const bool valid = loadObj(filename, obj);
+    if (!obj.warning.empty())
+        fprintf(stderr, "  warning: %s", obj.warning.c_str());
+    if (!valid) {
+        fprintf(stderr, "  error: %s%s: import failure\n", obj.error.c_str(), filename.c_str());
+        return false;
+    }
+    const std::vector<ObjMaterial>& objMaterials = obj.materials;
+    std::string basedir = ".";
+    const size_t dirSep = filename.find_last_of("/\\");
+    if (dirSep != std::string::npos)
+        basedir = filename.substr(0, dirSep);
+
+    /* all texture files, each loaded once */
+    std::set<std::string> textureFileSet;
+    for (const ObjMaterial& M : objMaterials) {
+        for (const std::string* n : { &M.normalTex, &M.bumpTex, &M.diffuseTex, &M.specularTex, &M.shininessTex, &M.alphaTex, &M.emissiveTex })
+            if (n->size() > 0)
+                textureFileSet.insert(*n);
+    }
+    std::map<std::string, ArrayContainer> textureFileMap;
+    for (const std::string& name : textureFileSet) {
+        std::string fileName = basedir + "/" + name;
+        for (char& c : fileName)
+            if (c == '\\')
+                c = '/';
+        std::string err;
+        ArrayContainer img = loadImage(fileName, &err);
+        fprintf(stderr, "    %s: %s\n", name.c_str(), err.empty() ? "ok" : err.c_str());
+        textureFileMap.insert(std::pair<std::string, ArrayContainer>(name, img));
+    }
+
+    /* the materials */
+    std::vector<Material*> materials;
+    std::vector<std::string> materialNames;
+    std::vector<bool> materialIsLight, materialWantsTangents;
+    std::map<std::string, Texture*> textureMap;
+    for (const ObjMaterial& M : objMaterials) {
+        vec3 dif = vec3(M.diffuse), spc = vec3(M.specular), emi = vec3(M.emission), tra = vec3(M.transmittance);
+        const float shi = M.shininess, ior = M.ior;
+        float opa = M.dissolve;
+        if (importBits & ImportBitInvertedTf)
+            tra = vec3(1.0f) - tra;
+        if (opa >= 1.0f && max(tra) < 1.0f) {
+            opa = average(tra);
+            tra = vec3(1.0f) - tra;
+        }
+        if (opa < 1.0f && max(tra) <= 0.0f)
+            tra = (1.0f - opa) * dif;
+        Texture* nrmTex = nullptr;
+        if (M.normalTex.size() > 0)
+            nrmTex = importTexture(textureMap, textureFileMap, M.normalTex, M.normalOpt.scale, M.normalOpt.originOffset, nullptr, LinearizeSRGB_Off);
+        else if (M.bumpTex.size() > 0)
+            nrmTex = importTexture(textureMap, textureFileMap, M.bumpTex, M.bumpOpt.scale, M.bumpOpt.originOffset, nullptr, LinearizeSRGB_Off, M.bumpOpt.bumpMultiplier);
+        int imgComp = 0;
+        Texture* difTex = nullptr;
+        if (M.diffuseTex.size() > 0)
+            difTex = importTexture(textureMap, textureFileMap, M.diffuseTex, M.diffuseOpt.scale, M.diffuseOpt.originOffset, &imgComp);
+        const bool difTexHasAlpha = (difTex && (imgComp == 2 || imgComp == 4));
+        const bool lightsOff = (importBits & ImportBitDisableLightSources) != 0;
+        if (!difTexHasAlpha && max(spc) <= 0.0f && M.specularTex.size() == 0
+                && (lightsOff || (max(emi) <= 0.0f && M.emissiveTex.size() == 0)) && opa >= 1.0f && M.alphaTex.size() == 0) {
+            MaterialLambertian* mat = new MaterialLambertian(dif, difTex);
+            mat->normalTex = nrmTex;
+            materials.push_back(mat);
+            materialIsLight.push_back(false);
+            materialWantsTangents.push_back(mat->normalTex != nullptr);
+        } else if ((importBits & ImportBitWithGlass) && !difTex && M.specularTex.size() == 0 && max(emi) <= 0.0f
+                && M.emissiveTex.size() == 0 && opa < 1.0f && M.alphaTex.size() == 0) {
+            MaterialGlass* mat = new MaterialGlass(transparentColorToAbsorption(dif), ior);
+            mat->normalTex = nrmTex;
+            materials.push_back(mat);
+            materialIsLight.push_back(false);
+            materialWantsTangents.push_back(mat->normalTex != nullptr);
+        } else {
+            MaterialModPhong* mat = new MaterialModPhong;
+            mat->normalTex = nrmTex;
+            mat->haveNIR = false;
+            int specComp = 0;
+            mat->diffuse = vec4(dif, 0.0f);
+            mat->diffuseTex = difTex;
+            mat->diffuseTexHasAlpha = difTexHasAlpha;
+            mat->specular = vec4(spc, 0.0f);
+            if (M.specularTex.size() > 0)
+                mat->specularTex = importTexture(textureMap, textureFileMap, M.specularTex, M.specularOpt.scale, M.specularOpt.originOffset, &specComp);
+            mat->specularTexHasAlpha = (mat->specularTex && (specComp == 2 || specComp == 4));
+            mat->shininess = shi;
+            if (M.shininessTex.size() > 0)
+                mat->shininessTex = importTexture(textureMap, textureFileMap, M.shininessTex, M.shininessOpt.scale, M.shininessOpt.originOffset, nullptr, LinearizeSRGB_Off);
+            mat->opacity = opa;
+            if (M.alphaTex.size() > 0)
+                mat->opacityTex = importTexture(textureMap, textureFileMap, M.alphaTex, M.alphaOpt.scale, M.alphaOpt.originOffset, nullptr, LinearizeSRGB_Off);
+            mat->indexOfRefraction = ior;
+            mat->transmissive = vec4(tra, 0.0f);
+            if (!lightsOff)
+                mat->emissive = vec4(emi, 0.0f);
+            if (!lightsOff && M.emissiveTex.size() > 0)
+                mat->emissiveTex = importTexture(textureMap, textureFileMap, M.emissiveTex, M.emissiveOpt.scale, M.emissiveOpt.originOffset);
+            materials.push_back(mat);
+            materialIsLight.push_back(dot(mat->emissive, mat->emissive) > 0.0f || mat->emissiveTex);
+            materialWantsTangents.push_back(mat->normalTex != nullptr);
+        }
+        materialNames.push_back(M.name);
+    }
+    for (auto it = textureMap.cbegin(); it != textureMap.cend(); it++)
+        scene.take(it->second);
+    for (size_t i = 0; i < materials.size(); i++)
+        scene.take(materials[i], materialNames[i]);
+    if (importBits & ImportBitTwoSidedMaterials) {
+        for (size_t i = 0; i < materials.size(); i++) {
+            MaterialTwoSided* mat = new MaterialTwoSided(materials[i], materials[i]);
+            materials[i] = mat;
+            scene.take(mat, materialNames[i]);
+        }
+    }
+
+    /* the shapes: one MeshInstance per (material, shape); serial, see the header of this file */
+    Material* nullMaterial = scene.take(new MaterialLambertian(vec4(0.5f)));
+    for (int matId = -1; matId < int(materials.size()); matId++) {
+        for (size_t s = 0; s < obj.shapes.size(); s++) {
+            const ObjShape& shape = obj.shapes[s];
+            std::map<std::tuple<int, int, int>, unsigned int> indexTupleMap;
+            std::vector<vec3> positions, normals;
+            std::vector<vec2> texcoords;
+            std::vector<unsigned int> indices;
+            bool haveNormals = true, haveTexCoords = true;
+            for (size_t i = 0; i < shape.indices.size(); i++) {
+                if (shape.materialIds[i / 3] != matId)
+                    continue;
+                const ObjIndex& index = shape.indices[i];
+                const int vi = index.vertex, ni = index.normal, ti = index.texcoord;
+                const std::tuple<int, int, int> indexTuple = std::make_tuple(vi, ni, ti);
+                auto it = indexTupleMap.find(indexTuple);
+                if (it != indexTupleMap.end()) {
+                    indices.push_back(it->second);
+                    continue;
+                }
+                const unsigned int newIndex = indexTupleMap.size();
+                if (vi < 0 || size_t(vi) >= obj.vertices.size() / 3) {
+                    fprintf(stderr, "%s: vertex index out of range in shape '%s'\n", filename.c_str(), shape.name.c_str());
+                    return false;
+                }
+                positions.push_back(vec3(obj.vertices.data() + 3 * vi));
+                if (ni < 0)
+                    haveNormals = false;
+                if (ti < 0)
+                    haveTexCoords = false;
+                if (haveNormals) {
+                    if (size_t(ni) >= obj.normals.size() / 3)
+                        return false;
+                    const vec3 n = vec3(obj.normals.data() + 3 * ni);
+                    if (!all(isfinite(n)) || dot(n, n) < epsilon) {
+                        fprintf(stderr, "      warning: invalid normals in shape %zu '%s'\n", s, shape.name.c_str());
+                        haveNormals = false;
+                    } else {
+                        normals.push_back(normalize(n));
+                    }
+                }
+                if (haveTexCoords) {
+                    if (size_t(ti) >= obj.texcoords.size() / 2)
+                        return false;
+                    texcoords.push_back(vec2(obj.texcoords.data() + 2 * ti));
+                }
+                indices.push_back(newIndex);
+                indexTupleMap.insert(std::make_pair(indexTuple, newIndex));
+            }
+            if (indices.size() == 0)
+                continue;
+            if (!haveNormals)
+                normals = computeNormals(positions, indices);
+            if (!haveTexCoords)
+                texcoords.clear();
+            Material* mat = matId < 0 ? nullMaterial : materials[matId];
+            const bool matIsLight = matId < 0 ? false : bool(materialIsLight[matId]);
+            const bool matWantsTangents = matId < 0 ? false : bool(materialWantsTangents[matId]);
+            Mesh* mesh = new Mesh(positions, normals, texcoords, indices, transformation, matWantsTangents);
+            scene.take(mesh);
+            scene.take(new MeshInstance(mesh, mat), (matIsLight && !(importBits & ImportBitDisableHotSpots)) ? HotSpot : ColdSpot);
+        }
+    }
+    fprintf(stderr, "%s: import done\n", filename.c_str());
+    return true;
+}
+
+}

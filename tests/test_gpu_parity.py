@@ -401,3 +401,18 @@ def test_full_size_config_3_rows_bit_exact(dev, oracle):
     for row in (200, 871):
         ref, _ = oracle.render(sc, s, block=(row * w, w))
         assert bits_equal(got[row], ref[row]), "row %d" % row
+
+
+@pytest.mark.parametrize("bits", [0, 4 | 16])
+def test_imported_obj_scene_bit_exact(dev, oracle, bits):
+    """Scope row f1: a scene that comes through importIntoScene (OBJ + MTL + PPM / PGM / PNG textures, bump
+    map converted to a normal map, alpha cut-out, transparent and emissive materials, a polygon, faces
+    without normals): GPU == oracle; with ImportBitTwoSidedMaterials | ImportBitWithGlass as well."""
+    import os
+    obj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "obj", "scene.obj")
+    sc = host.import_obj(obj, 64, 48, eye=(0.5, 2.2, 6.5), at=(0.0, 1.2, 0.0), import_bits=bits, env_radiance=0.05)
+    assert sc is not None and sc.d.tri_count == 25
+    ref, rc = oracle.render(sc, 5)
+    got, gc = dev.DeviceScene(sc).render(5, with_counters=True)
+    assert np.isfinite(got).all() and got.sum() > 0
+    assert bits_equal(got, ref) and gc == rc

@@ -185,3 +185,35 @@ def test_tga_pnm_pfm_hdr_decoders(tmp_path):
     f = tmp_path / "x.jpg"
     f.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
     assert host.image_load(str(f)) is None
+
+
+def _fixture_scene(import_bits=0, w=64, h=48):
+    return host.import_obj(os.path.join(OBJ_DIR, "scene.obj"), w, h, eye=(0.5, 2.2, 6.5), at=(0.0, 1.2, 0.0),
+                           import_bits=import_bits, env_radiance=0.05)
+
+
+def test_import_into_scene_structure_and_material_rules(oracle):
+    """importIntoScene on the fixture room (tests/golden/obj/scene.obj, written by make_scene_fixture.py):
+    one MeshInstance per (material, shape) in the serial order no-material, then MTL order; Lambertian
+    where nothing else is needed, ModPhong otherwise; emissive material -> hot spots; a missing Tf reads
+    as a transparent filter (import.hpp:305-311); an undecodable texture becomes the dummy texture; with
+    ImportBitTwoSidedMaterials | ImportBitWithGlass every material is wrapped and the pane is glass."""
+    from wurblpt_amd import _abi
+    sc = _fixture_scene()
+    d = sc.d
+    assert (d.tri_count, d.instance_count, d.hotspot_count) == (25, 9, 2)
+    types = [d.materials[i].type for i in range(d.material_count)]
+    assert types == [_abi.MAT_LAMBERTIAN] * 3 + [_abi.MAT_MODPHONG] * 5
+    assert d.texture_count == 5  # floor, floor bump->normal map, leaf, dummy, environment
+    floor = d.materials[1]
+    assert floor.normal_tex >= 0 and d.tri_geom[1].flags & 2  # the normal-mapped material gets tangents
+    lamp = d.materials[4]
+    assert tuple(lamp.v[3])[:3] == (18.0, 17.0, 15.0)
+    broken = d.materials[7]
+    assert broken.f[1] == 0.0  # opacity: missing Tf
+    img, cnt = oracle.render(sc, 4)
+    assert np.isfinite(img).all() and img.mean() > 0.05 and cnt["pdf_tests"] > 0
+    sc2 = _fixture_scene(host.IMPORT_TWO_SIDED_MATERIALS | host.IMPORT_WITH_GLASS)
+    types2 = [sc2.d.materials[i].type for i in range(sc2.d.material_count)]
+    assert types2.count(_abi.MAT_TWOSIDED) == 7 and types2.count(_abi.MAT_GLASS) == 1
+    assert host.import_obj(os.path.join(OBJ_DIR, "nothing_here.obj"), 8, 8, (0, 0, 1), (0, 0, 0)) is None

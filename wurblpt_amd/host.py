@@ -171,6 +171,21 @@ def measured_like(width, height, rgl0, rgl1, seed=3, detail=1.0, tex_size=1024, 
     return HostScene(h, width, height, "measured_like(seed=%d,detail=%g)" % (seed, detail))
 
 
+IMPORT_DISABLE_LIGHT_SOURCES, IMPORT_DISABLE_HOT_SPOTS, IMPORT_TWO_SIDED_MATERIALS, IMPORT_INVERTED_TF, IMPORT_WITH_GLASS = 1, 2, 4, 8, 16
+
+
+def import_obj(filename, width, height, eye, at, vfov_degrees=45.0, import_bits=0, scale=1.0, rotate_y_degrees=0.0, env_radiance=0.0):
+    """importIntoScene (include/wurblpt/import.hpp) of an OBJ file, an optional constant environment and a
+    look-at camera; None if the file cannot be imported."""
+    L = lib()
+    L.wpt_host_import_obj.restype = C.c_void_p
+    L.wpt_host_import_obj.argtypes = [C.c_char_p, C.c_uint, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_uint, C.c_uint]
+    e = (C.c_float * 3)(*eye)
+    a = (C.c_float * 3)(*at)
+    h = L.wpt_host_import_obj(filename.encode(), import_bits, scale, rotate_y_degrees, env_radiance, e, a, vfov_degrees, width, height)
+    return HostScene(h, width, height, "import_obj(%s)" % os.path.basename(filename)) if h else None
+
+
 def image_load(filename):
     """Decodes an image file with the importer's decoders: numpy array [h, w, comps], row 0 = bottom."""
     L = lib()

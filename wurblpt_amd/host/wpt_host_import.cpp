@@ -7,10 +7,17 @@
 #include <string>
 #include <vector>
 
+#include "../../include/wurblpt/camera.hpp"
 #include "../../include/wurblpt/imageio.hpp"
+#include "../../include/wurblpt/import.hpp"
+#include "../../include/wurblpt/sensor.hpp"
 #include "../../include/wurblpt/objreader.hpp"
 
 using namespace WurblPT;
+
+struct wpt_host_scene;
+wpt_host_scene* wptHostFinish(Scene* scene, unsigned int width, unsigned int height, float vfovRadians, const vec3& from,
+        const vec3& at, float aperture, float focusDist);
 
 namespace {
 
@@ -121,4 +128,23 @@ extern "C" unsigned long long wpt_host_image_load(const char* filename, unsigned
     if (data)
         memcpy(data, img.data(), img.dataSize() < capacity ? img.dataSize() : capacity);
     return img.dataSize();
+}
+
+/* importIntoScene (include/wurblpt/import.hpp) + a constant environment of the given radiance (0 = none)
+ * + a look-at camera.  rotateYDegrees / scale form the import transformation the way
+ * wurblpt-sponza.cpp:49-53 does. */
+extern "C" wpt_host_scene* wpt_host_import_obj(const char* objFile, unsigned int importBits, float scale, float rotateYDegrees,
+        float envRadiance, const float* eye, const float* at, float vfovDegrees, unsigned int width, unsigned int height)
+{
+    Scene* scene = new Scene;
+    const Transformation T(vec3(0.0f), toQuat(radians(rotateYDegrees), vec3(0.0f, 1.0f, 0.0f)), vec3(scale));
+    if (!importIntoScene(*scene, objFile, T, importBits)) {
+        delete scene;
+        return nullptr;
+    }
+    if (envRadiance > 0.0f) {
+        Texture* tex = scene->take(new TextureConstant(vec4(envRadiance)));
+        scene->take(new EnvironmentMapEquiRect(tex));
+    }
+    return wptHostFinish(scene, width, height, radians(vfovDegrees), vec3(eye), vec3(at), 0.0f, 1.0f);
 }
