@@ -1,7 +1,8 @@
 /*
  * camera.hpp -- camera description (reference camera.hpp:42-120).  Ray generation itself
  * (camera.hpp:123-185) runs in the HIP kernel from the wpt_camera record made here.
- * Surround / stereoscopic modes and camera animation are outside the device path.
+ * Surround / stereoscopic modes and camera animation are outside the device path; lens distortion
+ * and depth of field are part of the record.
  */
 #pragma once
 
@@ -36,7 +37,7 @@ public:
     /* false if this camera needs a feature the kernel does not have */
     bool describe(wpt_camera& out) const
     {
-        if (surroundMode != Surround_Off || stereoscopicDistance > 0.0f || optics.distortion.active)
+        if (surroundMode != Surround_Off || stereoscopicDistance > 0.0f)
             return false;
         out.l = optics.projection.l;
         out.r = optics.projection.r;
@@ -52,6 +53,17 @@ public:
         out.rotation[3] = transformation.rotation.w;
         out.lens_radius = optics.depthOfField.lensRadius;
         out.focus_dist = optics.depthOfField.focusDist;
+        /* LensDistortion and its helper (optics.hpp:203-212) */
+        const LensDistortion& ld = optics.distortion;
+        out.distortion_type = ld.type == LensDistortion::RadialAndPlanar ? WPT_DISTORTION_RADIAL_AND_PLANAR
+            : ld.type == LensDistortion::RadialOnly ? WPT_DISTORTION_RADIAL_ONLY
+            : ld.type == LensDistortion::OpenCV ? WPT_DISTORTION_OPENCV : WPT_DISTORTION_NONE;
+        out.k1 = ld.k1; out.k2 = ld.k2; out.k3 = ld.k3; out.p1 = ld.p1; out.p2 = ld.p2;
+        out.b1 = ld.b1; out.b2 = ld.b2; out.b3 = ld.b3; out.b4 = ld.b4;
+        const vec2 c = optics.projection.center(), f = optics.projection.focalLength(), fi = optics.projection.inverseFocalLength();
+        out.dist_center[0] = c.x(); out.dist_center[1] = c.y();
+        out.dist_focal_length[0] = f.x(); out.dist_focal_length[1] = f.y();
+        out.dist_inverse_focal_length[0] = fi.x(); out.dist_inverse_focal_length[1] = fi.y();
         return true;
     }
 };

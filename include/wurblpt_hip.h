@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define WPT_ABI_VERSION 3u
+#define WPT_ABI_VERSION 4u
 
 typedef enum {
     WPT_OK = 0,
@@ -246,6 +246,7 @@ typedef struct wpt_scene_desc {
 
 /* ---- camera, parameters ---------------------------------------------- */
 
+enum { WPT_DISTORTION_NONE = 0, WPT_DISTORTION_RADIAL_AND_PLANAR = 1, WPT_DISTORTION_RADIAL_ONLY = 2, WPT_DISTORTION_OPENCV = 3 };
 /* What Camera::getRay needs for a static pinhole / thin lens camera
  * (camera.hpp:123-185, optics.hpp:37-69,311-334, transformation.hpp:48-83). */
 typedef struct wpt_camera {
@@ -255,6 +256,12 @@ typedef struct wpt_camera {
     float scaling[3];
     float lens_radius;
     float focus_dist;
+    /* LensDistortion (optics.hpp:112-309) and its per-frame helper (:203-212, from the projection):
+     * undistort() maps the distorted image coordinates of a sample to the ones a ray is made from */
+    uint32_t distortion_type; /* WPT_DISTORTION_* */
+    float k1, k2, k3, p1, p2;
+    float b1, b2, b3, b4;     /* RadialOnly: coefficients of the exact inverse (:176-180) */
+    float dist_center[2], dist_focal_length[2], dist_inverse_focal_length[2];
 } wpt_camera;
 
 /* Parameters (wurblpt.hpp:79-96) plus the SensorRGB gates (sensor_rgb.hpp:41-51). */

@@ -506,6 +506,52 @@ int main(int argc, char* argv[])
         }
     }
 
+    /* ---- LensDistortion (optics.hpp:112-309): undistort, distort of the result, and Camera::getRay
+     * through it, for the three models on an off-centre projection ---- */
+    {
+        const unsigned int W = 640, H = 480;
+        Projection proj(W, H, vec2(311.5f, 250.25f), vec2(520.0f, 515.0f));
+        LensDistortion models[3] = { LensDistortion(-0.21f, 0.07f, 0.0012f, -0.0009f), LensDistortion(-0.18f, 0.05f, -0.01f),
+            LensDistortion(-0.25f, 0.09f, -0.015f, 0.0011f, -0.0007f) };
+        const char* names[3] = { "radial_and_planar", "radial_only", "opencv" };
+        for (int m = 0; m < 3; m++) {
+            LensDistortion::Helper helper = models[m].getHelper(proj, W, H);
+            Optics optics(proj, models[m], LensDepthOfField());
+            Camera camera(optics, Transformation::fromLookAt(vec3(0.5f, 1.0f, 3.0f), vec3(0.0f, 0.8f, -1.0f), vec3(0.0f, 1.0f, 0.0f)));
+            Camera::RayHelper rh = camera.getRayHelper(0.0f, W, H);
+            Prng prng(0);
+            std::vector<float> pq, und, rays;
+            for (int j = 0; j < 12; j++)
+                for (int i = 0; i < 16; i++) {
+                    float p = (i + 0.41f) / 16.0f, q = (j + 0.67f) / 12.0f;
+                    pq.push_back(p);
+                    pq.push_back(q);
+                    float up = p, uq = q;
+                    models[m].undistort(up, uq, helper);
+                    und.push_back(up);
+                    und.push_back(uq);
+                    models[m].distort(up, uq, helper);
+                    und.push_back(up);
+                    und.push_back(uq);
+                    Ray r = camera.getRay(p, q, 0.0f, 0.0f, rh, prng);
+                    push3(rays, r.origin);
+                    push3(rays, r.direction);
+                }
+            std::vector<float> desc = { proj.l, proj.r, proj.b, proj.t,
+                camera.transformation.translation.x(), camera.transformation.translation.y(), camera.transformation.translation.z(),
+                camera.transformation.rotation.x, camera.transformation.rotation.y, camera.transformation.rotation.z, camera.transformation.rotation.w,
+                camera.transformation.scaling.x(), camera.transformation.scaling.y(), camera.transformation.scaling.z(),
+                float(int(models[m].type)), models[m].k1, models[m].k2, models[m].k3, models[m].p1, models[m].p2,
+                models[m].b1, models[m].b2, models[m].b3, models[m].b4,
+                helper.center.x(), helper.center.y(), helper.focalLength.x(), helper.focalLength.y(),
+                helper.inverseFocalLength.x(), helper.inverseFocalLength.y(), float(W), float(H) };
+            floats((std::string("lens_") + names[m] + "_desc").c_str(), desc);
+            floats((std::string("lens_") + names[m] + "_pq").c_str(), pq);
+            floats((std::string("lens_") + names[m] + "_undistort_distort").c_str(), und);
+            floats((std::string("lens_") + names[m] + "_rays").c_str(), rays);
+        }
+    }
+
     /* ---- computeTangents / computeNormals (geometryproc.hpp:58-226) ---- */
     {
         /* a Cornell wall quad and a small random indexed mesh */

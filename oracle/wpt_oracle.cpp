@@ -33,6 +33,7 @@
 
 #include "../include/wurblpt_hip.h"
 #include "../wurblpt_amd/csrc/wpt_rgl.h"
+#include "../wurblpt_amd/csrc/wpt_lens.h"
 #include "../wurblpt_amd/csrc/wpt_math.h"
 
 namespace {
@@ -1507,9 +1508,11 @@ void tracePath(Ctx& c, float* sampleAccumulator, const Ray& startRay, size_t hot
     }
 }
 
-/* ---- camera.hpp:123-185 (Surround_Off, no lens distortion, no stereo, t0 == t1) ---- */
-inline Ray cameraGetRay(const wpt_camera& cam, float p, float q, Prng& prng)
+/* ---- camera.hpp:123-185 (Surround_Off, no stereo, t0 == t1) ---- */
+inline Ray cameraGetRay(const wpt_camera& cam, float p, float q, Prng& prng, uint32_t width = 1, uint32_t height = 1)
 {
+    if (cam.distortion_type != WPT_DISTORTION_NONE) /* camera.hpp:143-144 */
+        wptlens::undistort(cam, p, q, width, height);
     V3 P = V3 { mix_(cam.l, cam.r, p), mix_(cam.b, cam.t, q), -1.0f };
     V3 O = v3(0.0f);
     if (cam.lens_radius > 0.0f) { /* optics.hpp:326-334 */
@@ -1575,7 +1578,7 @@ int wpt_oracle_render(const wpt_scene_desc* scene, const wpt_camera* camera, con
                     uv = uv + V2 { 0.5f, 0.5f };
                 }
                 uv = uv * invSize;
-                Ray r = cameraGetRay(*camera, uv.x, uv.y, prng);
+                Ray r = cameraGetRay(*camera, uv.x, uv.y, prng, width, height);
                 c.cnt.samples++;
                 tracePath(c, sampleAccumulator, r, hotSpotsSize, invHotSpotsSize, prng);
             }
@@ -1741,6 +1744,32 @@ void wpt_oracle_rgl(const wpt_rgl_brdf* brdf, const float* pool, int n, const fl
         float* eo = eval_out + 4 * i;
         eo[0] = e.x; eo[1] = e.y; eo[2] = e.z;
         eo[3] = wptrgl::rglPdf<OracleMath>(*brdf, pool, wi, wo);
+    }
+}
+
+/* LensDistortion::undistort then ::distort of the result (optics.hpp:214-308): pq -> 4 floats per point */
+void wpt_oracle_lens(const wpt_camera* cam, uint32_t width, uint32_t height, int n, const float* pq, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        float p = pq[2 * i], q = pq[2 * i + 1];
+        wptlens::undistort(*cam, p, q, width, height);
+        out[4 * i] = p;
+        out[4 * i + 1] = q;
+        wptlens::distort(*cam, p, q);
+        out[4 * i + 2] = p;
+        out[4 * i + 3] = q;
+    }
+}
+
+/* Camera::getRay with the frame size (needed by the iterative undistortion): origin, direction */
+void wpt_oracle_camera_rays_sized(const wpt_camera* cam, uint32_t width, uint32_t height, int n, const float* pq, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        Prng prng { uint32_t(i) };
+        Ray r = cameraGetRay(*cam, pq[2 * i], pq[2 * i + 1], prng, width, height);
+        float* o = out + 6 * i;
+        o[0] = r.origin.x; o[1] = r.origin.y; o[2] = r.origin.z;
+        o[3] = r.direction.x; o[4] = r.direction.y; o[5] = r.direction.z;
     }
 }
 

@@ -416,3 +416,21 @@ def test_imported_obj_scene_bit_exact(dev, oracle, bits):
     got, gc = dev.DeviceScene(sc).render(5, with_counters=True)
     assert np.isfinite(got).all() and got.sum() > 0
     assert bits_equal(got, ref) and gc == rc
+
+
+@pytest.mark.parametrize("model,args", [(1, dict(k1=-0.21, k2=0.07, p1=0.0012, p2=-0.0009)), (2, dict(k1=-0.18, k2=0.05, k3=-0.01)),
+                                        (3, dict(k1=-0.25, k2=0.09, k3=-0.015, p1=0.0011, p2=-0.0007))])
+def test_lens_distortion_bit_exact(dev, oracle, model, args):
+    """Camera::getRay with LensDistortion (RadialAndPlanar, RadialOnly, OpenCV with its iteration; pinned to the
+    reference's optics.hpp by tests/test_oracle_golden.py): the Cornell frame through a distorting lens,
+    with and without a thin lens on top, GPU == oracle."""
+    for aperture in (0.0, 0.08):
+        sc = host.cornell(64, 48, 1, 2) if aperture == 0.0 else host.random_triangles(300, 4, 64, 48, True, aperture)
+        plain, _ = oracle.render(sc, 3)
+        host.set_distortion(sc, model, **args)
+        ref, rc = oracle.render(sc, 3)
+        assert not bits_equal(ref, plain)
+        got, gc = dev.DeviceScene(sc).render(3, with_counters=True)
+        assert bits_equal(got, ref) and gc == rc
+        got2, _ = dev.DeviceScene(sc).render(3)
+        assert bits_equal(got2, ref)

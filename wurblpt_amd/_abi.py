@@ -5,7 +5,7 @@ against values compiled from the header.
 """
 import ctypes as C
 
-WPT_ABI_VERSION = 3
+WPT_ABI_VERSION = 4
 WPT_OK = 0
 
 NODE_INNER, NODE_TRIANGLE, NODE_SPHERE, NODE_EMPTY = 0, 1, 2, 3
@@ -84,7 +84,10 @@ class SceneDesc(C.Structure):
 class Camera(C.Structure):
     _fields_ = [("l", C.c_float), ("r", C.c_float), ("b", C.c_float), ("t", C.c_float),
                 ("translation", C.c_float * 3), ("rotation", C.c_float * 4), ("scaling", C.c_float * 3),
-                ("lens_radius", C.c_float), ("focus_dist", C.c_float)]
+                ("lens_radius", C.c_float), ("focus_dist", C.c_float),
+                ("distortion_type", C.c_uint32), ("k1", C.c_float), ("k2", C.c_float), ("k3", C.c_float), ("p1", C.c_float),
+                ("p2", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("b3", C.c_float), ("b4", C.c_float),
+                ("dist_center", C.c_float * 2), ("dist_focal_length", C.c_float * 2), ("dist_inverse_focal_length", C.c_float * 2)]
 
 
 class Params(C.Structure):
@@ -104,6 +107,6 @@ class Counters(C.Structure):
 STRUCT_SIZES = {
     "wpt_bvh_node": (BvhNode, 32), "wpt_tri_geom": (TriGeom, 48), "wpt_tri_attr": (TriAttr, 96),
     "wpt_instance": (Instance, 48), "wpt_sphere": (Sphere, 48), "wpt_hotspot": (Hotspot, 116), "wpt_material": (Material, 128),
-    "wpt_texture": (Texture, 88), "wpt_rgl_warp": (RglWarp, 76), "wpt_rgl_brdf": (RglBrdf, 388), "wpt_camera": (Camera, 64), "wpt_params": (Params, 32),
+    "wpt_texture": (Texture, 88), "wpt_rgl_warp": (RglWarp, 76), "wpt_rgl_brdf": (RglBrdf, 388), "wpt_camera": (Camera, 128), "wpt_params": (Params, 32),
     "wpt_counters": (Counters, 48),
 }

@@ -15,6 +15,7 @@
 #define WPT_BLOCKS_H
 
 #include "wpt_device.h"
+#include "wpt_lens.h"
 
 namespace wptk {
 
@@ -202,6 +203,10 @@ WPT_D int blockNew(const FrameArgs& fa, PathState& ps)
     }
     u *= 1.0f / (float)fa.width;
     v *= 1.0f / (float)fa.height;
+    /* the samples lie in the distorted output image: rays are made from the undistorted coordinates
+     * (camera.hpp:143-144) */
+    if ((F & FEAT_LENS) && fa.cam.distortion_type != WPT_DISTORTION_NONE)
+        wptlens::undistort(fa.cam, u, v, fa.width, fa.height);
     f3 P = mk3(mixr(fa.cam.l, fa.cam.r, u), mixr(fa.cam.b, fa.cam.t, v), -1.0f);
     f3 O = mk3(0.0f, 0.0f, 0.0f);
     if ((F & FEAT_LENS) && fa.cam.lens_radius > 0.0f) {

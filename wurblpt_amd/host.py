@@ -72,6 +72,7 @@ class HostScene:
         self.width, self.height, self.name = width, height, name
         self.desc = lib().wpt_host_scene_desc(handle)
         self.camera = lib().wpt_host_scene_camera(handle)
+        self._handle_for_camera = handle
         self.bvh_levels = lib().wpt_host_scene_bvh_levels(handle)
 
     def __del__(self):
@@ -93,6 +94,15 @@ class HostScene:
     def nodes_array(self):
         n = self.d.node_count
         return np.ctypeslib.as_array(C.cast(self.d.nodes, C.POINTER(C.c_uint32)), shape=(n, 8)).copy()
+
+
+def set_distortion(scene, model, k1=0.0, k2=0.0, k3=0.0, p1=0.0, p2=0.0):
+    """Lens distortion for the scene's camera: model 1 RadialAndPlanar(k1,k2,p1,p2), 2 RadialOnly(k1,k2,k3),
+    3 OpenCV(k1,k2,k3,p1,p2), 0 none."""
+    L = lib()
+    L.wpt_host_scene_set_distortion.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.wpt_host_scene_set_distortion.restype = None
+    L.wpt_host_scene_set_distortion(scene._handle_for_camera, model, k1, k2, k3, p1, p2)
 
 
 def cornell(width, height, tall_box_material=0, short_object_material=0):

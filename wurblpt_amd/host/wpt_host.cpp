@@ -243,6 +243,26 @@ wpt_host_scene* wpt_host_random_triangles(unsigned int n, unsigned int seed, int
     return finishScene(hs, width, height, radians(60.0f), vec3(0.3f, 0.4f, 3.5f), vec3(0.0f, 0.0f, 0.0f), aperture, 3.5f);
 }
 
+/* Gives the scene's camera a lens distortion: model 1 = RadialAndPlanar(k1, k2, p1, p2), 2 = RadialOnly(k1, k2, k3),
+ * 3 = OpenCV(k1, k2, k3, p1, p2), 0 = none; constructors and helper of optics.hpp:155-212 */
+void wpt_host_scene_set_distortion(wpt_host_scene* hs, int model, float k1, float k2, float k3, float p1, float p2)
+{
+    wpt_camera& c = hs->camera;
+    const Projection proj(c.l, c.r, c.b, c.t);
+    const LensDistortion ld = model == 1 ? LensDistortion(k1, k2, p1, p2) : model == 2 ? LensDistortion(k1, k2, k3)
+        : model == 3 ? LensDistortion(k1, k2, k3, p1, p2) : LensDistortion();
+    Camera cam(Optics(proj, ld, LensDepthOfField(2.0f * c.lens_radius, c.focus_dist)),
+            Transformation(vec3(c.translation), quat(c.rotation[0], c.rotation[1], c.rotation[2], c.rotation[3]), vec3(c.scaling)));
+    wpt_camera out;
+    memset(&out, 0, sizeof(out));
+    if (cam.describe(out)) {
+        /* keep the depth-of-field values bit for bit */
+        out.lens_radius = c.lens_radius;
+        out.focus_dist = c.focus_dist;
+        c = out;
+    }
+}
+
 const wpt_scene_desc* wpt_host_scene_desc(const wpt_host_scene* hs) { return &hs->desc; }
 const wpt_camera* wpt_host_scene_camera(const wpt_host_scene* hs) { return &hs->camera; }
 unsigned int wpt_host_scene_bvh_levels(const wpt_host_scene* hs) { return hs->flat.bvhLevels; }
