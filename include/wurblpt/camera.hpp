@@ -1,8 +1,8 @@
 /*
  * camera.hpp -- camera description (reference camera.hpp:42-120).  Ray generation itself
  * (camera.hpp:123-185) runs in the HIP kernel from the wpt_camera record made here.
- * Surround / stereoscopic modes and camera animation are outside the device path; lens distortion
- * and depth of field are part of the record.
+ * Camera animation is outside the device path; surround and stereoscopic modes, lens distortion and
+ * depth of field are part of the record.
  */
 #pragma once
 
@@ -37,8 +37,8 @@ public:
     /* false if this camera needs a feature the kernel does not have */
     bool describe(wpt_camera& out) const
     {
-        if (surroundMode != Surround_Off || stereoscopicDistance > 0.0f)
-            return false;
+        out.surround_mode = surroundMode == Surround_180 ? WPT_SURROUND_180 : surroundMode == Surround_360 ? WPT_SURROUND_360 : WPT_SURROUND_OFF;
+        out.stereoscopic_distance = stereoscopicDistance;
         out.l = optics.projection.l;
         out.r = optics.projection.r;
         out.b = optics.projection.b;

@@ -75,7 +75,7 @@ inline void mcpt(MPICoordinator& mpiCoordinator, Sensor& sensor, const Camera& c
         mcptFatal("only SensorRGB runs on the device path");
     wpt_camera cam;
     if (!camera.describe(cam))
-        mcptFatal("this camera mode (surround / stereo) is outside the device path");
+        mcptFatal("this camera cannot be described to the device path");
     FlatScene flat;
     std::string error;
     if (!scene.flatten(flat, &error))

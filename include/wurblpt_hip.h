@@ -246,6 +246,7 @@ typedef struct wpt_scene_desc {
 
 /* ---- camera, parameters ---------------------------------------------- */
 
+enum { WPT_SURROUND_OFF = 0, WPT_SURROUND_180 = 1, WPT_SURROUND_360 = 2 };
 enum { WPT_DISTORTION_NONE = 0, WPT_DISTORTION_RADIAL_AND_PLANAR = 1, WPT_DISTORTION_RADIAL_ONLY = 2, WPT_DISTORTION_OPENCV = 3 };
 /* What Camera::getRay needs for a static pinhole / thin lens camera
  * (camera.hpp:123-185, optics.hpp:37-69,311-334, transformation.hpp:48-83). */
@@ -262,6 +263,10 @@ typedef struct wpt_camera {
     float k1, k2, k3, p1, p2;
     float b1, b2, b3, b4;     /* RadialOnly: coefficients of the exact inverse (:176-180) */
     float dist_center[2], dist_focal_length[2], dist_inverse_focal_length[2];
+    /* Camera::surroundMode and ::stereoscopicDistance (camera.hpp:45-52,128-170): 180 / 360 degree
+     * cameras ignore the optics; a stereoscopic camera renders the left view into the upper half */
+    uint32_t surround_mode; /* WPT_SURROUND_* */
+    float stereoscopic_distance;
 } wpt_camera;
 
 /* Parameters (wurblpt.hpp:79-96) plus the SensorRGB gates (sensor_rgb.hpp:41-51). */

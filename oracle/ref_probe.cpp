@@ -552,6 +552,37 @@ int main(int argc, char* argv[])
         }
     }
 
+    /* ---- Camera::getRay in the surround and stereoscopic modes (camera.hpp:128-170) ---- */
+    {
+        const struct { Camera::SurroundMode mode; float stereo; const char* name; } modes[4] = {
+            { Camera::Surround_180, 0.0f, "surround180" }, { Camera::Surround_360, 0.0f, "surround360" },
+            { Camera::Surround_360, 0.065f, "surround360_stereo" }, { Camera::Surround_Off, 0.065f, "stereo" } };
+        for (const auto& md : modes) {
+            Optics optics(Projection(radians(50.0f), 1.5f), LensDistortion(), LensDepthOfField());
+            Camera camera(md.mode, md.stereo, optics, Transformation::fromLookAt(vec3(0.5f, 1.0f, 3.0f), vec3(0.0f, 0.8f, -1.0f), vec3(0.0f, 1.0f, 0.0f)));
+            Camera::RayHelper rh = camera.getRayHelper(0.0f, 96, 64);
+            Prng prng(0);
+            std::vector<float> pq, rays;
+            for (int j = 0; j < 12; j++)
+                for (int i = 0; i < 16; i++) {
+                    float p = (i + 0.41f) / 16.0f, q = (j + 0.67f) / 12.0f;
+                    pq.push_back(p);
+                    pq.push_back(q);
+                    Ray r = camera.getRay(p, q, 0.0f, 0.0f, rh, prng);
+                    push3(rays, r.origin);
+                    push3(rays, r.direction);
+                }
+            std::vector<float> desc = { optics.projection.l, optics.projection.r, optics.projection.b, optics.projection.t,
+                camera.transformation.translation.x(), camera.transformation.translation.y(), camera.transformation.translation.z(),
+                camera.transformation.rotation.x, camera.transformation.rotation.y, camera.transformation.rotation.z, camera.transformation.rotation.w,
+                camera.transformation.scaling.x(), camera.transformation.scaling.y(), camera.transformation.scaling.z(),
+                float(int(md.mode)), md.stereo };
+            floats((std::string("camera_") + md.name + "_desc").c_str(), desc);
+            floats((std::string("camera_") + md.name + "_pq").c_str(), pq);
+            floats((std::string("camera_") + md.name + "_rays").c_str(), rays);
+        }
+    }
+
     /* ---- computeTangents / computeNormals (geometryproc.hpp:58-226) ---- */
     {
         /* a Cornell wall quad and a small random indexed mesh */

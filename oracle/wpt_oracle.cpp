@@ -1511,17 +1511,37 @@ void tracePath(Ctx& c, float* sampleAccumulator, const Ray& startRay, size_t hot
 /* ---- camera.hpp:123-185 (Surround_Off, no stereo, t0 == t1) ---- */
 inline Ray cameraGetRay(const wpt_camera& cam, float p, float q, Prng& prng, uint32_t width = 1, uint32_t height = 1)
 {
-    if (cam.distortion_type != WPT_DISTORTION_NONE) /* camera.hpp:143-144 */
-        wptlens::undistort(cam, p, q, width, height);
-    V3 P = V3 { mix_(cam.l, cam.r, p), mix_(cam.b, cam.t, q), -1.0f };
-    V3 O = v3(0.0f);
-    if (cam.lens_radius > 0.0f) { /* optics.hpp:326-334 */
-        P = P * v3(cam.focus_dist);
-        V2 d = cam.lens_radius * inUnitDisk(prng.in01x2());
-        O = V3 { d.x, d.y, 0.0f };
+    float stereoscopicShift = 0.0f;
+    if (cam.stereoscopic_distance > 0.0f) { /* camera.hpp:128-138 */
+        q *= 2.0f;
+        if (q < 1.0f) {
+            stereoscopicShift = -0.5f * cam.stereoscopic_distance;
+        } else {
+            q -= 1.0f;
+            stereoscopicShift = +0.5f * cam.stereoscopic_distance;
+        }
     }
-    V3 D = P - O;
-    O = O + V3 { 0.0f, 0.0f, 0.0f };
+    V3 O, D;
+    if (cam.surround_mode == WPT_SURROUND_OFF) {
+        if (cam.distortion_type != WPT_DISTORTION_NONE) /* camera.hpp:143-144 */
+            wptlens::undistort(cam, p, q, width, height);
+        V3 P = V3 { mix_(cam.l, cam.r, p), mix_(cam.b, cam.t, q), -1.0f };
+        O = v3(0.0f);
+        if (cam.lens_radius > 0.0f) { /* optics.hpp:326-334 */
+            P = P * v3(cam.focus_dist);
+            V2 d = cam.lens_radius * inUnitDisk(prng.in01x2());
+            O = V3 { d.x, d.y, 0.0f };
+        }
+        D = P - O;
+        O = O + V3 { stereoscopicShift, 0.0f, 0.0f };
+    } else { /* camera.hpp:158-170 */
+        float lon = (2.0f * p - 1.0f) * k_pi;
+        if (cam.surround_mode == WPT_SURROUND_180)
+            lon *= 0.5f;
+        float lat = (q - 0.5f) * k_pi;
+        D = V3 { m_cos(lat) * m_sin(lon), m_sin(lat), -m_cos(lat) * m_cos(lon) };
+        O = V3 { -m_cos(lon), 0.0f, -m_sin(lon) } * stereoscopicShift;
+    }
     V3 origin = v3(cam.translation) + quat_rotate(cam.rotation, O * v3(cam.scaling)); /* transformation.hpp:80-83 */
     V3 direction = quat_rotate(cam.rotation, D);
     return Ray { origin, normalize(direction), 0.0f, v4(1.0f) };

@@ -434,3 +434,17 @@ def test_lens_distortion_bit_exact(dev, oracle, model, args):
         assert bits_equal(got, ref) and gc == rc
         got2, _ = dev.DeviceScene(sc).render(3)
         assert bits_equal(got2, ref)
+
+
+@pytest.mark.parametrize("surround,stereo", [(1, 0.0), (2, 0.0), (2, 0.065), (0, 0.065)])
+def test_surround_and_stereo_cameras_bit_exact(dev, oracle, surround, stereo):
+    """180 / 360 degree and stereoscopic cameras (camera.hpp:128-170) from inside the Cornell box: GPU == oracle."""
+    sc = host.cornell(64, 64 if surround != 2 else 32, 1, 2)
+    plain, _ = oracle.render(sc, 3)
+    host.set_camera_mode(sc, surround, stereo)
+    ref, rc = oracle.render(sc, 3)
+    assert not bits_equal(ref, plain)
+    got, gc = dev.DeviceScene(sc).render(3, with_counters=True)
+    assert bits_equal(got, ref) and gc == rc
+    got2, _ = dev.DeviceScene(sc).render(3)
+    assert bits_equal(got2, ref)

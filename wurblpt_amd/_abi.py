@@ -87,7 +87,8 @@ class Camera(C.Structure):
                 ("lens_radius", C.c_float), ("focus_dist", C.c_float),
                 ("distortion_type", C.c_uint32), ("k1", C.c_float), ("k2", C.c_float), ("k3", C.c_float), ("p1", C.c_float),
                 ("p2", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("b3", C.c_float), ("b4", C.c_float),
-                ("dist_center", C.c_float * 2), ("dist_focal_length", C.c_float * 2), ("dist_inverse_focal_length", C.c_float * 2)]
+                ("dist_center", C.c_float * 2), ("dist_focal_length", C.c_float * 2), ("dist_inverse_focal_length", C.c_float * 2),
+                ("surround_mode", C.c_uint32), ("stereoscopic_distance", C.c_float)]
 
 
 class Params(C.Structure):
@@ -107,6 +108,6 @@ class Counters(C.Structure):
 STRUCT_SIZES = {
     "wpt_bvh_node": (BvhNode, 32), "wpt_tri_geom": (TriGeom, 48), "wpt_tri_attr": (TriAttr, 96),
     "wpt_instance": (Instance, 48), "wpt_sphere": (Sphere, 48), "wpt_hotspot": (Hotspot, 116), "wpt_material": (Material, 128),
-    "wpt_texture": (Texture, 88), "wpt_rgl_warp": (RglWarp, 76), "wpt_rgl_brdf": (RglBrdf, 388), "wpt_camera": (Camera, 128), "wpt_params": (Params, 32),
+    "wpt_texture": (Texture, 88), "wpt_rgl_warp": (RglWarp, 76), "wpt_rgl_brdf": (RglBrdf, 388), "wpt_camera": (Camera, 136), "wpt_params": (Params, 32),
     "wpt_counters": (Counters, 48),
 }

@@ -203,19 +203,41 @@ WPT_D int blockNew(const FrameArgs& fa, PathState& ps)
     }
     u *= 1.0f / (float)fa.width;
     v *= 1.0f / (float)fa.height;
-    /* the samples lie in the distorted output image: rays are made from the undistorted coordinates
-     * (camera.hpp:143-144) */
-    if ((F & FEAT_LENS) && fa.cam.distortion_type != WPT_DISTORTION_NONE)
-        wptlens::undistort(fa.cam, u, v, fa.width, fa.height);
-    f3 P = mk3(mixr(fa.cam.l, fa.cam.r, u), mixr(fa.cam.b, fa.cam.t, v), -1.0f);
-    f3 O = mk3(0.0f, 0.0f, 0.0f);
-    if ((F & FEAT_LENS) && fa.cam.lens_radius > 0.0f) {
-        P = sclr(P, fa.cam.focus_dist);
-        f2 d = inUnitDisk(in01x2(ps.prng));
-        O = mk3(fa.cam.lens_radius * d.x, fa.cam.lens_radius * d.y, 0.0f);
+    /* Camera::getRay (camera.hpp:123-185) */
+    float stereoscopicShift = 0.0f;
+    if ((F & FEAT_LENS) && fa.cam.stereoscopic_distance > 0.0f) {
+        v *= 2.0f; /* left view in the upper half, right view in the lower half */
+        if (v < 1.0f) {
+            stereoscopicShift = -0.5f * fa.cam.stereoscopic_distance;
+        } else {
+            v -= 1.0f;
+            stereoscopicShift = +0.5f * fa.cam.stereoscopic_distance;
+        }
     }
-    f3 D = sub(P, O);
-    O = add(O, mk3(0.0f, 0.0f, 0.0f));
+    f3 O, D;
+    if ((F & FEAT_LENS) && fa.cam.surround_mode != WPT_SURROUND_OFF) {
+        /* direction from longitude and latitude; the optics are ignored */
+        float lon = (2.0f * u - 1.0f) * k_pi;
+        if (fa.cam.surround_mode == WPT_SURROUND_180)
+            lon *= 0.5f;
+        const float lat = (v - 0.5f) * k_pi;
+        const float clat = wptm::cosf_(lat), slat = wptm::sinf_(lat), clon = wptm::cosf_(lon), slon = wptm::sinf_(lon);
+        D = mk3(clat * slon, slat, -clat * clon);
+        O = sclr(mk3(-clon, 0.0f, -slon), stereoscopicShift);
+    } else {
+        /* the samples lie in the distorted output image: rays are made from the undistorted coordinates */
+        if ((F & FEAT_LENS) && fa.cam.distortion_type != WPT_DISTORTION_NONE)
+            wptlens::undistort(fa.cam, u, v, fa.width, fa.height);
+        f3 P = mk3(mixr(fa.cam.l, fa.cam.r, u), mixr(fa.cam.b, fa.cam.t, v), -1.0f);
+        O = mk3(0.0f, 0.0f, 0.0f);
+        if ((F & FEAT_LENS) && fa.cam.lens_radius > 0.0f) {
+            P = sclr(P, fa.cam.focus_dist);
+            f2 d = inUnitDisk(in01x2(ps.prng));
+            O = mk3(fa.cam.lens_radius * d.x, fa.cam.lens_radius * d.y, 0.0f);
+        }
+        D = sub(P, O);
+        O = add(O, mk3(stereoscopicShift, 0.0f, 0.0f));
+    }
     ps.ray.o = add(ld3(fa.cam.translation), quatRotate(fa.cam.rotation, mul(O, ld3(fa.cam.scaling))));
     ps.ray.d = normalize(quatRotate(fa.cam.rotation, D));
     ps.ray.ri = mk4(1.0f, 1.0f, 1.0f, 1.0f);

@@ -588,7 +588,10 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
 
     /* a wave covers an 8x8 pixel tile when the block consists of whole groups of 8 rows */
     args.tiled = (width % 8 == 0 && block_start % width == 0 && block_size % (8 * width) == 0) ? 1u : 0u;
-    uint32_t need = scene->features | ((camera->lens_radius > 0.0f || camera->distortion_type != WPT_DISTORTION_NONE) ? FEAT_LENS : 0u);
+    uint32_t need = scene->features | ((camera->lens_radius > 0.0f || camera->distortion_type != WPT_DISTORTION_NONE
+                || camera->surround_mode != WPT_SURROUND_OFF || camera->stereoscopic_distance > 0.0f) ? FEAT_LENS : 0u);
+    if (camera->surround_mode > WPT_SURROUND_360)
+        return fail(WPT_ERR_UNSUPPORTED, "camera surround mode is not known to the kernel");
     if (camera->distortion_type > WPT_DISTORTION_OPENCV)
         return fail(WPT_ERR_UNSUPPORTED, "lens distortion model is not known to the kernel");
     dim3 grid((block_size + WG - 1) / WG);

@@ -105,6 +105,14 @@ def set_distortion(scene, model, k1=0.0, k2=0.0, k3=0.0, p1=0.0, p2=0.0):
     L.wpt_host_scene_set_distortion(scene._handle_for_camera, model, k1, k2, k3, p1, p2)
 
 
+def set_camera_mode(scene, surround_mode=0, stereoscopic_distance=0.0):
+    """Camera::surroundMode (0 off, 1 = 180 degrees, 2 = 360 degrees) and ::stereoscopicDistance."""
+    L = lib()
+    L.wpt_host_scene_set_camera_mode.argtypes = [C.c_void_p, C.c_int, C.c_float]
+    L.wpt_host_scene_set_camera_mode.restype = None
+    L.wpt_host_scene_set_camera_mode(scene._handle_for_camera, surround_mode, stereoscopic_distance)
+
+
 def cornell(width, height, tall_box_material=0, short_object_material=0):
     """Cornell box of wurblpt-cornellbox.cpp: tall box 0 = white / 1 = GGX metal,
     short box 0 = white / 2 = glass."""

@@ -263,6 +263,13 @@ void wpt_host_scene_set_distortion(wpt_host_scene* hs, int model, float k1, floa
     }
 }
 
+/* Camera::surroundMode (0 off, 1 = 180 degrees, 2 = 360 degrees) and ::stereoscopicDistance of the scene's camera */
+void wpt_host_scene_set_camera_mode(wpt_host_scene* hs, int surroundMode, float stereoscopicDistance)
+{
+    hs->camera.surround_mode = surroundMode == 1 ? WPT_SURROUND_180 : surroundMode == 2 ? WPT_SURROUND_360 : WPT_SURROUND_OFF;
+    hs->camera.stereoscopic_distance = stereoscopicDistance;
+}
+
 const wpt_scene_desc* wpt_host_scene_desc(const wpt_host_scene* hs) { return &hs->desc; }
 const wpt_camera* wpt_host_scene_camera(const wpt_host_scene* hs) { return &hs->camera; }
 unsigned int wpt_host_scene_bvh_levels(const wpt_host_scene* hs) { return hs->flat.bvhLevels; }
