@@ -539,6 +539,181 @@ inline bool loadHdr(const std::vector<unsigned char>& b, ArrayContainer& img, st
 
 }
 
+namespace imagedetail {
+
+inline uint32_t crc32(uint32_t crc, const unsigned char* p, size_t n)
+{
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++)
+                c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++)
+        crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return ~crc;
+}
+
+inline void putBe32(std::vector<unsigned char>& out, uint32_t v)
+{
+    out.push_back(v >> 24);
+    out.push_back((v >> 16) & 0xffu);
+    out.push_back((v >> 8) & 0xffu);
+    out.push_back(v & 0xffu);
+}
+
+inline void pngChunk(std::vector<unsigned char>& out, const char* type, const std::vector<unsigned char>& payload)
+{
+    putBe32(out, uint32_t(payload.size()));
+    const size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), payload.begin(), payload.end());
+    putBe32(out, crc32(0, out.data() + start, out.size() - start));
+}
+
+/* PNG with stored (uncompressed) deflate blocks: every decoder reads it, no compressor needed. */
+inline bool savePng(const ArrayContainer& img, std::vector<unsigned char>& out, std::string& error)
+{
+    const size_t w = img.dimension(0), h = img.dimension(1), comps = img.componentCount();
+    if (w == 0 || h == 0 || comps < 1 || comps > 4 || img.componentType() == float32) {
+        error = "PNG takes 1-4 components of uint8 or uint16";
+        return false;
+    }
+    const size_t cs = img.componentSize();
+    static const unsigned char colorType[5] = { 0, 0, 4, 2, 6 };
+    out.assign({ 0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n' });
+    std::vector<unsigned char> ihdr;
+    putBe32(ihdr, uint32_t(w));
+    putBe32(ihdr, uint32_t(h));
+    ihdr.push_back(cs == 1 ? 8 : 16);
+    ihdr.push_back(colorType[comps]);
+    ihdr.push_back(0);
+    ihdr.push_back(0);
+    ihdr.push_back(0);
+    pngChunk(out, "IHDR", ihdr);
+    /* scanlines top to bottom (array row 0 is the bottom one), filter type 0, samples big endian */
+    const size_t rowBytes = w * comps * cs;
+    std::vector<unsigned char> raw;
+    raw.reserve((rowBytes + 1) * h);
+    for (size_t y = 0; y < h; y++) {
+        const unsigned char* row = static_cast<const unsigned char*>(img.data()) + (h - 1 - y) * rowBytes;
+        raw.push_back(0);
+        if (cs == 1) {
+            raw.insert(raw.end(), row, row + rowBytes);
+        } else {
+            for (size_t i = 0; i < rowBytes; i += 2) {
+                uint16_t v;
+                memcpy(&v, row + i, 2);
+                raw.push_back(v >> 8);
+                raw.push_back(v & 0xffu);
+            }
+        }
+    }
+    std::vector<unsigned char> z;
+    z.push_back(0x78);
+    z.push_back(0x01);
+    uint32_t s1 = 1, s2 = 0;
+    for (size_t pos = 0; pos < raw.size() || pos == 0;) {
+        const size_t n = raw.size() - pos < 65535 ? raw.size() - pos : 65535;
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back(n & 0xffu);
+        z.push_back(n >> 8);
+        z.push_back(~n & 0xffu);
+        z.push_back((~n >> 8) & 0xffu);
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        for (size_t i = 0; i < n; i++) {
+            s1 = (s1 + raw[pos + i]) % 65521u;
+            s2 = (s2 + s1) % 65521u;
+        }
+        pos += n;
+        if (n == 0)
+            break;
+    }
+    putBe32(z, (s2 << 16) | s1);
+    pngChunk(out, "IDAT", z);
+    pngChunk(out, "IEND", std::vector<unsigned char>());
+    return true;
+}
+
+/* PGM/PPM for uint8/uint16 (1 or 3 components), PFM for float (1 or 3 components; bottom row first, little endian) */
+inline bool savePnm(const ArrayContainer& img, std::vector<unsigned char>& out, std::string& error)
+{
+    const size_t w = img.dimension(0), h = img.dimension(1), comps = img.componentCount();
+    if (w == 0 || h == 0 || (comps != 1 && comps != 3)) {
+        error = "PNM/PFM takes 1 or 3 components";
+        return false;
+    }
+    const size_t rowBytes = w * img.elementSize();
+    const unsigned char* data = static_cast<const unsigned char*>(img.data());
+    char header[96];
+    if (img.componentType() == float32) {
+        snprintf(header, sizeof(header), "%s\n%zu %zu\n-1.0\n", comps == 3 ? "PF" : "Pf", w, h);
+        out.assign(header, header + strlen(header));
+        out.insert(out.end(), data, data + rowBytes * h);
+        return true;
+    }
+    const bool wide = img.componentType() == uint16;
+    snprintf(header, sizeof(header), "%s\n%zu %zu\n%d\n", comps == 3 ? "P6" : "P5", w, h, wide ? 65535 : 255);
+    out.assign(header, header + strlen(header));
+    for (size_t y = 0; y < h; y++) {
+        const unsigned char* row = data + (h - 1 - y) * rowBytes;
+        if (!wide) {
+            out.insert(out.end(), row, row + rowBytes);
+        } else {
+            for (size_t i = 0; i < rowBytes; i += 2) {
+                uint16_t v;
+                memcpy(&v, row + i, 2);
+                out.push_back(v >> 8);
+                out.push_back(v & 0xffu);
+            }
+        }
+    }
+    return true;
+}
+
+}
+
+/* Saves an image by file name extension: .png (uint8/uint16), .ppm/.pgm/.pnm (uint8/uint16), .pfm (float).
+ * The counterpart of the reference's TGD::save() calls for the formats this build writes. */
+inline bool saveImage(const ArrayContainer& img, const std::string& filename, std::string* error = nullptr)
+{
+    using namespace imagedetail;
+    const size_t dot = filename.find_last_of('.');
+    std::string ext = dot == std::string::npos ? "" : filename.substr(dot + 1);
+    for (char& c : ext)
+        c = char(tolower(c));
+    std::vector<unsigned char> bytes;
+    std::string err;
+    bool ok = false;
+    if (ext == "png")
+        ok = savePng(img, bytes, err);
+    else if (ext == "pfm" && img.componentType() != float32)
+        err = "PFM takes float data";
+    else if ((ext == "ppm" || ext == "pgm" || ext == "pnm") && img.componentType() == float32)
+        err = "PPM/PGM take uint8 or uint16 data";
+    else if (ext == "pfm" || ext == "ppm" || ext == "pgm" || ext == "pnm")
+        ok = savePnm(img, bytes, err);
+    else
+        err = "no writer for this file type";
+    if (ok) {
+        FILE* f = fopen(filename.c_str(), "wb");
+        ok = f && fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+        if (f && fclose(f) != 0)
+            ok = false;
+        if (!ok)
+            err = "cannot write file";
+    }
+    if (!ok && error)
+        *error = filename + ": " + err;
+    return ok;
+}
+
 /* Loads an image file; an empty array (elementCount() == 0) and a message on failure. */
 inline ArrayContainer loadImage(const std::string& filename, std::string* error = nullptr)
 {

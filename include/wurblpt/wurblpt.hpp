@@ -25,6 +25,7 @@
 #include "material.hpp"
 #include "mesh.hpp"
 #include "mpi.hpp"
+#include "postproc.hpp"
 #include "scene.hpp"
 #include "sensor.hpp"
 #include "texture.hpp"

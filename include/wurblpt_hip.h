@@ -322,6 +322,23 @@ wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera,
  * kernels is bounded, so a protocol failure ends the launch instead of hanging the GPU). */
 wpt_status wpt_scene_check(wpt_scene* scene);
 
+/* ---- output side (postproc.hpp:44-108): per-pixel operations on a rendered frame ----
+ * Device forms work on `pixels` RGB triples in device memory on `hip_stream`.
+ *   to_srgb                          linear RGB float -> sRGB uint8 (values above 1 clipped), toSRGB()
+ *   max_luminance                    largest CIE Y of the frame, maxLuminance() (synchronises)
+ *   uniform_rational_quantization    Schlick's operator on Y, chromaticity kept
+ *   scale_luminance                  Y * factor, clamped to 100 * clamp if clamp > 0 */
+wpt_status wpt_postproc_to_srgb(const float* rgb_device, uint8_t* srgb_device, uint64_t pixels, void* hip_stream);
+wpt_status wpt_postproc_max_luminance(const float* rgb_device, uint64_t pixels, float* result_host, void* hip_stream);
+wpt_status wpt_postproc_uniform_rational_quantization(const float* rgb_device, float* out_device, uint64_t pixels,
+        float max_val, float brightness, void* hip_stream);
+wpt_status wpt_postproc_scale_luminance(const float* rgb_device, float* out_device, uint64_t pixels, float factor,
+        float clamp, void* hip_stream);
+/* The same for host buffers (upload, run, download): op 0 = to_srgb (out: uint8), 1 = uniform rational
+ * quantization (a = max_val, b = brightness; out: float), 2 = scale luminance (a = factor, b = clamp; out:
+ * float), 3 = max luminance (out: one float). */
+wpt_status wpt_postproc_host(int op, const float* rgb_host, void* out_host, uint64_t pixels, float a, float b);
+
 /* Kernel launch geometry knobs (0 = default); for benchmarking only, results do not change. */
 wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant);
 

@@ -34,6 +34,7 @@
 #include "camera.hpp"
 #include "geometryproc.hpp"
 #include "hitable_sphere.hpp"
+#include "color.hpp"
 #define POWITACQ_IMPLEMENTATION
 #include "powitacq_rgb.h"
 #define TINYOBJLOADER_IMPLEMENTATION
@@ -581,6 +582,36 @@ int main(int argc, char* argv[])
             floats((std::string("camera_") + md.name + "_pq").c_str(), pq);
             floats((std::string("camera_") + md.name + "_rays").c_str(), rays);
         }
+    }
+
+    /* ---- colour conversions the output side is built from (color.hpp:226-310) ---- */
+    {
+        std::mt19937 crng(99);
+        auto cu01 = [&crng]() { return float(crng() >> 8) * (1.0f / 16777216.0f); };
+        std::vector<float> in, out;
+        std::vector<long long> bytes;
+        for (int i = 0; i < 2048; i++) {
+            float scale = (i % 4 == 0) ? 30.0f : (i % 4 == 1 ? 1.0f : (i % 4 == 2 ? 0.01f : 3.0f));
+            vec3 rgb(cu01() * scale, cu01() * scale, cu01() * scale);
+            if (i % 64 == 5) rgb = vec3(0.0f);
+            if (i % 64 == 6) rgb = vec3(0.0031308f, 1.0f, 0.5f);
+            float newY = cu01() * 100.0f;
+            push3(in, rgb);
+            in.push_back(newY);
+            vec3 xyz = rgb_to_xyz(rgb);
+            push3(out, xyz);
+            push3(out, xyz_to_rgb(xyz));
+            push3(out, adjust_y(xyz, newY));
+            for (int c = 0; c < 3; c++) {
+                float v = min(rgb[c], 1.0f);
+                float s = rgb_to_srgb_helper(v);
+                out.push_back(s);
+                bytes.push_back(float_to_byte(s));
+            }
+        }
+        floats("color_in", in);     /* rgb(3) newY */
+        floats("color_out", out);   /* xyz(3) back to rgb(3) adjust_y(3) srgb of min(c,1) (3) */
+        ints("color_srgb_bytes", bytes);
     }
 
     /* ---- computeTangents / computeNormals (geometryproc.hpp:58-226) ---- */

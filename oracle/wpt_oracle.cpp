@@ -34,6 +34,7 @@
 #include "../include/wurblpt_hip.h"
 #include "../wurblpt_amd/csrc/wpt_rgl.h"
 #include "../wurblpt_amd/csrc/wpt_lens.h"
+#include "../wurblpt_amd/csrc/wpt_postproc.h"
 #include "../wurblpt_amd/csrc/wpt_math.h"
 
 namespace {
@@ -1791,6 +1792,45 @@ void wpt_oracle_camera_rays_sized(const wpt_camera* cam, uint32_t width, uint32_
         o[0] = r.origin.x; o[1] = r.origin.y; o[2] = r.origin.z;
         o[3] = r.direction.x; o[4] = r.direction.y; o[5] = r.direction.z;
     }
+}
+
+struct OraclePow {
+    static float pow(float x, float y) { return m_pow(x, y); }
+};
+/* colour conversions: in = rgb(3) newY; out = xyz(3) rgb(3) adjust_y(3) srgb(3); bytes = 3 per input */
+void wpt_oracle_color(int n, const float* in, float* out, uint8_t* bytes)
+{
+    for (int i = 0; i < n; i++) {
+        wptpp::V3 rgb { in[4 * i], in[4 * i + 1], in[4 * i + 2] };
+        wptpp::V3 xyz = wptpp::rgbToXyz(rgb), back = wptpp::xyzToRgb(xyz), adj = wptpp::adjustY(xyz, in[4 * i + 3]);
+        float* o = out + 12 * i;
+        o[0] = xyz.x; o[1] = xyz.y; o[2] = xyz.z; o[3] = back.x; o[4] = back.y; o[5] = back.z; o[6] = adj.x; o[7] = adj.y; o[8] = adj.z;
+        const float c[3] = { rgb.x, rgb.y, rgb.z };
+        for (int k = 0; k < 3; k++) {
+            const float v = c[k] < 1.0f ? c[k] : 1.0f;
+            o[9 + k] = wptpp::rgbToSrgbHelper<OraclePow>(v);
+            bytes[3 * i + k] = wptpp::toSrgbByte<OraclePow>(c[k]);
+        }
+    }
+}
+/* postproc.hpp restated per pixel: op 0 = uniformRationalQuantization(a = maxVal, b = brightness), 1 = scaleLuminance(a = factor, b = clamp) */
+void wpt_oracle_postproc(int op, int n, const float* rgb, float a, float b, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        wptpp::V3 v { rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] };
+        wptpp::V3 r = op == 0 ? wptpp::uniformRationalQuantization(v, a, b) : wptpp::scaleLuminance(v, a, b);
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+}
+float wpt_oracle_max_luminance(int n, const float* rgb)
+{
+    float lum = 0.0f;
+    for (int i = 0; i < n; i++) {
+        const float y = wptpp::luminance(wptpp::V3 { rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] });
+        if (y > lum)
+            lum = y;
+    }
+    return lum;
 }
 
 /* TangentSpace(n) (Duff) -> tangent, bitangent, then toWorldSpace(v), toTangentSpace(v): 12 floats */

@@ -448,3 +448,70 @@ def test_surround_and_stereo_cameras_bit_exact(dev, oracle, surround, stereo):
     assert bits_equal(got, ref) and gc == rc
     got2, _ = dev.DeviceScene(sc).render(3)
     assert bits_equal(got2, ref)
+
+
+def _postproc_frames():
+    rng = np.random.default_rng(77)
+    n = 1 << 16
+    hdr = (rng.random((n, 3), dtype=np.float32) ** 4 * 40.0).astype(np.float32)          # high dynamic range
+    hdr[:64] = 0.0                                                                       # black pixels: adjust_y's early out
+    hdr[64:128, 1:] = 0.0                                                                # pure red
+    hdr[128:192] = np.float32(1.0)                                                       # exactly white
+    hdr[192:200] = [-0.5, 0.2, 0.1]                                                      # negative component
+    ldr = rng.random((n, 3), dtype=np.float32) * np.float32(1.2)                         # partly above 1: clipped by toSRGB
+    ldr[:4096] = np.linspace(0.0, 0.0031308 * 2, 4096, dtype=np.float32)[:, None]        # around the linear / power switch
+    return hdr.reshape(256, 256, 3), ldr.reshape(256, 256, 3)
+
+
+def test_output_side_matches_reference_operators(dev, oracle, oracle_libm):
+    """toSRGB, maxLuminance, uniformRationalQuantization, scaleLuminance (postproc.hpp:44-110) on the device, through the
+    C ABI and through include/wurblpt/postproc.hpp, against the restatement pinned to color.hpp by the golden vectors."""
+    import ctypes as C
+    hdr, ldr = _postproc_frames()
+    n = hdr.shape[0] * hdr.shape[1]
+
+    def ref_float(op, frame, a, b):
+        out = np.zeros(3 * n, np.float32)
+        oracle.L.wpt_oracle_postproc(C.c_int(op), C.c_int(n), C.c_void_p(frame.ctypes.data), C.c_float(a), C.c_float(b),
+                                     C.c_void_p(out.ctypes.data))
+        return out.reshape(frame.shape)
+
+    oracle.L.wpt_oracle_max_luminance.restype = C.c_float
+    ref_max = oracle.L.wpt_oracle_max_luminance(C.c_int(n), C.c_void_p(hdr.ctypes.data))
+    assert ref_max > 1000.0
+    for api in (dev.postproc, host.postproc):
+        assert api("maxlum", hdr) == ref_max
+        for brightness in (1.0, 8.0):
+            got = api("urq", hdr, ref_max / 100.0, brightness)
+            assert bits_equal(got, ref_float(0, hdr, ref_max / 100.0, brightness))
+            assert np.nanmax(got @ np.float32([0.212671, 0.715160, 0.072169])) <= 1.0 + 1e-4     # luminances end in [0, 1]
+        for factor, clamp in ((0.05, 1.0), (3.0, 0.0), (0.5, 0.25)):
+            assert bits_equal(api("scale", hdr, factor, clamp), ref_float(1, hdr, factor, clamp))
+        # sRGB bytes: the libm back end is the one pinned bit for bit to the reference's own toSRGB arithmetic
+        srgb = api("srgb", ldr)
+        inp = np.zeros((n, 4), np.float32)
+        inp[:, :3] = ldr.reshape(n, 3)
+        for orc in (oracle, oracle_libm):
+            out = np.zeros(12 * n, np.float32)
+            ref_bytes = np.zeros(3 * n, np.uint8)
+            orc.L.wpt_oracle_color(C.c_int(n), C.c_void_p(inp.ctypes.data), C.c_void_p(out.ctypes.data), C.c_void_p(ref_bytes.ctypes.data))
+            assert np.array_equal(srgb.reshape(-1), ref_bytes)
+    # a frame with a fourth component keeps it zero, as the reference's r.set(i, {r, g, b}) does
+    rgba = np.concatenate([hdr, np.ones(hdr.shape[:2] + (1,), np.float32)], axis=2)
+    got = host.postproc("scale", rgba, 0.05, 1.0)
+    assert bits_equal(got[:, :, :3], ref_float(1, hdr, 0.05, 1.0)) and (got[:, :, 3] == 0).all()
+
+
+def test_rendered_frame_to_png(dev, oracle, tmp_path):
+    """End of the pipeline as wurblpt-cornellbox.cpp:272-273 does it: render -> uniformRationalQuantization(hdr, 1, 8) ->
+    toSRGB -> file."""
+    sc = host.cornell(48, 48, 1, 2)
+    frame, _ = dev.DeviceScene(sc).render(4)
+    rgb = np.ascontiguousarray(frame[:, :, :3])
+    assert host.postproc("maxlum", rgb) > 100.0
+    ldr = host.postproc("urq", rgb, 1.0, 8.0)
+    srgb = host.postproc("srgb", ldr)
+    path = str(tmp_path / "cornell.png")
+    assert host.image_save(path, srgb)
+    back = host.image_load(path)
+    assert np.array_equal(back, srgb) and srgb.max() > 200 and srgb.mean() > 5

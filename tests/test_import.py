@@ -217,3 +217,62 @@ def test_import_into_scene_structure_and_material_rules(oracle):
     types2 = [sc2.d.materials[i].type for i in range(sc2.d.material_count)]
     assert types2.count(_abi.MAT_TWOSIDED) == 7 and types2.count(_abi.MAT_GLASS) == 1
     assert host.import_obj(os.path.join(OBJ_DIR, "nothing_here.obj"), 8, 8, (0, 0, 1), (0, 0, 0)) is None
+
+
+def _png_pixels(path):
+    """Independent PNG reader (zlib + the five filters not needed: writers here use filter 0)."""
+    import struct
+    import zlib
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(b):
+        n, typ = struct.unpack(">I4s", b[pos:pos + 8])
+        body = b[pos + 8:pos + 8 + n]
+        assert zlib.crc32(typ + body) == struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0]
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    w, h, depth, ctype = hdr[:4]
+    comps = {0: 1, 4: 2, 2: 3, 6: 4}[ctype]
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * comps * depth // 8)
+    assert (raw[:, 0] == 0).all()
+    px = raw[:, 1:]
+    if depth == 16:
+        px = px.reshape(h, w * comps, 2).astype(np.uint16)
+        px = (px[:, :, 0] << 8) | px[:, :, 1]
+    return px.reshape(h, w, comps)[::-1]          # row 0 = bottom, like the arrays
+
+
+@pytest.mark.parametrize("comps", [1, 2, 3, 4])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_png_writer_round_trip(tmp_path, comps, dtype):
+    """saveImage() PNG: read back by zlib (checksums, layout) and by the importer's own decoder; 301 x 223 x 4 x 2 bytes
+    spans several stored deflate blocks."""
+    rng = np.random.default_rng(comps)
+    img = rng.integers(0, np.iinfo(dtype).max + 1, size=(223, 301, comps)).astype(dtype)
+    path = str(tmp_path / "out.png")
+    assert host.image_save(path, img)
+    assert np.array_equal(_png_pixels(path), img)
+    assert np.array_equal(host.image_load(path), img)
+
+
+def test_pnm_and_pfm_writers_round_trip(tmp_path):
+    rng = np.random.default_rng(5)
+    for comps, ext in ((1, "pgm"), (3, "ppm")):
+        for dtype in (np.uint8, np.uint16):
+            img = rng.integers(0, np.iinfo(dtype).max + 1, size=(17, 23, comps)).astype(dtype)
+            path = str(tmp_path / ("out." + ext))
+            assert host.image_save(path, img)
+            assert np.array_equal(host.image_load(path), img)
+    for comps in (1, 3):
+        img = rng.standard_normal((9, 14, comps)).astype(np.float32)
+        path = str(tmp_path / "out.pfm")
+        assert host.image_save(path, img)
+        assert np.array_equal(host.image_load(path).view(np.uint32), img.view(np.uint32))
+    # what a format cannot hold is refused, not converted
+    assert not host.image_save(str(tmp_path / "bad.png"), rng.random((4, 4, 3)).astype(np.float32))
+    assert not host.image_save(str(tmp_path / "bad.pfm"), np.zeros((4, 4, 3), np.uint8))
+    assert not host.image_save(str(tmp_path / "bad.jpg"), np.zeros((4, 4, 3), np.uint8))

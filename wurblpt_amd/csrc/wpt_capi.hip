@@ -13,6 +13,7 @@
 #include "../../include/wurblpt_hip.h"
 #include "wpt_pathtrace_pc.inc.h"
 #include "wpt_pathtrace_wf.inc.h"
+#include "wpt_postproc.h"
 
 using namespace wptd;
 using namespace wptk;
@@ -75,6 +76,39 @@ __global__ void wpt_expand_texels_kernel(const uint8_t* pool, const wpt_texture 
         return;
     const f4 v = imageTexelDecode(pool, t, i % t.width, i / t.width);
     out[i] = make_float4(v.x, v.y, v.z, v.w);
+}
+
+/* ---- output side: one thread per pixel (wpt_postproc.h) ---- */
+struct DevicePow {
+    static __device__ __forceinline__ float pow(float x, float y) { return wptm::powf_(x, y); }
+};
+__global__ void wpt_postproc_kernel(int op, const float* in, void* out, uint64_t pixels, float a, float b, uint32_t* maxBits)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= pixels)
+        return;
+    wptpp::V3 rgb;
+    rgb.x = in[3 * i];
+    rgb.y = in[3 * i + 1];
+    rgb.z = in[3 * i + 2];
+    if (op == 0) {
+        uint8_t* o = static_cast<uint8_t*>(out) + 3 * i;
+        o[0] = wptpp::toSrgbByte<DevicePow>(rgb.x);
+        o[1] = wptpp::toSrgbByte<DevicePow>(rgb.y);
+        o[2] = wptpp::toSrgbByte<DevicePow>(rgb.z);
+    } else if (op == 3) {
+        /* maximum of non-negative floats = maximum of their bit patterns; NaN and negative values never win,
+         * as in the sequential `if (y > lum)` starting from 0 */
+        const float y = wptpp::luminance(rgb);
+        if (y > 0.0f)
+            atomicMax(maxBits, __float_as_uint(y));
+    } else {
+        const wptpp::V3 r = op == 1 ? wptpp::uniformRationalQuantization(rgb, a, b) : wptpp::scaleLuminance(rgb, a, b);
+        float* o = static_cast<float*>(out) + 3 * i;
+        o[0] = r.x;
+        o[1] = r.y;
+        o[2] = r.z;
+    }
 }
 
 /* ---- host side of the C ABI ---- */
@@ -772,6 +806,99 @@ wpt_status wpt_scene_check(wpt_scene* scene)
 
 /* profiling hook: device buffer of 11 uint64 that counted launches add their wave-scheduler
  * statistics to (rounds, loop iterations and lane counts per state); NULL switches it off */
+namespace {
+static wpt_status postprocLaunch(int op, const float* in, void* out, uint64_t pixels, float a, float b, uint32_t* maxBits, void* hip_stream)
+{
+    if (!in || pixels == 0 || pixels > 0x7fffffffull * 256ull)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "bad frame for post-processing");
+    hipLaunchKernelGGL(wpt_postproc_kernel, dim3(uint32_t((pixels + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+            op, in, out, pixels, a, b, maxBits);
+    HIP_TRY(hipGetLastError());
+    return WPT_OK;
+}
+}
+
+wpt_status wpt_postproc_to_srgb(const float* rgb_device, uint8_t* srgb_device, uint64_t pixels, void* hip_stream)
+{
+    if (!srgb_device)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "NULL output");
+    return postprocLaunch(0, rgb_device, srgb_device, pixels, 0.0f, 0.0f, nullptr, hip_stream);
+}
+
+wpt_status wpt_postproc_uniform_rational_quantization(const float* rgb_device, float* out_device, uint64_t pixels, float max_val,
+        float brightness, void* hip_stream)
+{
+    if (!out_device)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "NULL output");
+    return postprocLaunch(1, rgb_device, out_device, pixels, max_val, brightness, nullptr, hip_stream);
+}
+
+wpt_status wpt_postproc_scale_luminance(const float* rgb_device, float* out_device, uint64_t pixels, float factor, float clamp,
+        void* hip_stream)
+{
+    if (!out_device)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "NULL output");
+    return postprocLaunch(2, rgb_device, out_device, pixels, factor, clamp, nullptr, hip_stream);
+}
+
+wpt_status wpt_postproc_max_luminance(const float* rgb_device, uint64_t pixels, float* result_host, void* hip_stream)
+{
+    if (!result_host)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "NULL output");
+    uint32_t* bits = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&bits), sizeof(uint32_t)));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    hipError_t e = hipMemsetAsync(bits, 0, sizeof(uint32_t), stream);
+    wpt_status st = e == hipSuccess ? postprocLaunch(3, rgb_device, nullptr, pixels, 0.0f, 0.0f, bits, hip_stream) : fail(WPT_ERR_HIP, hipGetErrorString(e));
+    uint32_t hostBits = 0;
+    if (st == WPT_OK) {
+        e = hipMemcpyAsync(&hostBits, bits, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(stream);
+        if (e != hipSuccess)
+            st = fail(WPT_ERR_HIP, std::string("max luminance: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(bits);
+    memcpy(result_host, &hostBits, sizeof(float));
+    return st;
+}
+
+wpt_status wpt_postproc_host(int op, const float* rgb_host, void* out_host, uint64_t pixels, float a, float b)
+{
+    if (!rgb_host || !out_host || pixels == 0 || op < 0 || op > 3)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "bad post-processing request");
+    if (wpt_device_count() <= 0)
+        return fail(WPT_ERR_NO_DEVICE, "no HIP device is available; post-processing has no CPU fallback either");
+    float* dIn = nullptr;
+    void* dOut = nullptr;
+    const size_t inBytes = size_t(pixels) * 3 * sizeof(float);
+    const size_t outBytes = op == 0 ? size_t(pixels) * 3 : (op == 3 ? 0 : inBytes);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dIn), inBytes));
+    hipError_t e = hipMemcpy(dIn, rgb_host, inBytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && outBytes > 0)
+        e = hipMalloc(&dOut, outBytes);
+    wpt_status st = e == hipSuccess ? WPT_OK : fail(WPT_ERR_HIP, std::string("post-processing buffers: ") + hipGetErrorString(e));
+    if (st == WPT_OK) {
+        if (op == 0)
+            st = wpt_postproc_to_srgb(dIn, static_cast<uint8_t*>(dOut), pixels, nullptr);
+        else if (op == 1)
+            st = wpt_postproc_uniform_rational_quantization(dIn, static_cast<float*>(dOut), pixels, a, b, nullptr);
+        else if (op == 2)
+            st = wpt_postproc_scale_luminance(dIn, static_cast<float*>(dOut), pixels, a, b, nullptr);
+        else
+            st = wpt_postproc_max_luminance(dIn, pixels, static_cast<float*>(out_host), nullptr);
+    }
+    if (st == WPT_OK && outBytes > 0) {
+        e = hipMemcpy(out_host, dOut, outBytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            st = fail(WPT_ERR_HIP, std::string("post-processing download: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(dIn);
+    if (dOut)
+        (void)hipFree(dOut);
+    return st;
+}
+
 wpt_status wpt_set_scheduler_stats(unsigned long long* stats_device)
 {
     g_schedStats = stats_device;

@@ -16,6 +16,8 @@ def lib_path():
 
 
 EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_scene_upload", "wpt_scene_free", "wpt_scene_check",
+           "wpt_postproc_to_srgb", "wpt_postproc_max_luminance", "wpt_postproc_uniform_rational_quantization",
+           "wpt_postproc_scale_luminance", "wpt_postproc_host",
            "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_kernel_name",
            "wpt_last_error"]
 
@@ -123,6 +125,20 @@ class DeviceScene:
         _check(lib().wpt_render_block(self._handle, self.host.camera, C.byref(p), w, h, samples_sqrt, start, size,
                                        C.c_void_p(out.ctypes.data)))
         return out
+
+
+def postproc(op, rgb, a=0.0, b=0.0):
+    """Output-side operations on a frame (float32 [..., 3]) through wpt_postproc_host: op "srgb" -> uint8 frame,
+    "urq" (a = max_val, b = brightness) and "scale" (a = factor, b = clamp) -> float frames, "maxlum" -> float."""
+    import numpy as np
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    pixels = rgb.size // 3
+    code = {"srgb": 0, "urq": 1, "scale": 2, "maxlum": 3}[op]
+    out = np.zeros(rgb.shape, np.uint8) if code == 0 else (np.zeros(1, np.float32) if code == 3 else np.zeros(rgb.shape, np.float32))
+    L = lib()
+    L.wpt_postproc_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float]
+    _check(L.wpt_postproc_host(code, C.c_void_p(rgb.ctypes.data), C.c_void_p(out.ctypes.data), pixels, a, b))
+    return float(out[0]) if code == 3 else out
 
 
 def selftest_aabb(boxes, rays):

@@ -219,6 +219,34 @@ def image_load(filename):
     return out
 
 
+def image_save(filename, img):
+    """Writes a numpy image [h, w, comps] (uint8, uint16 or float32; row 0 = bottom) by file name extension."""
+    img = np.ascontiguousarray(img)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    code = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.float32): 2}[img.dtype]
+    L = lib()
+    L.wpt_host_image_save.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]
+    return bool(L.wpt_host_image_save(filename.encode(), img.shape[1], img.shape[0], img.shape[2], code,
+                                      C.c_void_p(img.ctypes.data)))
+
+
+def postproc(op, img, a=0.0, b=0.0):
+    """The output side through include/wurblpt/postproc.hpp (needs a device): "srgb" -> toSRGB, "urq" ->
+    uniformRationalQuantization(a=maxVal, b=brightness), "scale" -> scaleLuminance(a=factor, b=clamp),
+    "maxlum" -> maxLuminance.  img: float32 [h, w, comps >= 3]."""
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    code = {"srgb": 0, "urq": 1, "scale": 2, "maxlum": 3}[op]
+    out = (np.zeros(img.shape[:2] + (3,), np.uint8) if code == 0 else
+           np.zeros(1, np.float32) if code == 3 else np.zeros(img.shape, np.float32))
+    L = lib()
+    L.wpt_host_postproc.argtypes = [C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+    if not L.wpt_host_postproc(code, img.shape[1], img.shape[0], img.shape[2], C.c_void_p(img.ctypes.data),
+                               C.c_void_p(out.ctypes.data), a, b):
+        raise RuntimeError("post-processing failed")
+    return float(out[0]) if code == 3 else out
+
+
 def bvh_build(boxes):
     """boxes: float32 [n, 6] (lo, hi) -> (uint32 [nodes, 8] raw node words, levels)."""
     boxes = np.ascontiguousarray(boxes, dtype=np.float32)

@@ -12,6 +12,7 @@
 #include "../../include/wurblpt/import.hpp"
 #include "../../include/wurblpt/sensor.hpp"
 #include "../../include/wurblpt/objreader.hpp"
+#include "../../include/wurblpt/postproc.hpp"
 
 using namespace WurblPT;
 
@@ -128,6 +129,44 @@ extern "C" unsigned long long wpt_host_image_load(const char* filename, unsigned
     if (data)
         memcpy(data, img.data(), img.dataSize() < capacity ? img.dataSize() : capacity);
     return img.dataSize();
+}
+
+/* Writes an array (row 0 = bottom) with saveImage(); 1 on success. */
+extern "C" int wpt_host_image_save(const char* filename, unsigned int width, unsigned int height, unsigned int comps,
+        unsigned int type, const void* data)
+{
+    ArrayContainer img(width, height, comps, ComponentType(type));
+    memcpy(img.data(), data, img.dataSize());
+    std::string error;
+    if (!saveImage(img, filename, &error)) {
+        fprintf(stderr, "wpt_host: %s\n", error.c_str());
+        return 0;
+    }
+    return 1;
+}
+
+/* The output side through include/wurblpt/postproc.hpp: op 0 toSRGB (out uint8 x 3), 1 uniformRationalQuantization(a, b),
+ * 2 scaleLuminance(a, b) (out float x comps), 3 maxLuminance (out one float).  1 on success. */
+extern "C" int wpt_host_postproc(int op, unsigned int width, unsigned int height, unsigned int comps, const float* in, void* out,
+        float a, float b)
+{
+    try {
+        Array<float> img(width, height, comps);
+        memcpy(img.data(), in, img.dataSize());
+        if (op == 0) {
+            Array<uint8_t> r = toSRGB(img);
+            memcpy(out, r.data(), r.dataSize());
+        } else if (op == 3) {
+            *static_cast<float*>(out) = maxLuminance(img);
+        } else {
+            Array<float> r = op == 1 ? uniformRationalQuantization(img, a, b) : scaleLuminance(img, a, b);
+            memcpy(out, r.data(), r.dataSize());
+        }
+        return 1;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "wpt_host: %s\n", e.what());
+        return 0;
+    }
 }
 
 /* importIntoScene (include/wurblpt/import.hpp) + a constant environment of the given radiance (0 = none)
