@@ -18,7 +18,7 @@
 
 namespace WurblPT {
 
-enum ComponentType { uint8 = 0, uint16 = 1, float32 = 2 };
+enum ComponentType { uint8 = 0, uint16 = 1, float32 = 2, int32 = 3 };
 
 inline size_t componentTypeSize(ComponentType t) { return t == uint8 ? 1 : t == uint16 ? 2 : 4; }
 
@@ -84,6 +84,7 @@ template<typename T> struct ComponentTypeOf;
 template<> struct ComponentTypeOf<uint8_t> { static constexpr ComponentType value = uint8; };
 template<> struct ComponentTypeOf<uint16_t> { static constexpr ComponentType value = uint16; };
 template<> struct ComponentTypeOf<float> { static constexpr ComponentType value = float32; };
+template<> struct ComponentTypeOf<int32_t> { static constexpr ComponentType value = int32; };
 
 template<typename T> class Array : public ArrayContainer
 {

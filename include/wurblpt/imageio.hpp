@@ -581,7 +581,7 @@ inline void pngChunk(std::vector<unsigned char>& out, const char* type, const st
 inline bool savePng(const ArrayContainer& img, std::vector<unsigned char>& out, std::string& error)
 {
     const size_t w = img.dimension(0), h = img.dimension(1), comps = img.componentCount();
-    if (w == 0 || h == 0 || comps < 1 || comps > 4 || img.componentType() == float32) {
+    if (w == 0 || h == 0 || comps < 1 || comps > 4 || (img.componentType() != uint8 && img.componentType() != uint16)) {
         error = "PNG takes 1-4 components of uint8 or uint16";
         return false;
     }
@@ -645,8 +645,8 @@ inline bool savePng(const ArrayContainer& img, std::vector<unsigned char>& out, 
 inline bool savePnm(const ArrayContainer& img, std::vector<unsigned char>& out, std::string& error)
 {
     const size_t w = img.dimension(0), h = img.dimension(1), comps = img.componentCount();
-    if (w == 0 || h == 0 || (comps != 1 && comps != 3)) {
-        error = "PNM/PFM takes 1 or 3 components";
+    if (w == 0 || h == 0 || (comps != 1 && comps != 3) || img.componentType() == int32) {
+        error = "PNM/PFM takes 1 or 3 components of uint8, uint16 or float";
         return false;
     }
     const size_t rowBytes = w * img.elementSize();

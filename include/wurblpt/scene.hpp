@@ -68,6 +68,7 @@ public:
     std::vector<float> rglData;
     wpt_envmap envmap;
     size_t bvhLevels = 0;
+    std::vector<int> materialSceneIndex; /* per flattened material: Scene::materialIndex() of it, -1 if the scene does not own it */
 
     wpt_scene_desc desc() const
     {
@@ -370,6 +371,10 @@ public:
                 return fail(ctx.error.empty() ? "an EnvironmentMap subclass that the device path does not know is used" : ctx.error);
         }
         out.materials = ctx.materials;
+        out.materialSceneIndex.assign(out.materials.size(), -1);
+        for (const auto& entry : ctx.materialIndex)
+            if (entry.second >= 0 && size_t(entry.second) < out.materialSceneIndex.size())
+                out.materialSceneIndex[entry.second] = materialIndex(entry.first);
         out.rglBrdfs = ctx.rglBrdfs;
         out.rglData = ctx.rglData;
         out.textures = ctx.textures;

@@ -147,4 +147,147 @@ inline void mcpt(Sensor& sensor, const Camera& camera, const Scene& scene, unsig
     mcpt(mpiCoordinator, sensor, camera, scene, samplesSqrt, t0, t1, params);
 }
 
+/* Ground Truth generation (reference: wurblpt.hpp:453-769).  One ray through the centre of every pixel
+ * on the device (wpt_ground_truth, wurblpt_hip.h); the arrays a caller did not ask for stay empty. */
+
+class GroundTruth
+{
+public:
+    static constexpr unsigned int WorldSpacePositions         = (1 << 0);
+    static constexpr unsigned int WorldSpaceGeometryNormals   = (1 << 1);
+    static constexpr unsigned int WorldSpaceGeometryTangents  = (1 << 2);
+    static constexpr unsigned int WorldSpaceMaterialNormals   = (1 << 3);
+    static constexpr unsigned int WorldSpaceMaterialTangents  = (1 << 4);
+    static constexpr unsigned int CameraSpacePositions        = (1 << 5);
+    static constexpr unsigned int CameraSpaceGeometryNormals  = (1 << 6);
+    static constexpr unsigned int CameraSpaceGeometryTangents = (1 << 7);
+    static constexpr unsigned int CameraSpaceMaterialNormals  = (1 << 8);
+    static constexpr unsigned int CameraSpaceMaterialTangents = (1 << 9);
+    static constexpr unsigned int CameraSpaceDepths           = (1 << 10);
+    static constexpr unsigned int CameraSpaceDistances        = (1 << 11);
+    static constexpr unsigned int TexCoords                   = (1 << 12);
+    static constexpr unsigned int WorldSpaceOffsetToPrev      = (1 << 13);
+    static constexpr unsigned int WorldSpaceOffsetToNext      = (1 << 14);
+    static constexpr unsigned int CameraSpaceOffsetToPrev     = (1 << 15);
+    static constexpr unsigned int CameraSpaceOffsetToNext     = (1 << 16);
+    static constexpr unsigned int PixelSpaceOffsetToPrev      = (1 << 17);
+    static constexpr unsigned int PixelSpaceOffsetToNext      = (1 << 18);
+    static constexpr unsigned int Materials                   = (1 << 19);
+    static constexpr unsigned int All                         = (1 << 20) - 1;
+
+    unsigned int bits;
+    Array<float> worldSpacePositions;
+    Array<float> worldSpaceGeometryNormals;
+    Array<float> worldSpaceGeometryTangents;
+    Array<float> worldSpaceMaterialNormals;
+    Array<float> worldSpaceMaterialTangents;
+    Array<float> cameraSpacePositions;
+    Array<float> cameraSpaceGeometryNormals;
+    Array<float> cameraSpaceGeometryTangents;
+    Array<float> cameraSpaceMaterialNormals;
+    Array<float> cameraSpaceMaterialTangents;
+    Array<float> cameraSpaceDepths;    // == -cameraSpacePosition.z
+    Array<float> cameraSpaceDistances; // == length(cameraSpacePosition)
+    Array<float> texCoords;
+    Array<float> worldSpaceOffsetToPrev;
+    Array<float> worldSpaceOffsetToNext;
+    Array<float> cameraSpaceOffsetToPrev;
+    Array<float> cameraSpaceOffsetToNext;
+    Array<float> pixelSpaceOffsetToPrev;
+    Array<float> pixelSpaceOffsetToNext;
+    Array<int32_t> materials;          // Scene::materialIndex() of the hitable's material, -1 where nothing is hit
+
+    GroundTruth() : bits(0) {}
+
+    GroundTruth(unsigned int width, unsigned int height, unsigned int bits = All) : bits(bits)
+    {
+        Array<float>* f[19] = { &worldSpacePositions, &worldSpaceGeometryNormals, &worldSpaceGeometryTangents,
+            &worldSpaceMaterialNormals, &worldSpaceMaterialTangents, &cameraSpacePositions, &cameraSpaceGeometryNormals,
+            &cameraSpaceGeometryTangents, &cameraSpaceMaterialNormals, &cameraSpaceMaterialTangents, &cameraSpaceDepths,
+            &cameraSpaceDistances, &texCoords, &worldSpaceOffsetToPrev, &worldSpaceOffsetToNext, &cameraSpaceOffsetToPrev,
+            &cameraSpaceOffsetToNext, &pixelSpaceOffsetToPrev, &pixelSpaceOffsetToNext };
+        for (int k = 0; k < 19; k++)
+            if (bits & (1u << k))
+                *f[k] = Array<float>(width, height, wpt_gt_components[k]);
+        if (bits & Materials)
+            materials = Array<int32_t>(width, height, 1);
+    }
+
+    /* the arrays in the order of the bits, as wpt_ground_truth takes them (NULL where not asked for) */
+    void arrayPointers(void* out[WPT_GT_ARRAY_COUNT])
+    {
+        ArrayContainer* a[WPT_GT_ARRAY_COUNT] = { &worldSpacePositions, &worldSpaceGeometryNormals, &worldSpaceGeometryTangents,
+            &worldSpaceMaterialNormals, &worldSpaceMaterialTangents, &cameraSpacePositions, &cameraSpaceGeometryNormals,
+            &cameraSpaceGeometryTangents, &cameraSpaceMaterialNormals, &cameraSpaceMaterialTangents, &cameraSpaceDepths,
+            &cameraSpaceDistances, &texCoords, &worldSpaceOffsetToPrev, &worldSpaceOffsetToNext, &cameraSpaceOffsetToPrev,
+            &cameraSpaceOffsetToNext, &pixelSpaceOffsetToPrev, &pixelSpaceOffsetToNext, &materials };
+        for (int k = 0; k < WPT_GT_ARRAY_COUNT; k++)
+            out[k] = (bits & (1u << k)) ? a[k]->data() : nullptr;
+    }
+};
+
+/* The device path holds static scenes, so the only motion the flow arrays can show is the camera's:
+ * cameraPrev / cameraNext are the camera at tPrev / tNext (NULL = it does not move). */
+inline GroundTruth getGroundTruth(const Sensor& sensor, const Camera& camera, const Camera* cameraPrev, const Camera* cameraNext,
+        const Scene& scene, unsigned int groundTruthBits = GroundTruth::All, const Parameters& params = Parameters())
+{
+    if (scene.bvhNeedsUpdate(0.0f, 0.0f))
+        mcptFatal("Scene::updateBVH() must run before getGroundTruth()");
+    wpt_camera cam, camPrev, camNext;
+    if (!camera.describe(cam) || (cameraPrev && !cameraPrev->describe(camPrev)) || (cameraNext && !cameraNext->describe(camNext)))
+        mcptFatal("this camera cannot be described to the device path");
+    FlatScene flat;
+    std::string error;
+    if (!scene.flatten(flat, &error))
+        mcptFatal(error);
+    const wpt_scene_desc desc = flat.desc();
+    wpt_params p;
+    p.max_path_components = params.maxPathComponents;
+    p.rr_threshold = params.rrThreshold;
+    p.randomize_ray_over_pixel = 0;
+    p.min_hit_distance = params.minHitDistance;
+    p.min_dist_to_light = 0.0f;
+    p.max_dist_to_light = std::numeric_limits<float>::max();
+    p.min_path_len = 0.0f;
+    p.max_path_len = std::numeric_limits<float>::max();
+    const unsigned int width = sensor.width();
+    const unsigned int height = sensor.height();
+    GroundTruth gt(width, height, groundTruthBits);
+    fprintf(stderr, "Getting ground truth for %ux%u pixels... ", width, height);
+    if (wpt_device_count() <= 0)
+        mcptFatal(std::string("no HIP device: ") + wpt_last_error());
+    wpt_scene* dscene = nullptr;
+    if (wpt_scene_upload(&desc, &dscene) != WPT_OK)
+        mcptFatal(wpt_last_error());
+    void* arrays[WPT_GT_ARRAY_COUNT];
+    gt.arrayPointers(arrays);
+    const wpt_status st = wpt_ground_truth(dscene, &cam, cameraPrev ? &camPrev : nullptr, cameraNext ? &camNext : nullptr, &p, width,
+            height, arrays);
+    wpt_scene_free(dscene);
+    if (st != WPT_OK)
+        mcptFatal(wpt_last_error());
+    /* the kernel reports positions in the flattened material list; the reference reports Scene::materialIndex() */
+    if (groundTruthBits & GroundTruth::Materials) {
+        for (size_t i = 0; i < gt.materials.elementCount(); i++) {
+            int32_t& m = gt.materials[i][0];
+            m = (m >= 0 && size_t(m) < flat.materialSceneIndex.size()) ? flat.materialSceneIndex[m] : -1;
+        }
+    }
+    fprintf(stderr, "done\n");
+    return gt;
+}
+
+inline GroundTruth getGroundTruth(const Sensor& sensor, const Camera& camera, const Scene& scene, float t0, float /* tPrev */,
+        float /* tNext */, unsigned int groundTruthBits = GroundTruth::All, const Parameters& params = Parameters())
+{
+    (void)t0; /* Camera::at(t) is the same for every t here */
+    return getGroundTruth(sensor, camera, nullptr, nullptr, scene, groundTruthBits, params);
+}
+
+inline GroundTruth getGroundTruth(const Sensor& sensor, const Camera& camera, const Scene& scene, float t0 = 0.0f,
+        unsigned int groundTruthBits = GroundTruth::All, const Parameters& params = Parameters())
+{
+    return getGroundTruth(sensor, camera, scene, t0, t0, t0, groundTruthBits, params);
+}
+
 }

@@ -322,6 +322,46 @@ wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera,
  * kernels is bounded, so a protocol failure ends the launch instead of hanging the GPU). */
 wpt_status wpt_scene_check(wpt_scene* scene);
 
+/* ---- ground truth (GroundTruth / getGroundTruth, wurblpt.hpp:453-769) ----
+ * One ray through the centre of every pixel, without pixel jitter or lens sampling; arrays of what its
+ * first hit is (zero where nothing is hit, material -1).  Array k is the reference's GroundTruth bit k. */
+enum {
+    WPT_GT_WORLD_SPACE_POSITIONS = 0,          /* 3 floats per pixel */
+    WPT_GT_WORLD_SPACE_GEOMETRY_NORMALS = 1,   /* 3 */
+    WPT_GT_WORLD_SPACE_GEOMETRY_TANGENTS = 2,  /* 3 */
+    WPT_GT_WORLD_SPACE_MATERIAL_NORMALS = 3,   /* 3: after the material's normal map */
+    WPT_GT_WORLD_SPACE_MATERIAL_TANGENTS = 4,  /* 3 */
+    WPT_GT_CAMERA_SPACE_POSITIONS = 5,         /* 3 */
+    WPT_GT_CAMERA_SPACE_GEOMETRY_NORMALS = 6,  /* 3 */
+    WPT_GT_CAMERA_SPACE_GEOMETRY_TANGENTS = 7, /* 3 */
+    WPT_GT_CAMERA_SPACE_MATERIAL_NORMALS = 8,  /* 3 */
+    WPT_GT_CAMERA_SPACE_MATERIAL_TANGENTS = 9, /* 3 */
+    WPT_GT_CAMERA_SPACE_DEPTHS = 10,           /* 1: -z of the camera space position */
+    WPT_GT_CAMERA_SPACE_DISTANCES = 11,        /* 1: its length */
+    WPT_GT_TEXCOORDS = 12,                     /* 2 */
+    WPT_GT_WORLD_SPACE_OFFSET_TO_PREV = 13,    /* 3: zero, the device path holds static scenes */
+    WPT_GT_WORLD_SPACE_OFFSET_TO_NEXT = 14,    /* 3 */
+    WPT_GT_CAMERA_SPACE_OFFSET_TO_PREV = 15,   /* 3: from the camera at tPrev / tNext */
+    WPT_GT_CAMERA_SPACE_OFFSET_TO_NEXT = 16,   /* 3 */
+    WPT_GT_PIXEL_SPACE_OFFSET_TO_PREV = 17,    /* 2: Surround_Off, non-stereoscopic cameras only (camera.hpp:207-208) */
+    WPT_GT_PIXEL_SPACE_OFFSET_TO_NEXT = 18,    /* 2 */
+    WPT_GT_MATERIALS = 19,                     /* 1 int32: index into wpt_scene_desc::materials of the hitable's material */
+    WPT_GT_ARRAY_COUNT = 20
+};
+/* components per pixel of array k */
+static const uint32_t wpt_gt_components[WPT_GT_ARRAY_COUNT] = { 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 2, 3, 3, 3, 3, 2, 2, 1 };
+
+/* arrays_device[k]: device array of width * height * wpt_gt_components[k] elements (row 0 = bottom), or
+ * NULL for an array that is not wanted.  camera_prev / camera_next: the camera at tPrev / tNext (only the
+ * transformation is read); NULL = the camera itself.  Asynchronous on `hip_stream`. */
+wpt_status wpt_ground_truth_device(wpt_scene* scene, const wpt_camera* camera, const wpt_camera* camera_prev,
+        const wpt_camera* camera_next, const wpt_params* params, uint32_t width, uint32_t height,
+        void* const arrays_device[WPT_GT_ARRAY_COUNT], void* hip_stream);
+/* The same into host arrays (synchronous). */
+wpt_status wpt_ground_truth(wpt_scene* scene, const wpt_camera* camera, const wpt_camera* camera_prev,
+        const wpt_camera* camera_next, const wpt_params* params, uint32_t width, uint32_t height,
+        void* const arrays_host[WPT_GT_ARRAY_COUNT]);
+
 /* ---- output side (postproc.hpp:44-108): per-pixel operations on a rendered frame ----
  * Device forms work on `pixels` RGB triples in device memory on `hip_stream`.
  *   to_srgb                          linear RGB float -> sRGB uint8 (values above 1 clipped), toSRGB()

@@ -498,6 +498,16 @@ int main(int argc, char* argv[])
                 }
             floats(variant == 0 ? "camera_pinhole_pq" : "camera_lens_pq", pq);
             floats(variant == 0 ? "camera_pinhole_rays" : "camera_lens_rays", res);
+            if (variant == 1) {
+                /* the form getGroundTruth uses (wurblpt.hpp:660-662): no randomness, so no depth of field offset */
+                std::vector<float> plain;
+                for (size_t k = 0; k < pq.size(); k += 2) {
+                    Ray r = camera.getRay(pq[k], pq[k + 1], 0.0f, 0.0f, rh, prng, false);
+                    push3(plain, r.origin);
+                    push3(plain, r.direction);
+                }
+                floats("camera_lens_rays_without_randomness", plain);
+            }
             std::vector<float> camdesc = { optics.projection.l, optics.projection.r, optics.projection.b, optics.projection.t,
                 camera.transformation.translation.x(), camera.transformation.translation.y(), camera.transformation.translation.z(),
                 camera.transformation.rotation.x, camera.transformation.rotation.y, camera.transformation.rotation.z, camera.transformation.rotation.w,
@@ -550,6 +560,28 @@ int main(int argc, char* argv[])
             floats((std::string("lens_") + names[m] + "_pq").c_str(), pq);
             floats((std::string("lens_") + names[m] + "_undistort_distort").c_str(), und);
             floats((std::string("lens_") + names[m] + "_rays").c_str(), rays);
+            /* what getGroundTruth does with a hit position (wurblpt.hpp:679,706-717): world space -> camera space with
+             * the inverse camera transformation, camera space -> (distorted) image space */
+            {
+                Camera::ImageSpaceHelper ish = camera.getImageSpaceHelper(W, H);
+                Transformation inv = inverse(camera.at(0.0f));
+                Prng pointPrng(17 + m);
+                std::vector<float> ws, cs, ic;
+                for (int k = 0; k < 256; k++) {
+                    /* points on rays through the image, 0.5 .. 8.5 units away */
+                    Ray r = camera.getRay(pointPrng.in01(), pointPrng.in01(), 0.0f, 0.0f, rh, prng, false);
+                    vec3 wsPos = r.origin + (0.5f + 8.0f * pointPrng.in01()) * r.direction;
+                    vec3 csPos = inv.rotation * wsPos + inv.translation;
+                    vec2 imageCoord = camera.cameraSpaceToImageSpace(csPos, ish);
+                    push3(ws, wsPos);
+                    push3(cs, csPos);
+                    ic.push_back(imageCoord.x());
+                    ic.push_back(imageCoord.y());
+                }
+                floats((std::string("lens_") + names[m] + "_world_points").c_str(), ws);
+                floats((std::string("lens_") + names[m] + "_camera_points").c_str(), cs);
+                floats((std::string("lens_") + names[m] + "_image_coords").c_str(), ic);
+            }
         }
     }
 

@@ -1768,6 +1768,156 @@ void wpt_oracle_rgl(const wpt_rgl_brdf* brdf, const float* pool, int n, const fl
     }
 }
 
+/* inverse(Transformation) (transformation.hpp:157-163) of the camera transformation */
+struct InverseCamera {
+    float rotation[4];
+    V3 translation;
+    explicit InverseCamera(const wpt_camera& cam)
+    {
+        rotation[0] = -cam.rotation[0];
+        rotation[1] = -cam.rotation[1];
+        rotation[2] = -cam.rotation[2];
+        rotation[3] = cam.rotation[3];
+        V3 invT = -v3(cam.translation);
+        V3 invS = 1.0f / v3(cam.scaling);
+        translation = quat_rotate(rotation, invT * invS);
+    }
+    V3 point(V3 p) const { return quat_rotate(rotation, p) + translation; }
+    V3 direction(V3 d) const { return quat_rotate(rotation, d); }
+};
+
+/* Camera::cameraSpaceToImageSpace (camera.hpp:194-217) */
+inline V2 cameraSpaceToImageSpace(const wpt_camera& cam, V3 p)
+{
+    float P00 = 2.0f / (cam.r - cam.l);
+    float P11 = 2.0f / (cam.t - cam.b);
+    float P03 = (cam.r + cam.l) / (cam.r - cam.l);
+    float P13 = (cam.t + cam.b) / (cam.t - cam.b);
+    V2 projected = V2 { P00 * p.x + P03 * p.z, P11 * p.y + P13 * p.z };
+    float w = -p.z;
+    V2 ndc = V2 { projected.x / w, projected.y / w };
+    V2 imageCoord = 0.5f * ndc + V2 { 0.5f, 0.5f };
+    wptlens::distort(cam, imageCoord.x, imageCoord.y);
+    return imageCoord;
+}
+
+/* cameraSpaceToImageSpace of n camera space points: 2 floats per point */
+void wpt_oracle_camera_to_image(const wpt_camera* cam, int n, const float* points, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        V2 ic = cameraSpaceToImageSpace(*cam, v3(points + 3 * i));
+        out[2 * i] = ic.x;
+        out[2 * i + 1] = ic.y;
+    }
+}
+
+/* world space -> camera space with inverse(camera transformation) (wurblpt.hpp:679): 3 floats per point */
+void wpt_oracle_world_to_camera(const wpt_camera* cam, int n, const float* points, float* out)
+{
+    const InverseCamera inv(*cam);
+    for (int i = 0; i < n; i++) {
+        V3 p = inv.point(v3(points + 3 * i));
+        out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
+    }
+}
+
+/* getGroundTruth (wurblpt.hpp:626-761) for a static scene; arrays[k] (GroundTruth bit k, wurblpt_hip.h) may be NULL */
+int wpt_oracle_ground_truth(const wpt_scene_desc* scene, const wpt_camera* camera, const wpt_camera* camera_prev,
+        const wpt_camera* camera_next, const wpt_params* params, uint32_t width, uint32_t height, void* const* arrays)
+{
+    if (!scene || !camera || !params || !arrays || width == 0 || height == 0)
+        return 1;
+    const wpt_camera& camPrev = camera_prev ? *camera_prev : *camera;
+    const wpt_camera& camNext = camera_next ? *camera_next : *camera;
+    wpt_camera rayCam = *camera;
+    rayCam.lens_radius = 0.0f; /* getRay(..., withRandomness = false): no depth of field offset */
+    const InverseCamera inv0(*camera), invPrev(camPrev), invNext(camNext);
+    const unsigned int pixels = width * height;
+    float invWidth = 1.0f / width;
+    float invHeight = 1.0f / height;
+    auto set3 = [&](int k, unsigned int pixel, V3 v) {
+        if (arrays[k]) {
+            float* o = static_cast<float*>(arrays[k]) + 3 * size_t(pixel);
+            o[0] = v.x; o[1] = v.y; o[2] = v.z;
+        }
+    };
+    auto set2 = [&](int k, unsigned int pixel, V2 v) {
+        if (arrays[k]) {
+            float* o = static_cast<float*>(arrays[k]) + 2 * size_t(pixel);
+            o[0] = v.x; o[1] = v.y;
+        }
+    };
+#pragma omp parallel
+    {
+        Ctx c;
+        c.sc = scene;
+        c.pr = params;
+        memset(&c.cnt, 0, sizeof(c.cnt));
+#pragma omp for schedule(dynamic, 64)
+        for (unsigned int pixel = 0; pixel < pixels; pixel++) {
+            unsigned int y = pixel / width;
+            unsigned int x = pixel % width;
+            Prng prng { pixel };
+            V2 pixelCoord = V2 { (x + 0.5f) * invWidth, (y + 0.5f) * invHeight };
+            Ray ray = cameraGetRay(rayCam, pixelCoord.x, pixelCoord.y, prng, width, height);
+            const HitRecord hr = bvhHit(c, ray, RayHelper(ray), params->min_hit_distance, k_maxval);
+            V3 wsPos = v3(0.0f), wsGNrm = v3(0.0f), wsGTan = v3(0.0f), wsMNrm = v3(0.0f), wsMTan = v3(0.0f);
+            V3 csPos = v3(0.0f), csGNrm = v3(0.0f), csGTan = v3(0.0f), csMNrm = v3(0.0f), csMTan = v3(0.0f);
+            float csDepth = 0.0f, csDist = 0.0f;
+            V2 txCor = V2 { 0.0f, 0.0f };
+            V3 wsOP = v3(0.0f), wsON = v3(0.0f), csOP = v3(0.0f), csON = v3(0.0f);
+            V2 psOP = V2 { 0.0f, 0.0f }, psON = V2 { 0.0f, 0.0f };
+            int matInd = -1;
+            if (hr.haveHit) {
+                const uint32_t mat = materialOfPrim(c, hr.prim);
+                wsPos = hr.position;
+                wsGNrm = hr.normal;
+                wsGTan = hr.tangent;
+                TangentSpace ts = tangentSpaceAt(c, scene->materials[mat], hr);
+                wsMNrm = ts.normal;
+                wsMTan = ts.tangent;
+                csPos = inv0.point(wsPos);
+                csGNrm = inv0.direction(wsGNrm);
+                csGTan = inv0.direction(wsGTan);
+                csMNrm = inv0.direction(wsMNrm);
+                csMTan = inv0.direction(wsMTan);
+                csDepth = -csPos.z;
+                csDist = length(csPos);
+                txCor = hr.texcoords;
+                V3 wsPosPrev = wsPos; /* no animated hitables on this path */
+                V3 wsPosNext = wsPos;
+                wsOP = wsPosPrev - wsPos;
+                wsON = wsPosNext - wsPos;
+                V3 csPosPrev = invPrev.point(wsPosPrev);
+                V3 csPosNext = invNext.point(wsPosNext);
+                csOP = csPosPrev - csPos;
+                csON = csPosNext - csPos;
+                if (arrays[17] || arrays[18]) {
+                    V2 size = V2 { float(width), float(height) };
+                    V2 psPos = pixelCoord * size;
+                    V2 psPosPrev = cameraSpaceToImageSpace(*camera, csPosPrev) * size;
+                    V2 psPosNext = cameraSpaceToImageSpace(*camera, csPosNext) * size;
+                    psOP = psPosPrev - psPos;
+                    psON = psPosNext - psPos;
+                }
+                matInd = int(mat);
+            }
+            set3(0, pixel, wsPos); set3(1, pixel, wsGNrm); set3(2, pixel, wsGTan); set3(3, pixel, wsMNrm); set3(4, pixel, wsMTan);
+            set3(5, pixel, csPos); set3(6, pixel, csGNrm); set3(7, pixel, csGTan); set3(8, pixel, csMNrm); set3(9, pixel, csMTan);
+            if (arrays[10])
+                static_cast<float*>(arrays[10])[pixel] = csDepth;
+            if (arrays[11])
+                static_cast<float*>(arrays[11])[pixel] = csDist;
+            set2(12, pixel, txCor);
+            set3(13, pixel, wsOP); set3(14, pixel, wsON); set3(15, pixel, csOP); set3(16, pixel, csON);
+            set2(17, pixel, psOP); set2(18, pixel, psON);
+            if (arrays[19])
+                static_cast<int32_t*>(arrays[19])[pixel] = matInd;
+        }
+    }
+    return 0;
+}
+
 /* LensDistortion::undistort then ::distort of the result (optics.hpp:214-308): pq -> 4 floats per point */
 void wpt_oracle_lens(const wpt_camera* cam, uint32_t width, uint32_t height, int n, const float* pq, float* out)
 {

@@ -50,6 +50,21 @@ class Oracle:
             raise RuntimeError("oracle render failed: %d" % rc)
         return frame, cnt.as_dict()
 
+    def ground_truth(self, scene, bits=(1 << 20) - 1, camera_prev=None, camera_next=None, params=None, width=None, height=None):
+        """getGroundTruth restated: dict name -> numpy array, as wurblpt_amd.device.ground_truth returns it."""
+        from wurblpt_amd import device, host
+        w = width or scene.width
+        h = height or scene.height
+        p = params if params is not None else host.default_params()
+        arrays, ptrs = device.gt_arrays(w, h, bits)
+        self.L.wpt_oracle_ground_truth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        rc = self.L.wpt_oracle_ground_truth(C.cast(scene.desc, C.c_void_p), C.cast(scene.camera, C.c_void_p),
+                                            C.addressof(camera_prev) if camera_prev is not None else None,
+                                            C.addressof(camera_next) if camera_next is not None else None, C.addressof(p), w, h, ptrs)
+        if rc != 0:
+            raise RuntimeError("oracle ground truth failed: %d" % rc)
+        return {device.GT_NAMES[k]: a for k, a in enumerate(arrays) if a is not None}
+
     def envmap_tables(self, scene, n=None):
         """Importance tables of the scene's environment map (M, Ms, Mcs) as numpy arrays."""
         n = n or scene.d.envmap.N

@@ -515,3 +515,118 @@ def test_rendered_frame_to_png(dev, oracle, tmp_path):
     assert host.image_save(path, srgb)
     back = host.image_load(path)
     assert np.array_equal(back, srgb) and srgb.max() > 200 and srgb.mean() > 5
+
+
+def _moved_camera(scene, shift, yaw):
+    """The scene's camera translated by `shift` and turned by `yaw` radians about the world y axis."""
+    import ctypes as C
+    from wurblpt_amd import _abi
+    cam = _abi.Camera()
+    C.memmove(C.addressof(cam), C.addressof(scene.camera.contents), C.sizeof(cam))
+    for k in range(3):
+        cam.translation[k] = float(np.float32(cam.translation[k]) + np.float32(shift[k]))
+    qx, qy, qz, qw = [np.float32(v) for v in cam.rotation]
+    s, c = np.float32(np.sin(0.5 * yaw)), np.float32(np.cos(0.5 * yaw))
+    # (0, s, 0, c) * q
+    cam.rotation[0] = float(c * qx + s * qz)
+    cam.rotation[1] = float(c * qy + s * qw)
+    cam.rotation[2] = float(c * qz - s * qx)
+    cam.rotation[3] = float(c * qw - s * qy)
+    return cam
+
+
+def _ground_truth_scenes(name):
+    import os
+    if name == "cornell":
+        return host.cornell(96, 64, 1, 2)
+    if name == "spheres":
+        return host.spheres(96, 64, 1)
+    if name == "sponza_like":
+        return host.sponza_like(96, 64, detail=0.05, tex_size=32, env_width=64, importance_n=16)
+    obj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "obj", "scene.obj")
+    return host.import_obj(obj, 96, 64, eye=(0.5, 2.2, 6.5), at=(0.0, 1.2, 0.0), import_bits=4 if name == "obj_two_sided" else 0,
+                           env_radiance=0.05)
+
+
+def _assert_ground_truth_equal(got, ref):
+    assert sorted(got) == sorted(ref)
+    for name in ref:
+        a, b = got[name], ref[name]
+        assert a.dtype == b.dtype and a.shape == b.shape, name
+        nbad = int((a.view(np.uint32) != b.view(np.uint32)).sum())
+        assert nbad == 0, "%s: %d of %d values differ" % (name, nbad, a.size)
+
+
+@pytest.mark.parametrize("name", ["cornell", "spheres", "sponza_like", "obj", "obj_two_sided"])
+def test_ground_truth_bit_exact(dev, oracle, name):
+    """getGroundTruth (wurblpt.hpp:626-761) through wpt_ground_truth with a camera that moves between tPrev, t0 and
+    tNext: all twenty arrays equal the restatement bit for bit; triangles and spheres, textures with normal maps,
+    two-sided wrappers (reported as themselves, not looked through)."""
+    sc = _ground_truth_scenes(name)
+    prev = _moved_camera(sc, (-0.04, 0.01, 0.02), -0.01)
+    nxt = _moved_camera(sc, (0.05, -0.01, -0.03), 0.015)
+    ref = oracle.ground_truth(sc, camera_prev=prev, camera_next=nxt)
+    ds = dev.DeviceScene(sc)
+    got = dev.ground_truth(ds, camera_prev=prev, camera_next=nxt)
+    _assert_ground_truth_equal(got, ref)
+    hit = got["materials"][:, :, 0] >= 0
+    assert 0.3 < hit.mean() <= 1.0 and got["materials"].max() < sc.d.material_count
+    # what the arrays mean
+    cs = got["camera_space_positions"]
+    assert np.array_equal(got["camera_space_depths"][:, :, 0], -cs[:, :, 2])
+    assert np.allclose(got["camera_space_distances"][:, :, 0], np.linalg.norm(cs, axis=2), rtol=1e-6)
+    for key in ("world_space_geometry_normals", "world_space_material_normals", "camera_space_material_normals"):
+        assert np.allclose(np.linalg.norm(got[key], axis=2)[hit], 1.0, atol=1e-4), key
+    assert (got["world_space_offset_to_prev"] == 0).all() and (got["world_space_offset_to_next"] == 0).all()
+    assert np.abs(got["pixel_space_offset_to_prev"][hit]).max() > 0.2       # the camera moved: flow of a pixel or so
+    assert np.abs(got["pixel_space_offset_to_next"][hit]).max() < 20.0
+    for key, arr in got.items():                                              # nothing hit: zeros, material -1
+        if key != "materials":
+            assert (arr[~hit] == 0).all(), key
+    # a subset of the arrays, and a static camera: pixel space offsets vanish up to rounding
+    some = dev.ground_truth(ds, bits=(1 << 0) | (1 << 10) | (1 << 17) | (1 << 19))
+    assert sorted(some) == ["camera_space_depths", "materials", "pixel_space_offset_to_prev", "world_space_positions"]
+    assert bits_equal(some["world_space_positions"], got["world_space_positions"])
+    assert np.abs(some["pixel_space_offset_to_prev"]).max() < 1e-3            # the reference asserts this bound (wurblpt.hpp:712)
+
+
+def test_ground_truth_cameras_with_distortion_and_surround(dev, oracle):
+    """Pixel space flow goes through LensDistortion::distort (camera.hpp:215); 360 degree cameras give every array
+    but the pixel space ones, which the reference cannot compute either (camera.hpp:207-208)."""
+    sc = host.cornell(96, 64, 1, 2)
+    host.set_distortion(sc, 3, k1=-0.25, k2=0.09, k3=-0.015, p1=0.0011, p2=-0.0007)
+    prev = _moved_camera(sc, (-0.04, 0.01, 0.02), -0.01)
+    ds = dev.DeviceScene(sc)
+    got = dev.ground_truth(ds, camera_prev=prev)
+    _assert_ground_truth_equal(got, oracle.ground_truth(sc, camera_prev=prev))
+    static = dev.ground_truth(ds, bits=1 << 17)
+    assert np.abs(static["pixel_space_offset_to_prev"]).max() < 2e-3         # distort(undistort(x)) == x up to the iteration's tolerance
+    host.set_distortion(sc, 0)
+    host.set_camera_mode(sc, 2, 0.0)
+    bits = dev.GT_ALL & ~((1 << 17) | (1 << 18))
+    got = dev.ground_truth(ds, bits=bits, camera_prev=prev)
+    _assert_ground_truth_equal(got, oracle.ground_truth(sc, bits=bits, camera_prev=prev))
+    assert 0.01 < (got["materials"] >= 0).mean() < 0.5                        # the camera stands in front of the open box
+    with pytest.raises(RuntimeError):
+        dev.ground_truth(ds, bits=1 << 17)
+
+
+def test_get_ground_truth_host_api(dev, oracle):
+    """include/wurblpt/wurblpt.hpp getGroundTruth(): same arrays as the C ABI gives, materials reported as
+    Scene::materialIndex() like the reference does."""
+    import os
+    obj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "obj", "scene.obj")
+    eye, at = (0.5, 2.2, 6.5), (0.0, 1.2, 0.0)
+    sc = host.import_obj(obj, 80, 60, eye=eye, at=at, import_bits=4, env_radiance=0.05)
+    prev_fa = (0.45, 2.2, 6.55, 0.0, 1.2, 0.0)
+    got = host.get_ground_truth(sc, prev_from_at=prev_fa)
+    # the same camera pair through the C ABI
+    other = host.import_obj(obj, 80, 60, eye=prev_fa[:3], at=prev_fa[3:], import_bits=4, env_radiance=0.05)
+    ref = oracle.ground_truth(sc, camera_prev=other.camera.contents)
+    table = host.material_scene_index(sc)
+    assert sorted(table[table >= 0].tolist()) == sorted(set(table[table >= 0].tolist()))   # one scene index per material
+    flat = ref.pop("materials")
+    mapped = np.where(flat >= 0, table[np.maximum(flat, 0)], -1).astype(np.int32)
+    assert np.array_equal(got.pop("materials"), mapped)
+    _assert_ground_truth_equal(got, ref)
+    assert np.abs(got["camera_space_offset_to_prev"]).max() > 0.01 and (got["camera_space_offset_to_next"] == 0).all()

@@ -217,3 +217,29 @@ def test_furnace_modphong_conserves_energy_in_expectation(oracle):
     for material in (3, 4):
         c, _, _ = _furnace_centre(oracle, material, spp_sqrt=6)
         assert 0.8 < c.mean() < 1.005
+
+
+def test_ground_truth_restatement_is_consistent(oracle):
+    """The CPU restatement of getGroundTruth (wurblpt.hpp:626-761): its first hit is the path tracer's first hit, its
+    arrays mean what the reference says (its building blocks are pinned in test_oracle_golden.py)."""
+    from wurblpt_amd import device
+    sc = host.cornell(48, 48, 1, 2)
+    gt = oracle.ground_truth(sc)
+    assert sorted(gt) == sorted(device.GT_NAMES)
+    hit = gt["materials"][:, :, 0] >= 0
+    assert hit.mean() > 0.9
+    cs = gt["camera_space_positions"]
+    assert np.array_equal(gt["camera_space_depths"][:, :, 0], -cs[:, :, 2]) and (cs[:, :, 2][hit] < 0).all()
+    assert np.allclose(np.linalg.norm(gt["world_space_geometry_normals"], axis=2)[hit], 1.0, atol=1e-5)
+    # the light is material-emitting geometry in the ceiling: the pixel that sees it is the one the renderer makes brightest
+    p = host.default_params()
+    p.max_path_components = 2
+    p.randomize_ray_over_pixel = 0
+    frame, _ = oracle.render(sc, 1, p)
+    y, x = np.unravel_index(np.argmax(frame.sum(axis=2)), frame.shape[:2])
+    light_material = gt["materials"][y, x, 0]
+    assert light_material >= 0 and (gt["materials"] == light_material).mean() < 0.1
+    assert gt["world_space_positions"][y, x, 1] > 1.9            # near the ceiling of the box
+    # only the arrays that were asked for come back
+    some = oracle.ground_truth(sc, bits=(1 << 12) | (1 << 19))
+    assert sorted(some) == ["materials", "texcoords"] and np.array_equal(some["materials"], gt["materials"])

@@ -769,6 +769,75 @@ wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera, const wp
     return st;
 }
 
+wpt_status wpt_ground_truth_device(wpt_scene* scene, const wpt_camera* camera, const wpt_camera* camera_prev,
+        const wpt_camera* camera_next, const wpt_params* params, uint32_t width, uint32_t height,
+        void* const arrays_device[WPT_GT_ARRAY_COUNT], void* hip_stream)
+{
+    if (!scene || !camera || !params || !arrays_device)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (width == 0 || height == 0 || uint64_t(width) * height > 0xffffffffull)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "width and height must be positive");
+    if (camera->surround_mode > WPT_SURROUND_360)
+        return fail(WPT_ERR_UNSUPPORTED, "camera surround mode is not known to the kernel");
+    if (camera->distortion_type > WPT_DISTORTION_OPENCV)
+        return fail(WPT_ERR_UNSUPPORTED, "lens distortion model is not known to the kernel");
+    if ((arrays_device[WPT_GT_PIXEL_SPACE_OFFSET_TO_PREV] || arrays_device[WPT_GT_PIXEL_SPACE_OFFSET_TO_NEXT])
+            && (camera->surround_mode != WPT_SURROUND_OFF || camera->stereoscopic_distance > 0.0f))
+        return fail(WPT_ERR_UNSUPPORTED, "pixel space offsets exist for Surround_Off, non-stereoscopic cameras only (camera.hpp:207-208)");
+    GroundTruthArgs args;
+    args.scene = scene->view;
+    args.cam = *camera;
+    args.camPrev = camera_prev ? *camera_prev : *camera;
+    args.camNext = camera_next ? *camera_next : *camera;
+    args.par = *params;
+    args.width = width;
+    args.height = height;
+    bool any = false;
+    for (int k = 0; k < WPT_GT_ARRAY_COUNT; k++) {
+        args.array[k] = arrays_device[k];
+        any = any || arrays_device[k];
+    }
+    if (!any)
+        return WPT_OK;
+    launchGroundTruth(args, static_cast<hipStream_t>(hip_stream));
+    HIP_TRY(hipGetLastError());
+    return WPT_OK;
+}
+
+wpt_status wpt_ground_truth(wpt_scene* scene, const wpt_camera* camera, const wpt_camera* camera_prev,
+        const wpt_camera* camera_next, const wpt_params* params, uint32_t width, uint32_t height,
+        void* const arrays_host[WPT_GT_ARRAY_COUNT])
+{
+    if (!arrays_host)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "NULL argument");
+    const size_t pixels = size_t(width) * height;
+    void* dev[WPT_GT_ARRAY_COUNT];
+    for (int k = 0; k < WPT_GT_ARRAY_COUNT; k++)
+        dev[k] = nullptr;
+    wpt_status st = WPT_OK;
+    for (int k = 0; k < WPT_GT_ARRAY_COUNT && st == WPT_OK; k++) {
+        if (arrays_host[k] && pixels > 0) {
+            hipError_t e = hipMalloc(&dev[k], pixels * wpt_gt_components[k] * 4);
+            if (e != hipSuccess)
+                st = fail(e == hipErrorOutOfMemory ? WPT_ERR_OUT_OF_MEMORY : WPT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        }
+    }
+    if (st == WPT_OK)
+        st = wpt_ground_truth_device(scene, camera, camera_prev, camera_next, params, width, height, dev, nullptr);
+    if (st == WPT_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        for (int k = 0; k < WPT_GT_ARRAY_COUNT && e == hipSuccess; k++)
+            if (dev[k])
+                e = hipMemcpy(arrays_host[k], dev[k], pixels * wpt_gt_components[k] * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            st = fail(WPT_ERR_HIP, std::string("ground truth: ") + hipGetErrorString(e));
+    }
+    for (int k = 0; k < WPT_GT_ARRAY_COUNT; k++)
+        if (dev[k])
+            (void)hipFree(dev[k]);
+    return st;
+}
+
 wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant)
 {
     if (threads_per_group != 0 && threads_per_group != WG)

@@ -1,0 +1,207 @@
+/*
+ * wpt_k_groundtruth.hip -- getGroundTruth (wurblpt.hpp:626-761): one ray through the centre of every
+ * pixel, no randomness, and the geometry / material / flow buffers of its first hit.
+ *
+ * One lane = one pixel, one ray: the walk is the reference's BVH::hit in the stackless form the path
+ * tracing kernels use, the hit record and the material tangent space are theirs too (wpt_device.h),
+ * the ray comes from blockNew (wpt_blocks.h) with the pixel jitter and the lens sampling switched off.
+ * The scene is static for the device path, so the world space offsets to the previous / next frame
+ * are zero and the camera space / pixel space ones come from the camera's motion alone.
+ */
+#include "wpt_pathtrace.inc.h"
+
+namespace wptk {
+
+struct InverseTransformation {
+    float rotation[4];
+    f3 translation;
+};
+
+/* inverse(Transformation) (transformation.hpp:157-163); applied as rotation * p + translation (wurblpt.hpp:679) */
+WPT_D InverseTransformation inverseOf(const wpt_camera& cam)
+{
+    InverseTransformation inv;
+    inv.rotation[0] = -cam.rotation[0];
+    inv.rotation[1] = -cam.rotation[1];
+    inv.rotation[2] = -cam.rotation[2];
+    inv.rotation[3] = cam.rotation[3];
+    const f3 invT = neg(ld3(cam.translation));
+    const f3 invS = mk3(1.0f / cam.scaling[0], 1.0f / cam.scaling[1], 1.0f / cam.scaling[2]);
+    inv.translation = quatRotate(inv.rotation, mul(invT, invS));
+    return inv;
+}
+
+/* Camera::cameraSpaceToImageSpace (camera.hpp:194-217) */
+WPT_D f2 cameraSpaceToImageSpace(const wpt_camera& cam, f3 p)
+{
+    const float P00 = 2.0f / (cam.r - cam.l);
+    const float P11 = 2.0f / (cam.t - cam.b);
+    const float P03 = (cam.r + cam.l) / (cam.r - cam.l);
+    const float P13 = (cam.t + cam.b) / (cam.t - cam.b);
+    const float px = P00 * p.x + P03 * p.z;
+    const float py = P11 * p.y + P13 * p.z;
+    const float pw = -p.z;
+    f2 ic;
+    ic.x = 0.5f * (px / pw) + 0.5f;
+    ic.y = 0.5f * (py / pw) + 0.5f;
+    wptlens::distort(cam, ic.x, ic.y);
+    return ic;
+}
+
+WPT_D void store3(void* array, uint32_t pixel, f3 v)
+{
+    if (array) {
+        float* o = static_cast<float*>(array) + 3 * (size_t)pixel;
+        o[0] = v.x;
+        o[1] = v.y;
+        o[2] = v.z;
+    }
+}
+WPT_D void store2(void* array, uint32_t pixel, f2 v)
+{
+    if (array) {
+        float* o = static_cast<float*>(array) + 2 * (size_t)pixel;
+        o[0] = v.x;
+        o[1] = v.y;
+    }
+}
+WPT_D void store1(void* array, uint32_t pixel, float v)
+{
+    if (array)
+        static_cast<float*>(array)[pixel] = v;
+}
+
+constexpr uint32_t GT_FEATURES = FEAT_TEXTURES | FEAT_LENS | FEAT_SPHERES;
+
+__global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs args)
+{
+    const uint32_t pixel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pixel >= args.width * args.height)
+        return;
+    const SceneView& sv = args.scene;
+
+    /* the ray: pixel centre, pinhole (getRay(..., withRandomness = false), wurblpt.hpp:660-662) */
+    FrameArgs fa;
+    fa.cam = args.cam;
+    fa.cam.lens_radius = 0.0f;
+    fa.par = args.par;
+    fa.par.randomize_ray_over_pixel = 0;
+    fa.width = args.width;
+    fa.height = args.height;
+    fa.samplesSqrt = 1;
+    PathState ps;
+    pathStateInit(ps, pixel, args.width);
+    blockNew<GT_FEATURES>(fa, ps);
+
+    /* BVH::hit (bvh.hpp:270-329): closest candidate, later candidates win ties */
+    const RayAux aux = rayAux(ps.ray.d);
+    Candidate best;
+    best.prim = NO_HIT;
+    best.a = best.invDet = best.U = best.V = best.W = 0.0f;
+    float amax = k_maxval;
+    uint32_t node = 0;
+    while (node < sv.nodeCount) {
+        const float4 n0 = sv.nodes[2 * node], n1 = sv.nodes[2 * node + 1];
+        const uint32_t skip = __float_as_uint(n1.z);
+        const uint32_t prim = __float_as_uint(n1.w);
+        const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.ray.o, aux.inv, args.par.min_hit_distance, amax);
+        if (hit && prim < NODE_EMPTY) {
+            Candidate c;
+            bool accepted;
+            if (prim & PRIM_SPHERE) {
+                c.invDet = c.U = c.V = c.W = 0.0f;
+                accepted = sphereTest(sv.spheres[prim & ~PRIM_SPHERE], ps.ray.o, ps.ray.d, args.par.min_hit_distance, amax, c.a);
+            } else {
+                const float4 g0 = sv.triGeom[3 * (size_t)prim], g1 = sv.triGeom[3 * (size_t)prim + 1], g2 = sv.triGeom[3 * (size_t)prim + 2];
+                accepted = triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), ps.ray.o, aux,
+                        args.par.min_hit_distance, amax, c);
+            }
+            if (accepted) {
+                c.prim = prim;
+                best = c;
+                amax = c.a;
+            }
+            node = node + 1;
+        } else {
+            node = (hit && prim == NODE_INNER) ? node + 1 : skip;
+        }
+    }
+
+    const f3 zero3 = mk3(0.0f, 0.0f, 0.0f);
+    f3 wsPos = zero3, wsGNrm = zero3, wsGTan = zero3, wsMNrm = zero3, wsMTan = zero3;
+    f3 csPos = zero3, csGNrm = zero3, csGTan = zero3, csMNrm = zero3, csMTan = zero3;
+    float csDepth = 0.0f, csDist = 0.0f;
+    f2 txCor;
+    txCor.x = txCor.y = 0.0f;
+    f3 wsOP = zero3, wsON = zero3, csOP = zero3, csON = zero3;
+    f2 psOP = txCor, psON = txCor;
+    int matInd = -1;
+    if (best.prim != NO_HIT) {
+        const Hit h = finishHit<GT_FEATURES>(sv, best, ps.ray.o, ps.ray.d);
+        wsPos = h.p;
+        wsGNrm = h.n;
+        wsGTan = h.t;
+        /* the hitable's own material: a two-sided wrapper is not looked through (wurblpt.hpp:675) */
+        const Frame ts = tangentSpaceAt<GT_FEATURES>(sv, sv.materials[h.material], h);
+        wsMNrm = ts.n;
+        wsMTan = ts.t;
+        const InverseTransformation inv0 = inverseOf(args.cam);
+        csPos = add(quatRotate(inv0.rotation, wsPos), inv0.translation);
+        csGNrm = quatRotate(inv0.rotation, wsGNrm);
+        csGTan = quatRotate(inv0.rotation, wsGTan);
+        csMNrm = quatRotate(inv0.rotation, wsMNrm);
+        csMTan = quatRotate(inv0.rotation, wsMTan);
+        csDepth = -csPos.z;
+        csDist = __builtin_sqrtf(dot(csPos, csPos));
+        txCor = h.tc;
+        const f3 wsPosPrev = wsPos, wsPosNext = wsPos;
+        wsOP = sub(wsPosPrev, wsPos);
+        wsON = sub(wsPosNext, wsPos);
+        const InverseTransformation invP = inverseOf(args.camPrev), invN = inverseOf(args.camNext);
+        const f3 csPosPrev = add(quatRotate(invP.rotation, wsPosPrev), invP.translation);
+        const f3 csPosNext = add(quatRotate(invN.rotation, wsPosNext), invN.translation);
+        csOP = sub(csPosPrev, csPos);
+        csON = sub(csPosNext, csPos);
+        if (args.array[17] || args.array[18]) {
+            const float fw = (float)args.width, fh = (float)args.height;
+            f2 psPos;
+            psPos.x = (((float)ps.px + 0.5f) * (1.0f / fw)) * fw;
+            psPos.y = (((float)ps.py + 0.5f) * (1.0f / fh)) * fh;
+            const f2 icPrev = cameraSpaceToImageSpace(args.cam, csPosPrev), icNext = cameraSpaceToImageSpace(args.cam, csPosNext);
+            psOP.x = icPrev.x * fw - psPos.x;
+            psOP.y = icPrev.y * fh - psPos.y;
+            psON.x = icNext.x * fw - psPos.x;
+            psON.y = icNext.y * fh - psPos.y;
+        }
+        matInd = (int)h.material;
+    }
+    store3(args.array[0], pixel, wsPos);
+    store3(args.array[1], pixel, wsGNrm);
+    store3(args.array[2], pixel, wsGTan);
+    store3(args.array[3], pixel, wsMNrm);
+    store3(args.array[4], pixel, wsMTan);
+    store3(args.array[5], pixel, csPos);
+    store3(args.array[6], pixel, csGNrm);
+    store3(args.array[7], pixel, csGTan);
+    store3(args.array[8], pixel, csMNrm);
+    store3(args.array[9], pixel, csMTan);
+    store1(args.array[10], pixel, csDepth);
+    store1(args.array[11], pixel, csDist);
+    store2(args.array[12], pixel, txCor);
+    store3(args.array[13], pixel, wsOP);
+    store3(args.array[14], pixel, wsON);
+    store3(args.array[15], pixel, csOP);
+    store3(args.array[16], pixel, csON);
+    store2(args.array[17], pixel, psOP);
+    store2(args.array[18], pixel, psON);
+    if (args.array[19])
+        static_cast<int32_t*>(args.array[19])[pixel] = matInd;
+}
+
+void launchGroundTruth(const GroundTruthArgs& args, hipStream_t stream)
+{
+    const uint32_t pixels = args.width * args.height;
+    hipLaunchKernelGGL(wpt_ground_truth_kernel, dim3((pixels + 255) / 256), dim3(256), 0, stream, args);
+}
+
+}

@@ -397,6 +397,16 @@ constexpr uint32_t FEAT_ALL = FEAT_TEXTURES | FEAT_MODPHONG | FEAT_ENVMAP | FEAT
 
 /* one launcher per instantiation, each defined in its own translation unit;
  * ldsBytes is the dynamic LDS size (0 for the HBM variants) */
+/* getGroundTruth (wpt_k_groundtruth.hip): array[k] is the device array of GroundTruth bit k or NULL */
+struct GroundTruthArgs {
+    SceneView scene;
+    wpt_camera cam, camPrev, camNext;
+    wpt_params par;
+    uint32_t width, height;
+    void* array[WPT_GT_ARRAY_COUNT];
+};
+void launchGroundTruth(const GroundTruthArgs& args, hipStream_t stream);
+
 void launchBasicLds(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream);
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream);

@@ -17,7 +17,7 @@ def lib_path():
 
 EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_scene_upload", "wpt_scene_free", "wpt_scene_check",
            "wpt_postproc_to_srgb", "wpt_postproc_max_luminance", "wpt_postproc_uniform_rational_quantization",
-           "wpt_postproc_scale_luminance", "wpt_postproc_host",
+           "wpt_postproc_scale_luminance", "wpt_postproc_host", "wpt_ground_truth_device", "wpt_ground_truth",
            "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_kernel_name",
            "wpt_last_error"]
 
@@ -125,6 +125,40 @@ class DeviceScene:
         _check(lib().wpt_render_block(self._handle, self.host.camera, C.byref(p), w, h, samples_sqrt, start, size,
                                        C.c_void_p(out.ctypes.data)))
         return out
+
+
+GT_NAMES = ("world_space_positions", "world_space_geometry_normals", "world_space_geometry_tangents",
+            "world_space_material_normals", "world_space_material_tangents", "camera_space_positions",
+            "camera_space_geometry_normals", "camera_space_geometry_tangents", "camera_space_material_normals",
+            "camera_space_material_tangents", "camera_space_depths", "camera_space_distances", "texcoords",
+            "world_space_offset_to_prev", "world_space_offset_to_next", "camera_space_offset_to_prev",
+            "camera_space_offset_to_next", "pixel_space_offset_to_prev", "pixel_space_offset_to_next", "materials")
+GT_COMPONENTS = (3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 2, 3, 3, 3, 3, 2, 2, 1)
+GT_ALL = (1 << 20) - 1
+
+
+def gt_arrays(width, height, bits=GT_ALL):
+    """Host arrays for a ground truth call: (list of numpy arrays or None, ctypes pointer array)."""
+    import numpy as np
+    arrays = [np.zeros((height, width, GT_COMPONENTS[k]), np.int32 if k == 19 else np.float32) if bits & (1 << k) else None
+              for k in range(20)]
+    ptrs = (C.c_void_p * 20)(*[a.ctypes.data if a is not None else None for a in arrays])
+    return arrays, ptrs
+
+
+def ground_truth(scene, bits=GT_ALL, camera_prev=None, camera_next=None, params=None, width=None, height=None):
+    """wpt_ground_truth on a DeviceScene: dict name -> numpy array [h, w, comps] of the requested GroundTruth bits."""
+    from . import host
+    w = width or scene.host.width
+    h = height or scene.host.height
+    p = params if params is not None else host.default_params()
+    arrays, ptrs = gt_arrays(w, h, bits)
+    L = lib()
+    L.wpt_ground_truth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    _check(L.wpt_ground_truth(scene._handle, C.cast(scene.host.camera, C.c_void_p),
+                              C.addressof(camera_prev) if camera_prev is not None else None,
+                              C.addressof(camera_next) if camera_next is not None else None, C.addressof(p), w, h, ptrs))
+    return {GT_NAMES[k]: a for k, a in enumerate(arrays) if a is not None}
 
 
 def postproc(op, rgb, a=0.0, b=0.0):

@@ -27,6 +27,8 @@ struct wpt_host_scene {
     wpt_scene_desc desc;
     wpt_camera camera;
     std::string error;
+    float vfov = 0.0f; /* the look-at camera the scene was finished with */
+    vec3 from, at;
 };
 
 namespace {
@@ -201,6 +203,9 @@ wpt_host_scene* finishSceneOf(wpt_host_scene* hs, Scene& scene, unsigned int wid
     Optics optics(Projection(vfovRadians, float(width) / height), LensDistortion(), LensDepthOfField(aperture, focusDist));
     Camera camera(optics, Transformation::fromLookAt(from, at, vec3(0.0f, 1.0f, 0.0f)));
     camera.describe(hs->camera);
+    hs->vfov = vfovRadians;
+    hs->from = from;
+    hs->at = at;
     return hs;
 }
 
@@ -212,7 +217,16 @@ wpt_host_scene* finishScene(wpt_host_scene* hs, unsigned int width, unsigned int
 
 }
 
-/* used by the other scene files of this library: takes ownership of `scene` */
+/* used by the other files of this library */
+Scene& wptHostSceneOf(wpt_host_scene* hs) { return *hs->scenePtr; } /* not hs->scene: wptHostFinish replaces the scene */
+void wptHostCameraOf(const wpt_host_scene* hs, float& vfovRadians, vec3& from, vec3& at)
+{
+    vfovRadians = hs->vfov;
+    from = hs->from;
+    at = hs->at;
+}
+
+/* takes ownership of `scene` */
 wpt_host_scene* wptHostFinish(Scene* scene, unsigned int width, unsigned int height, float vfovRadians, const vec3& from,
         const vec3& at, float aperture, float focusDist)
 {
@@ -273,6 +287,12 @@ void wpt_host_scene_set_camera_mode(wpt_host_scene* hs, int surroundMode, float 
 const wpt_scene_desc* wpt_host_scene_desc(const wpt_host_scene* hs) { return &hs->desc; }
 const wpt_camera* wpt_host_scene_camera(const wpt_host_scene* hs) { return &hs->camera; }
 unsigned int wpt_host_scene_bvh_levels(const wpt_host_scene* hs) { return hs->flat.bvhLevels; }
+/* Scene::materialIndex() of every flattened material (material_count ints) */
+void wpt_host_scene_material_scene_index(const wpt_host_scene* hs, int* out)
+{
+    for (size_t i = 0; i < hs->flat.materialSceneIndex.size(); i++)
+        out[i] = hs->flat.materialSceneIndex[i];
+}
 void wpt_host_scene_free(wpt_host_scene* hs) { delete hs; }
 
 /* Default Parameters (wurblpt.hpp:89-95) and SensorRGB gates (sensor_rgb.hpp:41-44) */

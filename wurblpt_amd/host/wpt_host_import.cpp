@@ -13,12 +13,16 @@
 #include "../../include/wurblpt/sensor.hpp"
 #include "../../include/wurblpt/objreader.hpp"
 #include "../../include/wurblpt/postproc.hpp"
+#include "../../include/wurblpt/wurblpt.hpp"
 
 using namespace WurblPT;
 
 struct wpt_host_scene;
 wpt_host_scene* wptHostFinish(Scene* scene, unsigned int width, unsigned int height, float vfovRadians, const vec3& from,
         const vec3& at, float aperture, float focusDist);
+
+Scene& wptHostSceneOf(wpt_host_scene* hs);
+void wptHostCameraOf(const wpt_host_scene* hs, float& vfovRadians, vec3& from, vec3& at);
 
 namespace {
 
@@ -167,6 +171,35 @@ extern "C" int wpt_host_postproc(int op, unsigned int width, unsigned int height
         fprintf(stderr, "wpt_host: %s\n", e.what());
         return 0;
     }
+}
+
+/* getGroundTruth() of include/wurblpt/wurblpt.hpp for a scene of this library with its look-at camera;
+ * prevFromAt / nextFromAt: eye and target (6 floats) of the camera at tPrev / tNext, or NULL.  arrays[k]:
+ * host array of GroundTruth bit k (width * height * components), or NULL.  1 on success. */
+extern "C" int wpt_host_get_ground_truth(wpt_host_scene* hs, unsigned int width, unsigned int height, const float* prevFromAt,
+        const float* nextFromAt, void* const* arrays)
+{
+    float vfov;
+    vec3 from, at;
+    wptHostCameraOf(hs, vfov, from, at);
+    const vec3 up(0.0f, 1.0f, 0.0f);
+    Optics optics(Projection(vfov, float(width) / height), LensDistortion(), LensDepthOfField(0.0f, 1.0f));
+    Camera camera(optics, Transformation::fromLookAt(from, at, up));
+    Camera cameraPrev(optics, prevFromAt ? Transformation::fromLookAt(vec3(prevFromAt), vec3(prevFromAt + 3), up) : camera.transformation);
+    Camera cameraNext(optics, nextFromAt ? Transformation::fromLookAt(vec3(nextFromAt), vec3(nextFromAt + 3), up) : camera.transformation);
+    unsigned int bits = 0;
+    for (int k = 0; k < WPT_GT_ARRAY_COUNT; k++)
+        if (arrays[k])
+            bits |= 1u << k;
+    SensorRGB sensor(width, height);
+    GroundTruth gt = getGroundTruth(sensor, camera, prevFromAt ? &cameraPrev : nullptr, nextFromAt ? &cameraNext : nullptr,
+            wptHostSceneOf(hs), bits);
+    void* src[WPT_GT_ARRAY_COUNT];
+    gt.arrayPointers(src);
+    for (int k = 0; k < WPT_GT_ARRAY_COUNT; k++)
+        if (arrays[k])
+            memcpy(arrays[k], src[k], size_t(width) * height * wpt_gt_components[k] * 4);
+    return 1;
 }
 
 /* importIntoScene (include/wurblpt/import.hpp) + a constant environment of the given radiance (0 = none)
