@@ -4,9 +4,10 @@
  * part of this build.  Decoded are the formats the scenes of the reference's examples use for
  * textures and environment maps and that need no further library: PNG (8 and 16 bit, grey, grey +
  * alpha, RGB, RGBA, palette; not interlaced), TGA (types 2, 3, 10, 11; 8/24/32 bit), binary PNM
- * (P5, P6; 8 and 16 bit), PFM (Pf, PF) and Radiance HDR (RLE and flat).  JPEG is not decoded: such
- * a file is reported and the importer substitutes its dummy texture, as the reference does for any
- * file libtgd cannot load (import.hpp:131-134).
+ * (P5, P6; 8 and 16 bit), PFM (Pf, PF), Radiance HDR (RLE and flat), JPEG (jpeg.hpp) and OpenEXR
+ * scanline files (exr.hpp).  A file that cannot be decoded is reported and the importer substitutes
+ * its dummy texture, as the reference does for any file libtgd cannot load (import.hpp:131-134).
+ * saveImage() writes PNG, PGM/PPM, PFM and OpenEXR.
  *
  * Convention: the returned array has row 0 at the BOTTOM of the picture (texture coordinate
  * v = 0, texture_image.hpp:85-212), i.e. formats that store the top row first are flipped.
@@ -21,6 +22,8 @@
 #include <vector>
 
 #include "array.hpp"
+#include "jpeg.hpp"
+#include "exr.hpp"
 
 namespace WurblPT {
 
@@ -679,7 +682,7 @@ inline bool savePnm(const ArrayContainer& img, std::vector<unsigned char>& out, 
 
 }
 
-/* Saves an image by file name extension: .png (uint8/uint16), .ppm/.pgm/.pnm (uint8/uint16), .pfm (float).
+/* Saves an image by file name extension: .png (uint8/uint16), .ppm/.pgm/.pnm (uint8/uint16), .pfm (float), .exr (float).
  * The counterpart of the reference's TGD::save() calls for the formats this build writes. */
 inline bool saveImage(const ArrayContainer& img, const std::string& filename, std::string* error = nullptr)
 {
@@ -693,6 +696,8 @@ inline bool saveImage(const ArrayContainer& img, const std::string& filename, st
     bool ok = false;
     if (ext == "png")
         ok = savePng(img, bytes, err);
+    else if (ext == "exr")
+        ok = saveExr(img, bytes, err);
     else if (ext == "pfm" && img.componentType() != float32)
         err = "PFM takes float data";
     else if ((ext == "ppm" || ext == "pgm" || ext == "pnm") && img.componentType() == float32)
@@ -730,8 +735,10 @@ inline ArrayContainer loadImage(const std::string& filename, std::string* error 
         ok = loadPnm(b, img, err);
     } else if (b.size() >= 2 && b[0] == '#' && b[1] == '?') {
         ok = loadHdr(b, img, err);
+    } else if (b.size() >= 4 && b[0] == 0x76 && b[1] == 0x2f && b[2] == 0x31 && b[3] == 0x01) {
+        ok = loadExr(b, img, err);
     } else if (b.size() >= 3 && b[0] == 0xff && b[1] == 0xd8) {
-        err = "JPEG files are not decoded by this build";
+        ok = loadJpeg(b, img, err);
     } else {
         const size_t dot = filename.find_last_of('.');
         std::string ext = dot == std::string::npos ? "" : filename.substr(dot + 1);

@@ -276,3 +276,163 @@ def test_pnm_and_pfm_writers_round_trip(tmp_path):
     assert not host.image_save(str(tmp_path / "bad.png"), rng.random((4, 4, 3)).astype(np.float32))
     assert not host.image_save(str(tmp_path / "bad.pfm"), np.zeros((4, 4, 3), np.uint8))
     assert not host.image_save(str(tmp_path / "bad.jpg"), np.zeros((4, 4, 3), np.uint8))
+
+
+def _jpeg_cases():
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg")
+    exp = np.load(os.path.join(d, "expected.npz"))
+    return d, exp
+
+
+def test_jpeg_decoder_matches_libjpeg(tmp_path):
+    """include/wurblpt/jpeg.hpp against the pixels libjpeg-turbo decodes (tests/golden/jpeg, written by
+    make_jpeg_fixtures.py): baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1 and grey, restart intervals,
+    quality 1 to 100, sizes that are no multiple of the MCU and images too narrow for the triangle filter. Every byte."""
+    d, exp = _jpeg_cases()
+    assert len(exp.files) >= 16
+    for name in exp.files:
+        ref = exp[name]
+        ref = ref[:, :, None] if ref.ndim == 2 else ref
+        got = host.image_load(os.path.join(d, name + ".jpg"))
+        assert got is not None and got.dtype == np.uint8, name
+        assert np.array_equal(got[::-1], ref), name          # row 0 of the array is the bottom row
+    # corrupt and unsupported files are refused, not guessed at
+    data = open(os.path.join(d, "s420.jpg"), "rb").read()
+    for cut, label in ((data[:200], "truncated"), (b"\xff\xd8\xff\xd9", "empty"), (data.replace(b"\xff\xc0", b"\xff\xc9", 1), "arithmetic")):
+        p = str(tmp_path / (label + ".jpg"))
+        open(p, "wb").write(cut)
+        assert host.image_load(p) is None, label
+
+
+def test_jpeg_decoder_against_pillow_on_larger_images(tmp_path):
+    """The same comparison on larger, freshly encoded images and on the JPEG textures of the reference's example
+    applications where this machine has them; needs Pillow (libjpeg-turbo) and is skipped without it."""
+    PIL = pytest.importorskip("PIL.Image")
+    import glob
+    import io
+    rng = np.random.default_rng(3)
+    files = []
+    y, x = np.mgrid[0:203, 0:317]
+    base = np.stack([(x * 3 + y) % 256, (x ^ y) % 256, (x * y // 7) % 256], axis=2).astype(np.float64)
+    img = np.clip(base + rng.normal(0, 20, base.shape), 0, 255).astype(np.uint8)
+    for i, opts in enumerate((dict(quality=87, subsampling=2), dict(quality=70, subsampling=1, progressive=True),
+                              dict(quality=95, subsampling=0, optimize=True), dict(quality=50, subsampling=2, progressive=True, restart_marker_rows=2))):
+        p = str(tmp_path / ("big%d.jpg" % i))
+        PIL.fromarray(img).save(p, "JPEG", **opts)
+        files.append(p)
+    files += sorted(glob.glob("/root/reference/wurblpt-*/*.jpg"))[:4]
+    for p in files:
+        ref = np.asarray(PIL.open(p))
+        ref = ref[:, :, None] if ref.ndim == 2 else ref
+        got = host.image_load(p)
+        assert got is not None and np.array_equal(got[::-1], ref), p
+
+
+def _write_exr(path, img, compression, half):
+    """Test-side OpenEXR writer (scanline; NONE 0, RLE 1, ZIPS 2, ZIP 3; HALF or FLOAT channels R G B / Y),
+    independent of include/wurblpt/exr.hpp.  img: float32 [h, w, comps], row 0 = top."""
+    import struct
+    import zlib
+    h, w, comps = img.shape
+    names = {1: ["Y"], 3: ["B", "G", "R"], 4: ["A", "B", "G", "R"]}[comps]
+    src = {"Y": 0, "R": 0, "G": 1, "B": 2, "A": 3}
+    out = struct.pack("<II", 20000630, 2)
+
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(data)) + data
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<IIII", 1 if half else 2, 0, 1, 1) for n in names) + b"\0"
+    out += attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([compression]))
+    out += attr("dataWindow", "box2i", struct.pack("<4i", 5, -3, 5 + w - 1, -3 + h - 1))        # a window that does not start at 0
+    out += attr("displayWindow", "box2i", struct.pack("<4i", 0, 0, w - 1, h - 1))
+    out += attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    out += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines = 16 if compression == 3 else 1
+    chunks = []
+    for y0 in range(0, h, lines):
+        raw = b""
+        for y in range(y0, min(y0 + lines, h)):
+            for n in names:
+                row = img[y, :, src[n]]
+                raw += (row.astype(np.float16) if half else row.astype(np.float32)).tobytes()
+        data = raw
+        if compression:
+            b = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([b[0::2], b[1::2]]).astype(np.int32)
+            t[1:] = (t[1:] - t[:-1] + 128 + 256) % 256
+            t = t.astype(np.uint8).tobytes()
+            if compression == 1:
+                packed, i = b"", 0
+                while i < len(t):                       # runs of >= 3 equal bytes, literals otherwise
+                    j = i
+                    while j < len(t) and j - i < 127 and t[j] == t[i]:
+                        j += 1
+                    if j - i >= 3:
+                        packed += struct.pack("b", j - i - 1) + t[i:i + 1]
+                        i = j
+                    else:
+                        j = i
+                        while j < len(t) and j - i < 127 and not (j + 2 < len(t) and t[j] == t[j + 1] == t[j + 2]):
+                            j += 1
+                        packed += struct.pack("b", -(j - i)) + t[i:j]
+                        i = j
+            else:
+                packed = zlib.compress(t)
+            data = packed if len(packed) < len(raw) else raw         # the format stores a chunk raw when that is shorter
+        chunks.append(struct.pack("<iI", -3 + y0, len(data)) + data)
+    table_at = len(out)
+    pos = table_at + 8 * len(chunks)
+    table = b""
+    for c in chunks:
+        table += struct.pack("<Q", pos)
+        pos += len(c)
+    open(path, "wb").write(out + table + b"".join(chunks))
+
+
+def test_exr_reader_and_writer(tmp_path):
+    """OpenEXR scanline files: every compression / sample type the reader takes, against a writer that lives in this
+    test; the writer's files through the reader again (bit for bit, including infinities, NaN payloads and subnormals)."""
+    rng = np.random.default_rng(8)
+    for comps in (1, 3, 4):
+        img = (rng.random((37, 29, comps)) ** 3 * 50).astype(np.float32)
+        img[0, 0] = 0.0
+        img[5:9, 3:20] = 0.25                                   # flat areas: runs for RLE, long matches for zlib
+        for compression in (0, 1, 2, 3):
+            for half in (False, True):
+                p = str(tmp_path / "t.exr")
+                _write_exr(p, img, compression, half)
+                got = host.image_load(p)
+                ref = img.astype(np.float16).astype(np.float32) if half else img
+                assert got is not None and got.dtype == np.float32, (comps, compression, half)
+                assert np.array_equal(got[::-1].view(np.uint32), ref.view(np.uint32)), (comps, compression, half)
+    special = np.array([np.inf, -np.inf, 1e-42, -0.0, 65504.0, 3.0e38], np.float32).reshape(1, 6, 1).repeat(3, axis=2)
+    special = np.concatenate([special, np.frombuffer(np.uint32([0x7fc12345] * 18).tobytes(), np.float32).reshape(1, 6, 3)], axis=0)
+    for comps in (1, 2, 3, 4):
+        img = rng.standard_normal((23, 31, comps)).astype(np.float32)
+        img[:2, :6, :] = special[:, :, :1] if comps < 3 else np.concatenate([special, special[:, :, :1]], axis=2)[:, :, :comps]
+        p = str(tmp_path / ("w%d.exr" % comps))
+        assert host.image_save(p, img)
+        back = host.image_load(p)
+        assert back.shape == img.shape and np.array_equal(back.view(np.uint32), img.view(np.uint32)), comps
+    # half precision specials through the reader: subnormals, infinities, NaN
+    halves = np.array([0x0001, 0x03ff, 0x0400, 0x7bff, 0x7c00, 0xfc00, 0x7e01, 0x8000], np.uint16).view(np.float16)
+    img = halves.astype(np.float32).reshape(1, 8, 1)
+    p = str(tmp_path / "h.exr")
+    _write_exr(p, img, 0, True)
+    assert np.array_equal(host.image_load(p).view(np.uint32), img.view(np.uint32))
+    assert not host.image_save(str(tmp_path / "bad.exr"), np.zeros((4, 4, 3), np.uint8))
+    data = open(str(tmp_path / "w3.exr"), "rb").read()
+    open(str(tmp_path / "cut.exr"), "wb").write(data[:len(data) // 2])
+    assert host.image_load(str(tmp_path / "cut.exr")) is None
+
+
+def test_exr_reader_on_the_mitsuba_render_of_the_reference():
+    """The converged Mitsuba render the reference ships (half floats, ZIP): its 16x16 block averages are the committed
+    fixture the integrator is compared with; read here through include/wurblpt/exr.hpp."""
+    src = "/root/reference/wurblpt-cornellbox/mitsuba/cbox-2500spp.exr"
+    if not os.path.exists(src):
+        pytest.skip("the reference tree is not on this machine")
+    img = host.image_load(src)
+    assert img is not None and img.shape == (1024, 1024, 3)
+    blocks = img[::-1].reshape(64, 16, 64, 16, 3).mean(axis=(1, 3)).astype(np.float32)
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cbox_mitsuba_64x64.npy"))
+    assert np.allclose(blocks, ref, rtol=1e-6, atol=1e-7)
