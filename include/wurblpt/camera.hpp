@@ -1,12 +1,15 @@
 /*
  * camera.hpp -- camera description (reference camera.hpp:42-120).  Ray generation itself
  * (camera.hpp:123-185) runs in the HIP kernel from the wpt_camera record made here.
- * Camera animation is outside the device path; surround and stereoscopic modes, lens distortion and
- * depth of field are part of the record.
+ * Surround and stereoscopic modes, lens distortion and depth of field are part of the record; an
+ * animated camera is described at t0 and its key frames go to the kernel with the scene's (mcpt()).
  */
 #pragma once
 
 #include "../wurblpt_hip.h"
+#include <memory>
+
+#include "animation.hpp"
 #include "optics.hpp"
 #include "transformation.hpp"
 
@@ -21,6 +24,7 @@ public:
     float stereoscopicDistance;
     Optics optics;
     Transformation transformation;
+    std::shared_ptr<const Animation> animation; /* takes the place of `transformation` when set; owned by the camera */
 
     Camera(SurroundMode surroundMode, float stereoscopicDistance, const Optics& optics,
             const Transformation& transformation = Transformation()) :
@@ -32,11 +36,23 @@ public:
     {
     }
 
-    Transformation at(float /* t */ = 0.0f) const { return transformation; }
-
-    /* false if this camera needs a feature the kernel does not have */
-    bool describe(wpt_camera& out) const
+    Camera(SurroundMode surroundMode, float stereoscopicDistance, const Optics& optics, const Animation* animation) :
+        surroundMode(surroundMode), stereoscopicDistance(stereoscopicDistance), optics(optics), transformation(), animation(animation)
     {
+    }
+    Camera(const Optics& optics, const Animation* animation) :
+        surroundMode(Surround_Off), stereoscopicDistance(0.0f), optics(optics), transformation(), animation(animation)
+    {
+    }
+
+    Transformation at(float t = 0.0f) const { return animation ? animation->at(t) : transformation; }
+
+    /* The camera at time t0 (Camera::getRayHelper, camera.hpp:114-120); false if it needs a feature the kernel
+     * does not have.  out.animation is -1: the caller enters the index of the key frames in the scene's pool. */
+    bool describe(wpt_camera& out, float t0 = 0.0f) const
+    {
+        const Transformation transformation = at(t0);
+        out.animation = -1;
         out.surround_mode = surroundMode == Surround_180 ? WPT_SURROUND_180 : surroundMode == Surround_360 ? WPT_SURROUND_360 : WPT_SURROUND_OFF;
         out.stereoscopic_distance = stereoscopicDistance;
         out.l = optics.projection.l;

@@ -263,6 +263,33 @@ template<typename T> struct quaternion {
 };
 typedef quaternion<float> quat;
 
+/* spherical linear interpolation (reference gvm.hpp:1765-1797) */
+template<typename T> quaternion<T> slerp(const quaternion<T>& q, const quaternion<T>& r, T alpha)
+{
+    quaternion<T> w = r;
+    T cosHalfAngle = q.x * r.x + q.y * r.y + q.z * r.z + q.w * r.w;
+    if (cosHalfAngle < T(0)) { /* q and -q are the same rotation */
+        w = quaternion<T>(-w.x, -w.y, -w.z, -w.w);
+        cosHalfAngle = -cosHalfAngle;
+    }
+    T tmpQ, tmpW;
+    if (cosHalfAngle >= T(1)) {
+        tmpQ = T(1);
+        tmpW = T(0);
+    } else {
+        T halfAngle = std::acos(cosHalfAngle);
+        T sinHalfAngle = std::sqrt(T(1) - cosHalfAngle * cosHalfAngle);
+        if (std::abs(sinHalfAngle) < epsilon_v<T>) {
+            tmpQ = T(0.5);
+            tmpW = T(0.5);
+        } else {
+            tmpQ = std::sin((T(1) - alpha) * halfAngle) / sinHalfAngle;
+            tmpW = std::sin(alpha * halfAngle) / sinHalfAngle;
+        }
+    }
+    return quaternion<T>(q.x * tmpQ + w.x * tmpW, q.y * tmpQ + w.y * tmpW, q.z * tmpQ + w.z * tmpW, q.w * tmpQ + w.w * tmpW);
+}
+
 /* Duff et al. orthonormal basis helper (reference gvm.hpp:1828-1835) */
 template<typename T> vector<T, 3> someTangentTo(const vector<T, 3>& v)
 {

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../wurblpt_hip.h"
+#include "animation.hpp"
 #include "bvh.hpp"
 #include "envmap.hpp"
 #include "material.hpp"
@@ -68,7 +69,35 @@ public:
     std::vector<float> rglData;
     wpt_envmap envmap;
     size_t bvhLevels = 0;
+    std::vector<wpt_animation> animations; /* the scene's animations, then whatever addAnimation() appended (the camera's) */
+    std::vector<wpt_keyframe> keyframes;
     std::vector<int> materialSceneIndex; /* per flattened material: Scene::materialIndex() of it, -1 if the scene does not own it */
+
+    /* appends an animation to the pool; -1 if it is not a key frame animation */
+    int addAnimation(const Animation* anim)
+    {
+        const AnimationKeyframes* kf = dynamic_cast<const AnimationKeyframes*>(anim);
+        if (!kf)
+            return -1;
+        wpt_animation a;
+        a.first_keyframe = keyframes.size();
+        a.keyframe_count = kf->keyframes().size();
+        for (const AnimationKeyframes::Keyframe& k : kf->keyframes()) {
+            wpt_keyframe r;
+            r.t = k.t;
+            for (int i = 0; i < 3; i++) {
+                r.translation[i] = k.transformation.translation[i];
+                r.scaling[i] = k.transformation.scaling[i];
+            }
+            r.rotation[0] = k.transformation.rotation.x;
+            r.rotation[1] = k.transformation.rotation.y;
+            r.rotation[2] = k.transformation.rotation.z;
+            r.rotation[3] = k.transformation.rotation.w;
+            keyframes.push_back(r);
+        }
+        animations.push_back(a);
+        return int(animations.size()) - 1;
+    }
 
     wpt_scene_desc desc() const
     {
@@ -97,6 +126,10 @@ public:
         d.rgl_data_count = rglData.size();
         d.rgl_brdfs = rglBrdfs.data();
         d.rgl_data = rglData.data();
+        d.animation_count = animations.size();
+        d.keyframe_count = keyframes.size();
+        d.animations = animations.data();
+        d.keyframes = keyframes.data();
         return d;
     }
 };
@@ -122,9 +155,12 @@ private:
     std::vector<std::unique_ptr<Hitable>> _handles;
     std::vector<const Hitable*> _hotSpots;
     std::unique_ptr<EnvironmentMap> _envmap;
+    std::vector<std::unique_ptr<Animation>> _animations;
+    std::vector<const Animation*> _animationsForCaching;
     std::vector<wpt_bvh_node> _bvh;
     size_t _bvhLevels;
     bool _bvhNeedsRebuild;
+    float _bvhT0, _bvhT1;
     std::map<const Material*, int> _materialMap;
     std::vector<std::string> _materialNames;
     std::string _error;
@@ -143,7 +179,55 @@ private:
     }
 
 public:
-    Scene() : _bvhLevels(0), _bvhNeedsRebuild(true) {}
+    Scene() : _bvhLevels(0), _bvhNeedsRebuild(true), _bvhT0(0.0f), _bvhT1(0.0f) {}
+
+    /* Returns the index mesh instances refer to (scene.hpp:86-91).  Camera animations stay with the camera. */
+    int take(Animation* anim)
+    {
+        _animations.push_back(std::unique_ptr<Animation>(anim));
+        _animationsForCaching.push_back(anim);
+        return int(_animations.size()) - 1;
+    }
+    const std::vector<const Animation*>& animations() const { return _animationsForCaching; }
+
+private:
+    /* HitableTriangle::aabb (hitable_triangle.hpp:336-393) for an animated instance: the box at t0, widened by
+     * intermediate shapes when the rotation changes over the interval.  As there, the second set of corners is
+     * taken from the t0 matrix again, so a pure translation between t0 and t1 does not widen the box. */
+    AABB animatedBox(const vec3 v[3], int ai, AnimationCache& animationCacheT0, AnimationCache& animationCacheT1) const
+    {
+        const Transformation& T0 = animationCacheT0.get(ai);
+        const Transformation& T1 = animationCacheT1.get(ai);
+        const mat4& M0 = animationCacheT0.getM(ai);
+        vec3 v00 = (M0 * vec4(v[0], 1.0f)).xyz();
+        vec3 v01 = (M0 * vec4(v[1], 1.0f)).xyz();
+        vec3 v02 = (M0 * vec4(v[2], 1.0f)).xyz();
+        if (T0 == T1)
+            return AABB(min(v00, v01, v02), max(v00, v01, v02));
+        const mat4& M1 = animationCacheT0.getM(ai);
+        vec3 v10 = (M1 * vec4(v[0], 1.0f)).xyz();
+        vec3 v11 = (M1 * vec4(v[1], 1.0f)).xyz();
+        vec3 v12 = (M1 * vec4(v[2], 1.0f)).xyz();
+        AABB box = merge(AABB(min(v00, v01, v02), max(v00, v01, v02)), AABB(min(v10, v11, v12), max(v10, v11, v12)));
+        if (T0.rotation != T1.rotation) {
+            unsigned int samples = 4;
+            float cosHalfAngle = dot(vec4(T0.rotation.x, T0.rotation.y, T0.rotation.z, T0.rotation.w),
+                    vec4(T1.rotation.x, T1.rotation.y, T1.rotation.z, T1.rotation.w));
+            if (std::abs(cosHalfAngle) < 1.0f)
+                samples += degrees(std::acos(cosHalfAngle)) * 2.0f;
+            for (unsigned int i = 1; i < samples - 1; i++) {
+                float alpha = i / (samples - 1.0f);
+                Transformation T = mix(T0, T1, alpha);
+                vec3 vt0 = T * v[0];
+                vec3 vt1 = T * v[1];
+                vec3 vt2 = T * v[2];
+                box = merge(box, AABB(min(vt0, vt1, vt2), max(vt0, vt1, vt2)));
+            }
+        }
+        return box;
+    }
+
+public:
 
     Mesh* take(Mesh* mesh)
     {
@@ -168,8 +252,8 @@ public:
     std::vector<const Hitable*> take(MeshInstance* instance, HotSpotType hotSpotType = ColdSpot)
     {
         std::vector<const Hitable*> handles;
-        if (instance->animationIndex >= 0)
-            _error = "animated mesh instances are outside the device path";
+        if (instance->animationIndex >= int(_animations.size()))
+            _error = "a mesh instance refers to an animation the scene does not have";
         unsigned int instanceIndex = _instances.size();
         _instances.push_back(instance);
         size_t n = instance->mesh->triangleCount();
@@ -212,7 +296,10 @@ public:
         return envmap;
     }
 
-    bool bvhNeedsUpdate(float /* t0 */ = 0.0f, float /* t1 */ = 0.0f) const { return _bvhNeedsRebuild; }
+    bool bvhNeedsUpdate(float t0 = 0.0f, float t1 = 0.0f) const
+    {
+        return _bvhNeedsRebuild || (_animations.size() > 0 && (_bvhT0 > t0 || _bvhT1 < t1));
+    }
 
     void updateBVH(float t0 = 0.0f, float t1 = 0.0f)
     {
@@ -222,11 +309,17 @@ public:
         }
         fprintf(stderr, "Building bounding volume hierarchy for %zu hitables\n", _hitables.size());
         std::vector<AABB> boxes(_hitables.size());
+        AnimationCache animationCacheT0(animations(), t0);
+        AnimationCache animationCacheT1(animations(), t1);
         for (size_t i = 0; i < _hitables.size(); i++) {
             if (_hitables[i].kind == WPT_NODE_TRIANGLE) {
                 vec3 v[3];
-                corners(_triangles[_hitables[i].index], v);
-                boxes[i] = AABB(min(v[0], v[1], v[2]), max(v[0], v[1], v[2]));
+                const Triangle& tri = _triangles[_hitables[i].index];
+                corners(tri, v);
+                if (tri.instance->animationIndex >= 0)
+                    boxes[i] = animatedBox(v, tri.instance->animationIndex, animationCacheT0, animationCacheT1);
+                else
+                    boxes[i] = AABB(min(v[0], v[1], v[2]), max(v[0], v[1], v[2]));
             } else {
                 /* HitableSphere::aabb (hitable_sphere.hpp:88-91) */
                 const Sphere* sp = _spheres[_hitables[i].index];
@@ -245,6 +338,8 @@ public:
         }
         fprintf(stderr, "Linearized bounding volume hierarchy with %zu nodes on %zu levels\n", _bvh.size(), _bvhLevels);
         _bvhNeedsRebuild = false;
+        _bvhT0 = t0;
+        _bvhT1 = t1;
     }
 
     const std::vector<const Hitable*>& hotSpots() const { return _hotSpots; }
@@ -276,6 +371,9 @@ public:
         out = FlatScene();
         out.nodes = _bvh;
         out.bvhLevels = _bvhLevels;
+        for (const Animation* anim : _animationsForCaching)
+            if (out.addAnimation(anim) < 0)
+                return fail("only key frame animations (AnimationKeyframes) can go to the device");
         out.instances.resize(_instances.size());
         for (size_t i = 0; i < _instances.size(); i++) {
             const MeshInstance* inst = _instances[i];
@@ -288,7 +386,8 @@ public:
                 return fail(ctx.error);
             r.material = m;
             r.flags = (inst->mesh->haveTexCoords ? WPT_TRI_HAVE_TEXCOORDS : 0) | (inst->mesh->haveTangents ? WPT_TRI_HAVE_TANGENTS : 0)
-                | (inst->transformation.isIdentity() ? 0 : WPT_TRI_TRANSFORM);
+                | (inst->transformation.isIdentity() ? 0 : WPT_TRI_TRANSFORM) | (inst->animationIndex >= 0 ? WPT_TRI_ANIMATE : 0);
+            r.animation = inst->animationIndex >= 0 ? inst->animationIndex : -1;
         }
         out.triGeom.resize(_triangles.size());
         out.triAttr.resize(_triangles.size());
@@ -346,6 +445,7 @@ public:
             const HitableRef& ref = _hitables[_hotSpots[i]->index];
             wpt_hotspot& h = out.hotspots[i];
             memset(&h, 0, sizeof(h));
+            h.animation = -1;
             h.prim = ref.index;
             if (ref.kind == WPT_NODE_SPHERE) {
                 h.kind = WPT_HOTSPOT_SPHERE;
@@ -353,6 +453,7 @@ public:
             }
             h.kind = WPT_HOTSPOT_TRIANGLE;
             const Triangle& t = _triangles[ref.index];
+            h.animation = t.instance->animationIndex >= 0 ? t.instance->animationIndex : -1;
             const Mesh* mesh = t.instance->mesh;
             h.transform = t.instance->transformation.isIdentity() ? 0 : 1;
             float* p[3] = { h.p0, h.p1, h.p2 };

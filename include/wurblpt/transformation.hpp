@@ -67,6 +67,11 @@ public:
 inline Transformation translate(const Transformation& T, const vec3& v) { Transformation R = T; R.translate(v); return R; }
 inline Transformation rotate(const Transformation& T, const quat& q) { Transformation R = T; R.rotate(q); return R; }
 inline Transformation scale(const Transformation& T, const vec3& s) { Transformation R = T; R.scale(s); return R; }
+/* positions and scalings linearly, rotations by slerp (transformation.hpp:199-205) */
+inline Transformation mix(const Transformation& T0, const Transformation& T1, float alpha)
+{
+    return Transformation(mix(T0.translation, T1.translation, alpha), slerp(T0.rotation, T1.rotation, alpha), mix(T0.scaling, T1.scaling, alpha));
+}
 inline Transformation operator*(const Transformation& S, const Transformation& T)
 {
     return scale(rotate(translate(S, T.translation), T.rotation), T.scaling);

@@ -55,6 +55,8 @@ inline wpt_params makeParams(const Parameters& params, const SensorRGB& sensor)
     p.max_dist_to_light = sensor.maxDistToLight;
     p.min_path_len = sensor.minPathLen;
     p.max_path_len = sensor.maxPathLen;
+    p.t0 = 0.0f;
+    p.t1 = 0.0f;
     return p;
 }
 
@@ -68,21 +70,27 @@ inline void mcpt(MPICoordinator& mpiCoordinator, Sensor& sensor, const Camera& c
         unsigned int samplesSqrt, float t0 = 0.0f, float t1 = 0.0f, const Parameters& params = Parameters())
 {
     if (scene.bvhNeedsUpdate(t0, t1))
-        mcptFatal("Scene::updateBVH() must run before mcpt()");
-    if (t0 != t1)
-        mcptFatal("motion blur (t0 != t1) is outside the device path");
+        mcptFatal("Scene::updateBVH(t0, t1) must run before mcpt()");
     SensorRGB* rgb = dynamic_cast<SensorRGB*>(&sensor);
     if (!rgb)
         mcptFatal("only SensorRGB runs on the device path");
     wpt_camera cam;
-    if (!camera.describe(cam))
+    if (!camera.describe(cam, t0))
         mcptFatal("this camera cannot be described to the device path");
     FlatScene flat;
     std::string error;
     if (!scene.flatten(flat, &error))
         mcptFatal(error);
+    if (camera.animation) {
+        /* the camera's key frames join the scene's pool; rays take them at their own time when t0 != t1 */
+        cam.animation = flat.addAnimation(camera.animation.get());
+        if (cam.animation < 0)
+            mcptFatal("only key frame animations (AnimationKeyframes) can go to the device");
+    }
     const wpt_scene_desc desc = flat.desc();
-    const wpt_params p = makeParams(params, *rgb);
+    wpt_params p = makeParams(params, *rgb);
+    p.t0 = t0;
+    p.t1 = t1;
     const unsigned int width = sensor.width();
     const unsigned int height = sensor.height();
     ArrayContainer* pixelArray = sensor.pixelArray();
@@ -250,6 +258,8 @@ inline GroundTruth getGroundTruth(const Sensor& sensor, const Camera& camera, co
     p.max_dist_to_light = std::numeric_limits<float>::max();
     p.min_path_len = 0.0f;
     p.max_path_len = std::numeric_limits<float>::max();
+    p.t0 = 0.0f;
+    p.t1 = 0.0f;
     const unsigned int width = sensor.width();
     const unsigned int height = sensor.height();
     GroundTruth gt(width, height, groundTruthBits);

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define WPT_ABI_VERSION 4u
+#define WPT_ABI_VERSION 5u
 
 typedef enum {
     WPT_OK = 0,
@@ -62,11 +62,13 @@ typedef struct wpt_bvh_node {
 } wpt_bvh_node;
 
 /* Triangle flags; mirror the HitableTriangle template arguments (hitable_triangle.hpp:36) */
-enum { WPT_TRI_HAVE_TEXCOORDS = 1, WPT_TRI_HAVE_TANGENTS = 2, WPT_TRI_TRANSFORM = 4 };
+enum { WPT_TRI_HAVE_TEXCOORDS = 1, WPT_TRI_HAVE_TANGENTS = 2, WPT_TRI_TRANSFORM = 4, WPT_TRI_ANIMATE = 8 };
 
 /* Intersection stream: world-space positions of one triangle (48 bytes).  With
  * WPT_TRI_TRANSFORM the positions are the instance's mat4 applied on the host with
- * the arithmetic of hitable_triangle.hpp:203-206, which is the value hit() recomputes per call. */
+ * the arithmetic of hitable_triangle.hpp:203-206, which is the value hit() recomputes per call.
+ * With WPT_TRI_ANIMATE the instance's animation at the ray's time is applied to them in the
+ * kernel (hitable_triangle.hpp:209-218). */
 typedef struct wpt_tri_geom {
     float v0[3];
     uint32_t instance;
@@ -89,8 +91,22 @@ typedef struct wpt_instance {
     float N[9];
     uint32_t material;
     uint32_t flags;
-    uint32_t reserved;
+    int32_t animation; /* MeshInstance::animationIndex: index into wpt_scene_desc::animations, -1 = none */
 } wpt_instance;
+
+/* Animations (animation_keyframes.hpp): key frames sorted by time; the transformation at a time is the
+ * first / last key frame outside their range and mix() of the two neighbours inside (translation and
+ * scaling linear, rotation by slerp).  The pool also holds the camera's animation (wpt_camera::animation). */
+typedef struct wpt_keyframe {
+    float t;
+    float translation[3];
+    float rotation[4]; /* quaternion x, y, z, w */
+    float scaling[3];
+} wpt_keyframe;
+typedef struct wpt_animation {
+    uint32_t first_keyframe;
+    uint32_t keyframe_count;
+} wpt_animation;
 
 /* A sphere (HitableSphere, hitable_sphere.hpp:32-76): centre = T.translation, radius =
  * max(T.scaling), rotation = T.rotation (turns the normal into texture space). 48 bytes. */
@@ -111,7 +127,7 @@ typedef struct wpt_hotspot {
     uint32_t prim;
     uint32_t transform;
     uint32_t kind;
-    uint32_t reserved;
+    int32_t animation; /* of the triangle's instance, -1 = none */
     float p0[3], p1[3], p2[3];
     float M[16];
 } wpt_hotspot;
@@ -242,6 +258,10 @@ typedef struct wpt_scene_desc {
     uint64_t rgl_data_count; /* floats in rgl_data */
     const wpt_rgl_brdf* rgl_brdfs;
     const float* rgl_data;
+    uint32_t animation_count;
+    uint32_t keyframe_count;
+    const wpt_animation* animations;
+    const wpt_keyframe* keyframes;
 } wpt_scene_desc;
 
 /* ---- camera, parameters ---------------------------------------------- */
@@ -267,6 +287,9 @@ typedef struct wpt_camera {
      * cameras ignore the optics; a stereoscopic camera renders the left view into the upper half */
     uint32_t surround_mode; /* WPT_SURROUND_* */
     float stereoscopic_distance;
+    /* Camera::animation: index into the scene's animation pool or -1.  translation / rotation / scaling
+     * above hold Camera::at(t0); with t0 != t1 a ray takes the animation at its own time (camera.hpp:175-180). */
+    int32_t animation;
 } wpt_camera;
 
 /* Parameters (wurblpt.hpp:79-96) plus the SensorRGB gates (sensor_rgb.hpp:41-51). */
@@ -277,6 +300,7 @@ typedef struct wpt_params {
     float min_hit_distance;
     float min_dist_to_light, max_dist_to_light;
     float min_path_len, max_path_len;
+    float t0, t1; /* mcpt()'s exposure interval: with t0 != t1 every camera ray draws its time in it (motion blur) */
 } wpt_params;
 
 /* Work counters of one render call; the roofline denominator. */

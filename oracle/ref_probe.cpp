@@ -35,6 +35,7 @@
 #include "geometryproc.hpp"
 #include "hitable_sphere.hpp"
 #include "color.hpp"
+#include "animation_keyframes.hpp"
 #define POWITACQ_IMPLEMENTATION
 #include "powitacq_rgb.h"
 #define TINYOBJLOADER_IMPLEMENTATION
@@ -883,6 +884,50 @@ int main(int argc, char* argv[])
         }
         ints("obj_material_strings", matStrings);  /* per material: name, then 7 texture names (diffuse specular shininess bump alpha emissive normal) */
         floats("obj_material_floats", matFloats);  /* per material: Kd Ks Ke Tf (3 each) Ns d Ni, then per texture scale(3) offset(3) bm */
+    }
+
+    /* ---- AnimationKeyframes::at, Transformation::toMat4 / toNormalMatrix / operator* (animation_keyframes.hpp:186-214,
+     * transformation.hpp:80-83,105-122,199-205, quaternion slerp gvm.hpp:1765-1797) ---- */
+    {
+        AnimationKeyframes anim;
+        const vec3 axes[5] = { vec3(0.0f, 1.0f, 0.0f), vec3(1.0f, 0.3f, -0.2f), vec3(-0.4f, 0.1f, 1.0f), vec3(0.0f, 0.0f, 1.0f), vec3(0.7f, -0.7f, 0.1f) };
+        const float angles[5] = { 0.0f, 40.0f, 170.0f, 260.0f, 260.0f };    /* 170 -> 260 degrees: slerp meets a negative dot product; the last two rotate alike */
+        const float times[5] = { -0.5f, 0.25f, 1.0f, 1.75f, 4.0f };
+        std::vector<float> kf;
+        for (int k = 0; k < 5; k++) {
+            Transformation T(vec3(0.3f * k - 0.5f, 0.2f * k * k, -0.7f * k + 0.1f), toQuat(radians(angles[k]), axes[k == 4 ? 3 : k]),
+                    vec3(1.0f + 0.25f * k, 1.0f, 1.0f - 0.1f * k));
+            anim.addKeyframe(times[k], T);
+            kf.push_back(times[k]);
+            push3(kf, T.translation);
+            kf.push_back(T.rotation.x); kf.push_back(T.rotation.y); kf.push_back(T.rotation.z); kf.push_back(T.rotation.w);
+            push3(kf, T.scaling);
+        }
+        std::vector<float> ts, res;
+        Prng prng(5);
+        for (int i = 0; i < 96; i++) {
+            float t = i < 5 ? times[i] : i < 8 ? (i == 5 ? -3.0f : i == 6 ? 9.0f : 0.25f + 1e-7f) : -0.7f + 5.0f * prng.in01();
+            Transformation T = anim.at(t);
+            mat4 M = T.toMat4();
+            mat3 N = T.toNormalMatrix();
+            vec3 p = vec3(prng.in01() - 0.5f, prng.in01() - 0.5f, prng.in01() - 0.5f);
+            vec3 viaM = (M * vec4(p, 1.0f)).xyz();
+            vec3 viaN = N * p;
+            vec3 viaT = T * p;
+            ts.push_back(t);
+            push3(ts, p);
+            push3(res, T.translation);
+            res.push_back(T.rotation.x); res.push_back(T.rotation.y); res.push_back(T.rotation.z); res.push_back(T.rotation.w);
+            push3(res, T.scaling);
+            for (int k = 0; k < 16; k++) res.push_back(M.values[k]);
+            for (int k = 0; k < 9; k++) res.push_back(N.values[k]);
+            push3(res, viaM);
+            push3(res, viaN);
+            push3(res, viaT);
+        }
+        floats("anim_keyframes", kf);      /* per key frame: t, translation (3), rotation xyzw (4), scaling (3) */
+        floats("anim_in", ts);             /* per case: t, point (3) */
+        floats("anim_out", res);           /* per case: transformation (10), toMat4 (16, column major), normal matrix (9), M * p, N * p, T * p */
     }
 
     fprintf(out, "\n}\n");

@@ -630,3 +630,62 @@ def test_get_ground_truth_host_api(dev, oracle):
     assert np.array_equal(got.pop("materials"), mapped)
     _assert_ground_truth_equal(got, ref)
     assert np.abs(got["camera_space_offset_to_prev"]).max() > 0.01 and (got["camera_space_offset_to_next"] == 0).all()
+
+
+@pytest.mark.parametrize("variant,t0,t1", [(0, 0.0, 1.0), (1, 0.2, 0.7), (2, 0.0, 1.0), (4, 0.0, 1.0), (0, 0.5, 0.5)])
+def test_motion_blur_and_animated_instances_bit_exact(dev, oracle, variant, t0, t1):
+    """The last part of scope row f4: an exposure interval (every camera ray draws its time, camera.hpp:175-184), a
+    camera that moves along key frames, mesh instances with an animation on top of their transformation (corners,
+    normals and tangents at the ray's time, hitable_triangle.hpp:209-218,296-317) and a moving light whose
+    pdfValue / direction follow it: GPU == oracle, frames and work counters.  t0 == t1 = 0.5: a still from the middle."""
+    sc = host.animated(64, 48, variant, t0, t1)
+    p = host.default_params()
+    p.t0, p.t1 = t0, t1
+    ref, rc = oracle.render(sc, 4, p)
+    ds = dev.DeviceScene(sc)
+    got, gc = ds.render(4, params=p, with_counters=True)
+    assert np.isfinite(got).all() and got.sum() > 0
+    nbad = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
+    assert nbad == 0, "%d of %d values differ, rel-L2 %.3g" % (nbad, got.size, rel_l2(got, ref))
+    assert gc == rc
+    got2, _ = ds.render(4, params=p)  # the product kernel
+    assert bits_equal(got2, ref)
+    if variant != 4:
+        with pytest.raises(RuntimeError):
+            dev.ground_truth(ds)      # not built for moving instances: refused, not wrong
+
+
+def test_exposure_interval_on_a_still_scene(dev, oracle):
+    """t0 != t1 without anything that moves: the time draw alone changes every path, so this runs the same kernel as
+    the animated scenes and has to agree with the restatement; blocks and full frame agree as well."""
+    sc = host.cornell(64, 64, 1, 2)
+    p = host.default_params()
+    p.t0, p.t1 = 0.0, 0.25
+    ref, rc = oracle.render(sc, 4, p)
+    ds = dev.DeviceScene(sc)
+    got, gc = ds.render(4, params=p, with_counters=True)
+    assert bits_equal(got, ref) and gc == rc
+    plain, _ = ds.render(4)
+    assert not bits_equal(plain, ref) and abs(plain.mean() - got.mean()) < 0.05 * plain.mean()
+    part = ds.render_block_host(4, (64 * 10 + 3, 500), params=p)
+    assert bits_equal(part, ref.reshape(-1, 3)[64 * 10 + 3:64 * 10 + 3 + 500])
+
+
+def test_mcpt_host_api(dev, oracle):
+    """The call an application makes: mcpt(sensor, camera, scene, samplesSqrt, t0, t1) of include/wurblpt/wurblpt.hpp
+    (scene flattening, camera description at t0, the camera's key frames joining the scene's, MPICoordinator block
+    loop, wpt_render_block) gives the frames the C ABI gives -- still, textured and animated scenes."""
+    sc = host.cornell(64, 64, 1, 2)
+    ref, _ = oracle.render(sc, 3)
+    assert bits_equal(host.mcpt(sc, 3), ref)
+    sc = host.sponza_like(64, 36, detail=0.05, tex_size=32, env_width=64, importance_n=16)
+    sc.set_envmap_tables(*oracle.envmap_tables(sc))
+    ref, _ = oracle.render(sc, 2)
+    got = host.mcpt(sc, 2)
+    assert bits_equal(got, ref)        # mcpt() has the importance tables built at upload; they equal the oracle's
+    for variant, t0, t1 in ((0, 0.0, 1.0), (2, 0.25, 0.25)):
+        sc = host.animated(64, 48, variant, t0, t1)
+        p = host.default_params()
+        p.t0, p.t1 = t0, t1
+        ref, _ = oracle.render(sc, 3, p)
+        assert bits_equal(host.mcpt(sc, 3, t0, t1), ref), variant

@@ -243,3 +243,37 @@ def test_ground_truth_restatement_is_consistent(oracle):
     # only the arrays that were asked for come back
     some = oracle.ground_truth(sc, bits=(1 << 12) | (1 << 19))
     assert sorted(some) == ["materials", "texcoords"] and np.array_equal(some["materials"], gt["materials"])
+
+
+def test_animated_scene_description_and_motion_blur(oracle):
+    """Scene::take(Animation*), animated mesh instances, Scene::updateBVH(t0, t1) and the exposure interval in the
+    CPU restatement: key frames travel with the scene, moving hitables are bounded for the whole interval, and the
+    frame changes with the interval as it must."""
+    sc = host.animated(48, 32, 0, 0.0, 1.0)
+    d = sc.d
+    assert d.animation_count == 4 and d.keyframe_count == 3 + 2 + 2 + 3 and sc.camera.contents.animation == 3
+    inst_anim = [d.instances[i].animation for i in range(d.instance_count)]
+    assert inst_anim == [-1, -1, -1, -1, 0, 1, 2]
+    flags = np.array([d.tri_geom[i].flags for i in range(d.tri_count)])
+    inst = np.array([d.tri_geom[i].instance for i in range(d.tri_count)])
+    assert ((flags & 8) != 0).tolist() == (inst >= 4).tolist()
+    assert d.hotspot_count == 2 and all(d.hotspots[i].animation == 2 for i in range(2))
+    # every moving triangle stays inside the root box for the whole interval (the walk could not find it otherwise)
+    nodes = sc.nodes_array()
+    lo, hi = nodes[0, 0:3].view(np.float32), nodes[0, 3:6].view(np.float32)
+    p = host.default_params()
+    seen = []
+    for t0, t1 in ((0.0, 1.0), (0.0, 0.0), (1.0, 1.0), (0.4, 0.6)):
+        p.t0, p.t1 = t0, t1
+        frame, cnt = oracle.render(sc, 3, p)
+        assert np.isfinite(frame).all() and frame.sum() > 0
+        seen.append(frame)
+    assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[1], seen[2]) and not np.array_equal(seen[0], seen[3])
+    assert (lo < hi).all()
+    # a still scene under an exposure interval is the same picture up to noise, but not the same numbers: every camera ray draws its time
+    still = host.cornell(32, 32, 1, 2)
+    p.t0, p.t1 = 0.0, 0.0
+    a, _ = oracle.render(still, 6, p)
+    p.t1 = 1.0
+    b, _ = oracle.render(still, 6, p)
+    assert not np.array_equal(a, b) and abs(a.mean() - b.mean()) < 0.05 * a.mean()

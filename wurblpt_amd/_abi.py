@@ -5,7 +5,7 @@ against values compiled from the header.
 """
 import ctypes as C
 
-WPT_ABI_VERSION = 4
+WPT_ABI_VERSION = 5
 WPT_OK = 0
 
 NODE_INNER, NODE_TRIANGLE, NODE_SPHERE, NODE_EMPTY = 0, 1, 2, 3
@@ -28,7 +28,15 @@ class TriAttr(C.Structure):
 
 
 class Instance(C.Structure):
-    _fields_ = [("N", C.c_float * 9), ("material", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("N", C.c_float * 9), ("material", C.c_uint32), ("flags", C.c_uint32), ("animation", C.c_int32)]
+
+
+class Keyframe(C.Structure):
+    _fields_ = [("t", C.c_float), ("translation", C.c_float * 3), ("rotation", C.c_float * 4), ("scaling", C.c_float * 3)]
+
+
+class Animation(C.Structure):
+    _fields_ = [("first_keyframe", C.c_uint32), ("keyframe_count", C.c_uint32)]
 
 
 class Sphere(C.Structure):
@@ -37,7 +45,7 @@ class Sphere(C.Structure):
 
 
 class Hotspot(C.Structure):
-    _fields_ = [("prim", C.c_uint32), ("transform", C.c_uint32), ("kind", C.c_uint32), ("reserved", C.c_uint32),
+    _fields_ = [("prim", C.c_uint32), ("transform", C.c_uint32), ("kind", C.c_uint32), ("animation", C.c_int32),
                 ("p0", C.c_float * 3), ("p1", C.c_float * 3), ("p2", C.c_float * 3), ("M", C.c_float * 16)]
 
 
@@ -78,7 +86,9 @@ class SceneDesc(C.Structure):
                 ("instances", C.POINTER(Instance)), ("materials", C.POINTER(Material)),
                 ("textures", C.POINTER(Texture)), ("texels", C.c_void_p), ("hotspots", C.POINTER(Hotspot)),
                 ("envmap", Envmap), ("spheres", C.POINTER(Sphere)), ("rgl_count", C.c_uint32), ("reserved", C.c_uint32),
-                ("rgl_data_count", C.c_uint64), ("rgl_brdfs", C.POINTER(RglBrdf)), ("rgl_data", C.POINTER(C.c_float))]
+                ("rgl_data_count", C.c_uint64), ("rgl_brdfs", C.POINTER(RglBrdf)), ("rgl_data", C.POINTER(C.c_float)),
+                ("animation_count", C.c_uint32), ("keyframe_count", C.c_uint32), ("animations", C.POINTER(Animation)),
+                ("keyframes", C.POINTER(Keyframe))]
 
 
 class Camera(C.Structure):
@@ -88,14 +98,14 @@ class Camera(C.Structure):
                 ("distortion_type", C.c_uint32), ("k1", C.c_float), ("k2", C.c_float), ("k3", C.c_float), ("p1", C.c_float),
                 ("p2", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("b3", C.c_float), ("b4", C.c_float),
                 ("dist_center", C.c_float * 2), ("dist_focal_length", C.c_float * 2), ("dist_inverse_focal_length", C.c_float * 2),
-                ("surround_mode", C.c_uint32), ("stereoscopic_distance", C.c_float)]
+                ("surround_mode", C.c_uint32), ("stereoscopic_distance", C.c_float), ("animation", C.c_int32)]
 
 
 class Params(C.Structure):
     _fields_ = [("max_path_components", C.c_uint32), ("rr_threshold", C.c_float),
                 ("randomize_ray_over_pixel", C.c_uint32), ("min_hit_distance", C.c_float),
                 ("min_dist_to_light", C.c_float), ("max_dist_to_light", C.c_float),
-                ("min_path_len", C.c_float), ("max_path_len", C.c_float)]
+                ("min_path_len", C.c_float), ("max_path_len", C.c_float), ("t0", C.c_float), ("t1", C.c_float)]
 
 
 class Counters(C.Structure):
@@ -108,6 +118,7 @@ class Counters(C.Structure):
 STRUCT_SIZES = {
     "wpt_bvh_node": (BvhNode, 32), "wpt_tri_geom": (TriGeom, 48), "wpt_tri_attr": (TriAttr, 96),
     "wpt_instance": (Instance, 48), "wpt_sphere": (Sphere, 48), "wpt_hotspot": (Hotspot, 116), "wpt_material": (Material, 128),
-    "wpt_texture": (Texture, 88), "wpt_rgl_warp": (RglWarp, 76), "wpt_rgl_brdf": (RglBrdf, 388), "wpt_camera": (Camera, 136), "wpt_params": (Params, 32),
+    "wpt_texture": (Texture, 88), "wpt_rgl_warp": (RglWarp, 76), "wpt_rgl_brdf": (RglBrdf, 388), "wpt_camera": (Camera, 140), "wpt_params": (Params, 40),
+    "wpt_keyframe": (Keyframe, 44), "wpt_animation": (Animation, 8),
     "wpt_counters": (Counters, 48),
 }

@@ -50,6 +50,7 @@ struct PathState {
     f4 neeFactor; /* attenuation * directSR.attenuation / directPdf * weight (wurblpt.hpp:211,243) */
     f3 srDir;
     uint32_t chosenPrim;
+    float time; /* FEAT_ANIM: the path's time (Ray::time; the thread's AnimationCache is set to it, wurblpt.hpp:361) */
 };
 
 struct FrameArgs {
@@ -76,6 +77,7 @@ WPT_D void pathStateInit(PathState& ps, uint32_t pixel, uint32_t width)
     ps.neeFactor = ps.att;
     ps.srDir = ps.ray.d;
     ps.chosenPrim = NO_HIT;
+    ps.time = 0.0f;
 }
 
 /* HitableTriangle::pdfValue (hitable_triangle.hpp:405-423) for one hot spot */
@@ -132,15 +134,26 @@ WPT_D f3 sphereDirection(const wpt_sphere& sp, f3 org, Prng& prng)
 
 /* mean pdf over all hot spots of hitting them from org along dir (wurblpt.hpp:181-184) */
 template<uint32_t F, bool COUNT, class Tri4>
-WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, LaneCounters& lc)
+WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, float time, LaneCounters& lc)
 {
     const RayAux h = rayAux(dir);
     float sum = 0.0f;
     for (uint32_t i = 0; i < sv.hotspotCount; i++) {
         const uint32_t p = sv.hotspots[i].prim;
-        if ((F & FEAT_SPHERES) && sv.hotspots[i].kind == WPT_HOTSPOT_SPHERE)
+        if ((F & FEAT_SPHERES) && sv.hotspots[i].kind == WPT_HOTSPOT_SPHERE) {
             sum += spherePdfValue(sv.spheres[p], org, dir);
-        else
+        } else if ((F & FEAT_ANIM) && sv.hotspots[i].animation >= 0) {
+            /* the light moves: its corners at the path's time (hitable_triangle.hpp:209-218,405-423) */
+            float4 g0 = tri4(3 * p), g1 = tri4(3 * p + 1), g2 = tri4(3 * p + 2);
+            float animationM[16];
+            wptanim::toMat4(animationAt(sv, sv.hotspots[i].animation, time), animationM);
+            const f3 v0 = animatePoint(animationM, mk3(g0.x, g0.y, g0.z)), v1 = animatePoint(animationM, mk3(g1.x, g1.y, g1.z)),
+                     v2 = animatePoint(animationM, mk3(g2.x, g2.y, g2.z));
+            g0.x = v0.x; g0.y = v0.y; g0.z = v0.z;
+            g1.x = v1.x; g1.y = v1.y; g1.z = v1.z;
+            g2.x = v2.x; g2.y = v2.y; g2.z = v2.z;
+            sum += hotSpotPdfValue(g0, g1, g2, org, dir, h);
+        } else
             sum += hotSpotPdfValue(tri4(3 * p), tri4(3 * p + 1), tri4(3 * p + 2), org, dir, h);
         if (COUNT)
             lc.pdfs++;
@@ -182,7 +195,7 @@ WPT_D int advancePath(const wpt_params& par, PathState& ps)
 
 /* wurblpt.hpp:348-360 + Camera::getRay (camera.hpp:123-185), pinhole or thin lens */
 template<uint32_t F>
-WPT_D int blockNew(const FrameArgs& fa, PathState& ps)
+WPT_D int blockNew(const FrameArgs& fa, PathState& ps, const SceneView* sv = nullptr)
 {
     const uint32_t samples = fa.samplesSqrt * fa.samplesSqrt;
     if (ps.sampleIndex >= samples)
@@ -238,8 +251,24 @@ WPT_D int blockNew(const FrameArgs& fa, PathState& ps)
         D = sub(P, O);
         O = add(O, mk3(stereoscopicShift, 0.0f, 0.0f));
     }
-    ps.ray.o = add(ld3(fa.cam.translation), quatRotate(fa.cam.rotation, mul(O, ld3(fa.cam.scaling))));
-    ps.ray.d = normalize(quatRotate(fa.cam.rotation, D));
+    if ((F & FEAT_ANIM) && fa.par.t0 != fa.par.t1) {
+        /* camera.hpp:175-184: the ray draws its time in the exposure interval; a moving camera is taken at that time */
+        const float t = fa.par.t0 + in01(ps.prng) * (fa.par.t1 - fa.par.t0);
+        ps.time = t;
+        if (fa.cam.animation >= 0 && sv) {
+            const wptanim::Trs T = animationAt(*sv, fa.cam.animation, t);
+            ps.ray.o = add(ld3(T.t), quatRotate(T.q, mul(O, ld3(T.s))));
+            ps.ray.d = normalize(quatRotate(T.q, D));
+        } else {
+            ps.ray.o = add(ld3(fa.cam.translation), quatRotate(fa.cam.rotation, mul(O, ld3(fa.cam.scaling))));
+            ps.ray.d = normalize(quatRotate(fa.cam.rotation, D));
+        }
+    } else {
+        if (F & FEAT_ANIM)
+            ps.time = fa.par.t0;
+        ps.ray.o = add(ld3(fa.cam.translation), quatRotate(fa.cam.rotation, mul(O, ld3(fa.cam.scaling))));
+        ps.ray.d = normalize(quatRotate(fa.cam.rotation, D));
+    }
     ps.ray.ri = mk4(1.0f, 1.0f, 1.0f, 1.0f);
     ps.att = mk4(1.0f, 1.0f, 1.0f, 1.0f);
     ps.opl = mk3(0.0f, 0.0f, 0.0f);
@@ -274,7 +303,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
     };
     if (COUNT)
         tSection = clock64();
-    Hit h = finishHit<F>(sv, best, ps.ray.o, ps.ray.d);
+    Hit h = finishHit<F>(sv, best, ps.ray.o, ps.ray.d, ps.time);
     const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
     if (COUNT)
         lc.scatters++;
@@ -298,7 +327,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
     ps.srDir = sr.dir;
     if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
         /* light sampling with MIS (wurblpt.hpp:179-220) */
-        const float hotSpotsPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, sr.dir, lc);
+        const float hotSpotsPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, sr.dir, ps.time, lc);
         ps.nextAtt = sclr(ps.nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
         section(3);
         uint32_t idx = (uint32_t)(in01(ps.prng) * (float)sv.hotspotCount);
@@ -315,10 +344,15 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
             f3 p = add(add(scl(bary.x, ld3(hs.p0)), scl(bary.y, ld3(hs.p1))), scl(bary.z, ld3(hs.p2)));
             if (hs.transform)
                 p = mat4mulPoint(hs.M, p);
+            if ((F & FEAT_ANIM) && hs.animation >= 0) {
+                float animationM[16];
+                wptanim::toMat4(animationAt(sv, hs.animation, ps.time), animationM);
+                p = animatePoint(animationM, p);
+            }
             directDir = normalize(sub(p, h.p));
         }
         section(4);
-        const float directPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, directDir, lc);
+        const float directPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, directDir, ps.time, lc);
         section(5);
         if (directPdf > 0.0f) {
             float dpdf;

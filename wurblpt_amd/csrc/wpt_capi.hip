@@ -135,6 +135,7 @@ struct wpt_scene {
     SceneView view;
     uint32_t features;
     uint32_t nodeCount, triCount;
+    uint32_t animationCount;
     std::vector<void*> allocations;
     uint32_t* status; /* device word: set by a launch that aborted */
     uint32_t* pixelCounters; /* LDS-state kernel: one "next pixel" word per launch in flight (64 of them) */
@@ -197,6 +198,9 @@ uint32_t sceneFeatures(const wpt_scene_desc* d)
     for (uint32_t i = 0; i < d->material_count; i++)
         if (d->materials[i].type == WPT_MAT_RGL)
             f |= FEAT_RGL;
+    for (uint32_t i = 0; i < d->instance_count; i++)
+        if (d->instances[i].animation >= 0)
+            f |= FEAT_ANIM;
     return f;
 }
 
@@ -302,6 +306,29 @@ wpt_status validate(const wpt_scene_desc* d)
         if (h.prim >= (h.kind == WPT_HOTSPOT_SPHERE ? d->sphere_count : d->tri_count))
             return fail(WPT_ERR_INVALID_ARGUMENT, "hot spot references a primitive outside the array");
     }
+    if (d->animation_count > 0 && (!d->animations || (d->keyframe_count > 0 && !d->keyframes)))
+        return fail(WPT_ERR_INVALID_ARGUMENT, "animation arrays are NULL");
+    for (uint32_t i = 0; i < d->animation_count; i++) {
+        const wpt_animation& a = d->animations[i];
+        if (uint64_t(a.first_keyframe) + a.keyframe_count > d->keyframe_count)
+            return fail(WPT_ERR_INVALID_ARGUMENT, "animation refers to key frames outside the array");
+        for (uint32_t k = 1; k < a.keyframe_count; k++)
+            if (!(d->keyframes[a.first_keyframe + k - 1].t < d->keyframes[a.first_keyframe + k].t))
+                return fail(WPT_ERR_INVALID_ARGUMENT, "key frames must be sorted by ascending time");
+    }
+    for (uint32_t i = 0; i < d->instance_count; i++) {
+        const wpt_instance& inst = d->instances[i];
+        if (inst.animation >= int32_t(d->animation_count) || ((inst.flags & WPT_TRI_ANIMATE) && inst.animation < 0))
+            return fail(WPT_ERR_INVALID_ARGUMENT, "mesh instance refers to an animation outside the array");
+    }
+    for (uint32_t i = 0; i < d->tri_count; i++) {
+        const wpt_tri_geom& g = d->tri_geom[i];
+        if ((g.flags & WPT_TRI_ANIMATE) && (g.instance >= d->instance_count || d->instances[g.instance].animation < 0))
+            return fail(WPT_ERR_INVALID_ARGUMENT, "animated triangle without an animated instance");
+    }
+    for (uint32_t i = 0; i < d->hotspot_count; i++)
+        if (d->hotspots[i].animation >= int32_t(d->animation_count))
+            return fail(WPT_ERR_INVALID_ARGUMENT, "hot spot refers to an animation outside the array");
     if (d->envmap.type > WPT_ENV_CUBE)
         return fail(WPT_ERR_UNSUPPORTED, "environment map type is not known to the kernel");
     if (d->envmap.type == WPT_ENV_EQUIRECT && (d->envmap.tex < 0 || uint32_t(d->envmap.tex) >= d->texture_count))
@@ -475,6 +502,9 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     UP(uploadArray(s, desc->spheres, desc->sphere_count, &s->view.spheres));
     UP(uploadArray(s, desc->rgl_brdfs, desc->rgl_count, &s->view.rglBrdfs));
     UP(uploadArray(s, desc->rgl_data, size_t(desc->rgl_data_count), &s->view.rglData));
+    UP(uploadArray(s, desc->animations, desc->animation_count, &s->view.animations));
+    UP(uploadArray(s, desc->keyframes, desc->keyframe_count, &s->view.keyframes));
+    s->animationCount = desc->animation_count;
     s->view.sphereCount = desc->sphere_count;
     for (int k = 0; k < 6; k++)
         s->view.envCube[k] = desc->envmap.cube_tex[k];
@@ -628,6 +658,14 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
         return fail(WPT_ERR_UNSUPPORTED, "camera surround mode is not known to the kernel");
     if (camera->distortion_type > WPT_DISTORTION_OPENCV)
         return fail(WPT_ERR_UNSUPPORTED, "lens distortion model is not known to the kernel");
+    if (camera->animation >= int32_t(scene->animationCount))
+        return fail(WPT_ERR_INVALID_ARGUMENT, "camera refers to an animation outside the scene's array");
+    /* an exposure interval changes every path (each camera ray draws its time), moving instances need the time too */
+    if (params->t0 != params->t1)
+        need |= FEAT_ANIM;
+    const bool anim = (need & FEAT_ANIM) != 0;
+    if (anim && (need & FEAT_RGL))
+        return fail(WPT_ERR_UNSUPPORTED, "measured BRDFs together with motion blur / animated instances are not instantiated");
     dim3 grid((block_size + WG - 1) / WG);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const bool count = counters_device != nullptr;
@@ -657,7 +695,13 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     args.wfState = nullptr;
     args.wfSlots = 0;
     const bool rgl = (need & FEAT_RGL) != 0; /* measured BRDFs have their own instantiation of the product kernel */
-    if (count) {
+    if (anim) {
+        /* its own instantiation of the product kernel, like the measured BRDFs */
+        if (count)
+            launchFullAnimCount(args, grid, stream);
+        else
+            launchFullAnim(args, grid, stream);
+    } else if (count) {
         if (basic)
             launchBasicCount(args, grid, stream);
         else if (rgl)
@@ -781,6 +825,8 @@ wpt_status wpt_ground_truth_device(wpt_scene* scene, const wpt_camera* camera, c
         return fail(WPT_ERR_UNSUPPORTED, "camera surround mode is not known to the kernel");
     if (camera->distortion_type > WPT_DISTORTION_OPENCV)
         return fail(WPT_ERR_UNSUPPORTED, "lens distortion model is not known to the kernel");
+    if (scene->features & FEAT_ANIM)
+        return fail(WPT_ERR_UNSUPPORTED, "ground truth of scenes with animated instances is not built");
     if ((arrays_device[WPT_GT_PIXEL_SPACE_OFFSET_TO_PREV] || arrays_device[WPT_GT_PIXEL_SPACE_OFFSET_TO_NEXT])
             && (camera->surround_mode != WPT_SURROUND_OFF || camera->stereoscopic_distance > 0.0f))
         return fail(WPT_ERR_UNSUPPORTED, "pixel space offsets exist for Surround_Off, non-stereoscopic cameras only (camera.hpp:207-208)");

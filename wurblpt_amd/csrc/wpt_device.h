@@ -24,6 +24,7 @@
 
 #include "../../include/wurblpt_hip.h"
 #include "wpt_math.h"
+#include "wpt_anim.h"
 #include "wpt_rgl.h"
 
 namespace wptd {
@@ -414,7 +415,8 @@ enum {
     FEAT_GGX = 32,       /* MaterialGGX */
     FEAT_GLASS = 64,     /* MaterialGlass, MaterialMirror */
     FEAT_SPHERES = 128,  /* HitableSphere leaves and sphere hot spots */
-    FEAT_RGL = 256       /* MaterialRGL, measured BRDFs (wpt_rgl.h) */
+    FEAT_RGL = 256,      /* MaterialRGL, measured BRDFs (wpt_rgl.h) */
+    FEAT_ANIM = 512      /* exposure interval t0 != t1 and / or animated instances (wpt_anim.h) */
 };
 
 /* a primitive index with this bit is a sphere (index in the low bits), otherwise a triangle */
@@ -454,7 +456,29 @@ struct SceneView {
     const int32_t* envLut; /* envLutSize + 1 entries: first bin whose cumulative importance reaches k / envLutSize, or NULL */
     uint32_t envLutSize;   /* a power of two */
     uint32_t sphereCount;
+    const wpt_animation* animations; /* key frame animations of instances and camera */
+    const wpt_keyframe* keyframes;
 };
+
+/* ---- animations at a ray's time (wpt_anim.h) ---- */
+struct DeviceAnimMath {
+    static WPT_D float acos(float x) { return wptm::acosf_(x); }
+    static WPT_D float sin(float x) { return wptm::sinf_(x); }
+    static WPT_D float sqrt(float x) { return __builtin_sqrtf(x); }
+};
+/* AnimationCache::get(ai) for a cache at time t (animation.hpp:61-117); recomputed where it is needed */
+WPT_D wptanim::Trs animationAt(const SceneView& sv, int ai, float t)
+{
+    const wpt_animation a = sv.animations[ai];
+    return wptanim::at<DeviceAnimMath>(sv.keyframes + a.first_keyframe, a.keyframe_count, t);
+}
+WPT_D f3 animatePoint(const float* M16, f3 p)
+{
+    const float in[3] = { p.x, p.y, p.z };
+    float out[3];
+    wptanim::mulPoint(M16, in, out);
+    return mk3(out[0], out[1], out[2]);
+}
 
 /* HitableSphere::hit, candidate part (hitable_sphere.hpp:104-147): the nearer root inside
  * (amin, amax), both bounds exclusive, computed without cancellation */
@@ -517,7 +541,7 @@ WPT_D Hit finishSphereHit(const SceneView& sv, const Candidate& c, f3 org, f3 di
 
 /* Rebuilds the HitRecord of the surviving candidate (hitable_triangle.hpp:273-324). */
 template<uint32_t F = 0>
-WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir)
+WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir, float time = 0.0f)
 {
     if ((F & FEAT_SPHERES) && (c.prim & PRIM_SPHERE))
         return finishSphereHit(sv, c, org, dir);
@@ -542,6 +566,13 @@ WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir)
     const float* N = sv.instances[instance].N;
     if (transform)
         nrm = mat3mul(N, nrm);
+    float animationN[9];
+    const bool animate = (F & FEAT_ANIM) && (flags & WPT_TRI_ANIMATE);
+    if (animate) { /* hitable_triangle.hpp:213,296-297 */
+        const wptanim::Trs T = animationAt(sv, sv.instances[instance].animation, time);
+        wptanim::toMat3(T.q, animationN);
+        nrm = mat3mul(animationN, nrm);
+    }
     nrm = normalize(nrm);
     if (backfacing)
         nrm = neg(nrm);
@@ -560,6 +591,8 @@ WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir)
         if (dot(tan, tan) > 0.0f) {
             if (transform)
                 tan = mat3mul(N, tan);
+            if (animate)
+                tan = mat3mul(animationN, tan);
             tan = normalize(sub(tan, scl(dot(nrm, tan), nrm)));
         }
     }

@@ -1,0 +1,12 @@
+/* wpt_k_full_anim.hip -- instantiates wpt_pathtrace<FEAT_ALL | FEAT_ANIM, false, false>: all features plus an exposure
+ * interval (per-ray time, moving camera) and animated mesh instances; 2 waves per SIMD for the wider path state */
+#include "wpt_pathtrace.inc.h"
+
+namespace wptk {
+
+void launchFullAnim(const KernelArgs& args, dim3 grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL | FEAT_ANIM, false, false, 2, false>), grid, dim3(WG), 0, stream, args);
+}
+
+}

@@ -1,0 +1,11 @@
+/* wpt_k_full_anim_count.hip -- instantiates wpt_pathtrace<FEAT_ALL | FEAT_ANIM, true, false> (work counters) */
+#include "wpt_pathtrace.inc.h"
+
+namespace wptk {
+
+void launchFullAnimCount(const KernelArgs& args, dim3 grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL | FEAT_ANIM, true, false, 2, false>), grid, dim3(WG), 0, stream, args);
+}
+
+}

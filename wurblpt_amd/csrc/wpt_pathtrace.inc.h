@@ -261,8 +261,16 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                             accepted = sphereTest(sv.spheres[leafPrim & ~PRIM_SPHERE], ps.ray.o, ps.ray.d, par.min_hit_distance, bound, c.a);
                         } else {
                             const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
-                            accepted = triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), ps.ray.o, aux,
-                                    par.min_hit_distance, bound, c);
+                            f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
+                            if ((F & FEAT_ANIM) && (__float_as_uint(g2.w) & WPT_TRI_ANIMATE)) {
+                                /* the instance moves: its corners at the ray's time (hitable_triangle.hpp:209-218) */
+                                float animationM[16];
+                                wptanim::toMat4(animationAt(sv, sv.instances[__float_as_uint(g0.w)].animation, ps.time), animationM);
+                                v0 = animatePoint(animationM, v0);
+                                v1 = animatePoint(animationM, v1);
+                                v2 = animatePoint(animationM, v2);
+                            }
+                            accepted = triangleTest(v0, v1, v2, ps.ray.o, aux, par.min_hit_distance, bound, c);
                         }
                         if (accepted) {
                             c.prim = leafPrim;
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 sched[10] += __popcll(__ballot(state == S_NEW));
             }
             if (state == S_NEW) /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
-                afterBlock(blockNew<F>(fa, ps));
+                afterBlock(blockNew<F>(fa, ps, &sv));
             if (COUNT) /* shader clock spent per kind of block: [11] traversal [12] shade [13] nee-end [14] new */
                 sched[14] += (unsigned long long)(clock64() - tBlock);
         }
@@ -414,6 +422,8 @@ void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFullCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFullRgl(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFullRglCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
+void launchFullAnim(const KernelArgs& args, dim3 grid, hipStream_t stream);
+void launchFullAnimCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 
 } /* namespace wptk */
 

@@ -133,6 +133,16 @@ def sponza_like(width, height, seed=1, detail=1.0, tex_size=1024, env_width=2048
     return HostScene(h, width, height, "sponza_like(seed=%d,detail=%g)" % (seed, detail))
 
 
+def animated(width, height, variant=0, t0=0.0, t1=1.0):
+    """A room with a turning cube, a swinging panel, a sliding light and a moving camera, bounded for the exposure
+    interval [t0, t1] (pass the same t0, t1 in the render parameters).  variant bit 0: thin lens; bit 1: static
+    camera; bit 2: static instances."""
+    L = lib()
+    L.wpt_host_animated.restype = C.c_void_p
+    L.wpt_host_animated.argtypes = [C.c_int, C.c_float, C.c_float, C.c_uint, C.c_uint]
+    return HostScene(L.wpt_host_animated(variant, t0, t1, width, height), width, height, "animated(variant=%d)" % variant)
+
+
 def courtyard_like(width, height, seed=2, triangles=10_000_000, tex_size=1024):
     """BASELINE config 4 stand-in: seeded San-Miguel-class courtyard dominated by foliage (clouds
     of small two-sided leaf quads), every material two-sided, constant environment without
@@ -217,6 +227,19 @@ def image_load(filename):
     out = np.zeros((info[1], info[0], info[2]), dtype=dtype)
     L.wpt_host_image_load(filename.encode(), info, C.c_void_p(out.ctypes.data), n)
     return out
+
+
+def mcpt(scene, samples_sqrt, t0=0.0, t1=0.0, width=None, height=None):
+    """mcpt() of include/wurblpt/wurblpt.hpp (needs a device): the scene, its camera and a SensorRGB through the C++
+    host API an application uses; returns the frame [h, w, 3]."""
+    w = width or scene.width
+    h = height or scene.height
+    frame = np.zeros((h, w, 3), np.float32)
+    L = lib()
+    L.wpt_host_mcpt.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_float, C.c_float, C.c_void_p]
+    if not L.wpt_host_mcpt(scene._handle, w, h, samples_sqrt, t0, t1, C.c_void_p(frame.ctypes.data)):
+        raise RuntimeError("mcpt failed")
+    return frame
 
 
 def material_scene_index(scene):

@@ -29,6 +29,7 @@ struct wpt_host_scene {
     std::string error;
     float vfov = 0.0f; /* the look-at camera the scene was finished with */
     vec3 from, at;
+    std::shared_ptr<Camera> cameraObject; /* the Camera the wpt_camera record was made from */
 };
 
 namespace {
@@ -203,6 +204,7 @@ wpt_host_scene* finishSceneOf(wpt_host_scene* hs, Scene& scene, unsigned int wid
     Optics optics(Projection(vfovRadians, float(width) / height), LensDistortion(), LensDepthOfField(aperture, focusDist));
     Camera camera(optics, Transformation::fromLookAt(from, at, vec3(0.0f, 1.0f, 0.0f)));
     camera.describe(hs->camera);
+    hs->cameraObject.reset(new Camera(camera));
     hs->vfov = vfovRadians;
     hs->from = from;
     hs->at = at;
@@ -219,6 +221,7 @@ wpt_host_scene* finishScene(wpt_host_scene* hs, unsigned int width, unsigned int
 
 /* used by the other files of this library */
 Scene& wptHostSceneOf(wpt_host_scene* hs) { return *hs->scenePtr; } /* not hs->scene: wptHostFinish replaces the scene */
+const Camera& wptHostCameraObjectOf(const wpt_host_scene* hs) { return *hs->cameraObject; }
 void wptHostCameraOf(const wpt_host_scene* hs, float& vfovRadians, vec3& from, vec3& at)
 {
     vfovRadians = hs->vfov;
@@ -233,6 +236,31 @@ wpt_host_scene* wptHostFinish(Scene* scene, unsigned int width, unsigned int hei
     wpt_host_scene* hs = new wpt_host_scene;
     hs->scenePtr.reset(scene);
     return finishSceneOf(hs, *scene, width, height, vfovRadians, from, at, aperture, focusDist);
+}
+
+/* the same for a scene with animations: BVH over [t0, t1], camera from an animation (owned by the camera) described
+ * at t0, its key frames appended to the scene's pool */
+wpt_host_scene* wptHostFinishAnimated(Scene* scene, unsigned int width, unsigned int height, float vfovRadians,
+        const Animation* cameraAnimation, float t0, float t1, float aperture, float focusDist)
+{
+    wpt_host_scene* hs = new wpt_host_scene;
+    hs->scenePtr.reset(scene);
+    scene->updateBVH(t0, t1);
+    if (!scene->flatten(hs->flat, &hs->error)) {
+        fprintf(stderr, "wpt_host: %s\n", hs->error.c_str());
+        delete hs;
+        return nullptr;
+    }
+    Optics optics(Projection(vfovRadians, float(width) / height), LensDistortion(), LensDepthOfField(aperture, focusDist));
+    Camera camera(optics, cameraAnimation);
+    camera.describe(hs->camera, t0);
+    hs->camera.animation = hs->flat.addAnimation(cameraAnimation);
+    hs->cameraObject.reset(new Camera(camera));
+    hs->desc = hs->flat.desc();
+    hs->vfov = vfovRadians;
+    hs->from = camera.at(t0).lookFrom();
+    hs->at = camera.at(t0).lookAt();
+    return hs;
 }
 
 extern "C" {
@@ -306,9 +334,44 @@ void wpt_host_default_params(wpt_params* p)
     p->max_dist_to_light = std::numeric_limits<float>::max();
     p->min_path_len = 0.0f;
     p->max_path_len = std::numeric_limits<float>::max();
+    p->t0 = 0.0f;
+    p->t1 = 0.0f;
 }
 
 /* ---- building blocks, exposed for parity tests against the reference's golden vectors ---- */
+
+/* AnimationKeyframes of include/wurblpt/animation.hpp from `count` key frames (11 floats each: t, translation,
+ * rotation xyzw, scaling), evaluated for n cases (t, point): per case the transformation (10 floats), toMat4 (16),
+ * toNormalMatrix (9), M * p, N * p, T * p -- the layout of the anim_out golden vector */
+void wpt_host_animation_at(const float* keyframes, unsigned int count, int n, const float* in, float* out)
+{
+    AnimationKeyframes anim;
+    /* added in reverse order: addKeyframe() has to sort them */
+    for (unsigned int k = count; k-- > 0;) {
+        const float* f = keyframes + 11 * k;
+        anim.addKeyframe(f[0], Transformation(vec3(f + 1), quat(f[4], f[5], f[6], f[7]), vec3(f + 8)));
+    }
+    for (int i = 0; i < n; i++) {
+        const Transformation T = anim.at(in[4 * i]);
+        const mat4 M = T.toMat4();
+        const mat3 N = T.toNormalMatrix();
+        const vec3 p(in + 4 * i + 1);
+        const vec3 viaM = (M * vec4(p, 1.0f)).xyz(), viaN = N * p, viaT = T * p;
+        float* o = out + 44 * i;
+        for (int k = 0; k < 3; k++) {
+            o[k] = T.translation[k];
+            o[7 + k] = T.scaling[k];
+            o[35 + k] = viaM[k];
+            o[38 + k] = viaN[k];
+            o[41 + k] = viaT[k];
+        }
+        o[3] = T.rotation.x; o[4] = T.rotation.y; o[5] = T.rotation.z; o[6] = T.rotation.w;
+        for (int k = 0; k < 16; k++)
+            o[10 + k] = M.values[k];
+        for (int k = 0; k < 9; k++)
+            o[26 + k] = N.values[k];
+    }
+}
 
 /* boxes: n x (lo[3], hi[3]); nodes_out must hold 2n-1 nodes; returns the node count */
 unsigned int wpt_host_bvh_build(unsigned int n, const float* boxes, wpt_bvh_node* nodes_out, unsigned int* levels)

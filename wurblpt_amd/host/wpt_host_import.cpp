@@ -23,6 +23,7 @@ wpt_host_scene* wptHostFinish(Scene* scene, unsigned int width, unsigned int hei
 
 Scene& wptHostSceneOf(wpt_host_scene* hs);
 void wptHostCameraOf(const wpt_host_scene* hs, float& vfovRadians, vec3& from, vec3& at);
+const Camera& wptHostCameraObjectOf(const wpt_host_scene* hs);
 
 namespace {
 
@@ -171,6 +172,22 @@ extern "C" int wpt_host_postproc(int op, unsigned int width, unsigned int height
         fprintf(stderr, "wpt_host: %s\n", e.what());
         return 0;
     }
+}
+
+/* mcpt() of include/wurblpt/wurblpt.hpp -- the call an application makes -- for a scene of this library and the
+ * camera it was finished with: renders width x height x samplesSqrt^2 over the exposure interval [t0, t1] on the
+ * device(s) and copies the sensor's frame (row 0 = bottom) to `frame`.  devices: how many GPUs the MPICoordinator
+ * may use (0 = all).  1 on success; failures inside mcpt() abort like the reference's asserts. */
+extern "C" int wpt_host_mcpt(wpt_host_scene* hs, unsigned int width, unsigned int height, unsigned int samplesSqrt, float t0, float t1,
+        float* frame)
+{
+    Scene& scene = wptHostSceneOf(hs);
+    if (scene.bvhNeedsUpdate(t0, t1))
+        scene.updateBVH(t0, t1);
+    SensorRGB sensor(width, height);
+    mcpt(sensor, wptHostCameraObjectOf(hs), scene, samplesSqrt, t0, t1);
+    memcpy(frame, sensor.result().data(), size_t(width) * height * 3 * sizeof(float));
+    return 1;
 }
 
 /* getGroundTruth() of include/wurblpt/wurblpt.hpp for a scene of this library with its look-at camera;

@@ -446,6 +446,67 @@ extern "C" wpt_host_scene* wpt_host_furnace(int material, int slices, unsigned i
     return wptHostFinish(scenePtr, width, height, radians(40.0f), vec3(0.0f, 0.0f, 5.0f), vec3(0.0f, 0.0f, 0.0f), 0.0f, 1.0f);
 }
 
+wpt_host_scene* wptHostFinishAnimated(Scene* scene, unsigned int width, unsigned int height, float vfovRadians,
+        const Animation* cameraAnimation, float t0, float t1, float aperture, float focusDist);
+
+/* A room with moving things for the exposure interval [t0, t1] (animation.hpp, animation_keyframes.hpp, the way
+ * wurblpt-animations.cpp sets such scenes up): floor, back wall and a side wall; a GGX cube that turns and drifts
+ * (three key frames, scaled), a textured two-sided panel that swings about the z axis, a quad light that slides and
+ * tilts (a hot spot, so its pdfValue / direction move too), a static glass block; the camera dollies sideways and
+ * pans.  variant bit 0: thin lens as well; bit 1: the camera stands still (only the instances move);
+ * bit 2: nothing but the camera moves. */
+extern "C" wpt_host_scene* wpt_host_animated(int variant, float t0, float t1, unsigned int width, unsigned int height)
+{
+    Scene* scenePtr = new Scene;
+    Scene& scene = *scenePtr;
+    const bool moveInstances = !(variant & 4);
+    Material* white = scene.take(new MaterialLambertian(vec3(0.73f, 0.72f, 0.69f)));
+    Material* blue = scene.take(new MaterialLambertian(vec3(0.15f, 0.25f, 0.6f)));
+    Material* metal = scene.take(new MaterialGGX(vec3(0.95f, 0.8f, 0.5f), vec2(0.15f)));
+    Material* glass = scene.take(new MaterialGlass(vec3(0.1f), 1.5f));
+    Texture* checker = scene.take(new TextureChecker(vec3(0.85f, 0.3f, 0.2f), vec3(0.9f, 0.9f, 0.85f), 6, 6));
+    Material* panel = scene.take(new MaterialTwoSided(scene.take(new MaterialLambertian(vec3(0.7f), checker)), blue));
+    Material* light = scene.take(new LightDiffuse(vec3(9.0f)));
+
+    AnimationKeyframes* cubeMotion = new AnimationKeyframes;
+    cubeMotion->addKeyframe(0.0f, Transformation(vec3(-0.6f, 0.35f, -0.2f), toQuat(radians(10.0f), vec3(0.0f, 1.0f, 0.0f)), vec3(0.35f)));
+    cubeMotion->addKeyframe(0.5f, Transformation(vec3(-0.45f, 0.4f, -0.1f), toQuat(radians(55.0f), vec3(0.2f, 1.0f, 0.0f)), vec3(0.38f)));
+    cubeMotion->addKeyframe(1.0f, Transformation(vec3(-0.2f, 0.5f, 0.1f), toQuat(radians(130.0f), vec3(0.3f, 1.0f, 0.1f)), vec3(0.3f, 0.4f, 0.3f)));
+    AnimationKeyframes* panelMotion = new AnimationKeyframes(0.0f, Transformation(vec3(0.7f, 0.8f, -0.6f), toQuat(radians(-25.0f), vec3(0.0f, 0.0f, 1.0f)), vec3(0.4f)),
+            1.0f, Transformation(vec3(0.7f, 0.8f, -0.6f), toQuat(radians(35.0f), vec3(0.0f, 0.0f, 1.0f)), vec3(0.4f)));
+    AnimationKeyframes* lightMotion = new AnimationKeyframes(0.0f, Transformation(vec3(-0.3f, 1.9f, -0.2f), toQuat(radians(90.0f), vec3(1.0f, 0.0f, 0.0f)), vec3(0.3f)),
+            1.0f, Transformation(vec3(0.3f, 1.85f, 0.1f), toQuat(radians(70.0f), vec3(1.0f, 0.1f, 0.0f)), vec3(0.3f)));
+    const int cubeAnim = scene.take(cubeMotion);
+    const int panelAnim = scene.take(panelMotion);
+    const int lightAnim = scene.take(lightMotion);
+
+    /* static room */
+    scene.take(new MeshInstance(scene.take(generateQuad()), white,
+                Transformation(vec3(0.0f, 0.0f, 0.0f), toQuat(radians(-90.0f), vec3(1.0f, 0.0f, 0.0f)), vec3(2.0f))));
+    scene.take(new MeshInstance(scene.take(generateQuad()), white, Transformation(vec3(0.0f, 1.0f, -1.5f), quat::null(), vec3(2.0f, 1.0f, 1.0f))));
+    scene.take(new MeshInstance(scene.take(generateQuad()), blue,
+                Transformation(vec3(-1.5f, 1.0f, 0.0f), toQuat(radians(90.0f), vec3(0.0f, 1.0f, 0.0f)), vec3(2.0f, 1.0f, 1.0f))));
+    scene.take(new MeshInstance(scene.take(generateCube()), glass, Transformation(vec3(0.5f, 0.3f, 0.4f), toQuat(radians(20.0f), vec3(0.0f, 1.0f, 0.0f)), vec3(0.25f, 0.3f, 0.25f))));
+    /* moving things: an instance transformation and an animation on top of it, an animation alone, a moving light */
+    if (moveInstances) {
+        scene.take(new MeshInstance(scene.take(generateCube(Transformation(), 2)), metal, Transformation(vec3(0.0f), toQuat(radians(15.0f), vec3(0.0f, 0.0f, 1.0f)), vec3(1.0f, 0.8f, 1.0f)), cubeAnim));
+        scene.take(new MeshInstance(scene.take(generateQuad(Transformation(), 3)), panel, panelAnim));
+        scene.take(new MeshInstance(scene.take(generateQuad()), light, lightAnim), HotSpot);
+    } else {
+        scene.take(new MeshInstance(scene.take(generateCube(Transformation(), 2)), metal, cubeMotion->at(0.3f)));
+        scene.take(new MeshInstance(scene.take(generateQuad(Transformation(), 3)), panel, panelMotion->at(0.3f)));
+        scene.take(new MeshInstance(scene.take(generateQuad()), light, lightMotion->at(0.3f)), HotSpot);
+    }
+    AnimationKeyframes* cameraMotion = new AnimationKeyframes;
+    const vec3 up(0.0f, 1.0f, 0.0f);
+    cameraMotion->addKeyframe(0.0f, Transformation::fromLookAt(vec3(0.1f, 0.9f, 3.0f), vec3(0.0f, 0.7f, 0.0f), up));
+    if (!(variant & 2)) {
+        cameraMotion->addKeyframe(0.6f, Transformation::fromLookAt(vec3(0.25f, 0.95f, 2.9f), vec3(0.05f, 0.7f, 0.0f), up));
+        cameraMotion->addKeyframe(1.0f, Transformation::fromLookAt(vec3(0.45f, 1.0f, 2.7f), vec3(0.1f, 0.75f, 0.0f), up));
+    }
+    return wptHostFinishAnimated(scenePtr, width, height, radians(45.0f), cameraMotion, t0, t1, (variant & 1) ? 0.05f : 0.0f, 3.0f);
+}
+
 /* Scenes with analytic spheres (hitable_sphere.hpp), the "next" row f2 of the scope table:
  * variant 0  ground + Lambertian (checker texture, rotated frame) / GGX / glass / mirror spheres,
  *            lit by a spherical light AND a quad light, both hot spots (mixed sphere and triangle
