@@ -276,8 +276,8 @@ public:
     /* scene.hpp:127-149 for a component that creates one HitableSphere (sphere.hpp:60-63) */
     std::vector<const Hitable*> take(Sphere* sphere, HotSpotType hotSpotType = ColdSpot)
     {
-        if (sphere->animationIndex >= 0)
-            _error = "animated spheres are outside the device path";
+        if (sphere->animationIndex >= int(_animations.size()))
+            _error = "a sphere refers to an animation the scene does not have";
         Hitable* h = new Hitable { (unsigned int)(_hitables.size()) };
         _handles.push_back(std::unique_ptr<Hitable>(h));
         _hitables.push_back(HitableRef { WPT_NODE_SPHERE, (unsigned int)(_spheres.size()) });
@@ -323,7 +323,17 @@ public:
             } else {
                 /* HitableSphere::aabb (hitable_sphere.hpp:88-91) */
                 const Sphere* sp = _spheres[_hitables[i].index];
-                boxes[i] = AABB(sp->center() - vec3(sp->radius()), sp->center() + vec3(sp->radius()));
+                if (sp->animationIndex < 0) {
+                    boxes[i] = AABB(sp->center() - vec3(sp->radius()), sp->center() + vec3(sp->radius()));
+                } else { /* :98-106 */
+                    const Transformation& T0 = animationCacheT0.get(sp->animationIndex);
+                    const Transformation& T1 = animationCacheT1.get(sp->animationIndex);
+                    vec3 c0 = T0 * sp->center();
+                    vec3 c1 = T1 * sp->center();
+                    float r0 = max(T0.scaling) * sp->radius();
+                    float r1 = max(T1.scaling) * sp->radius();
+                    boxes[i] = merge(AABB(c0 - vec3(r0), c0 + vec3(r0)), AABB(c1 - vec3(r1), c1 + vec3(r1)));
+                }
             }
         }
         BVHBuilder builder(boxes);
@@ -439,6 +449,7 @@ public:
             if (m < 0)
                 return fail(ctx.error);
             r.material = m;
+            r.animation = sp->animationIndex >= 0 ? sp->animationIndex : -1;
         }
         out.hotspots.resize(_hotSpots.size());
         for (size_t i = 0; i < _hotSpots.size(); i++) {

@@ -234,15 +234,18 @@ public:
     }
 };
 
-/* The device path holds static scenes, so the only motion the flow arrays can show is the camera's:
- * cameraPrev / cameraNext are the camera at tPrev / tNext (NULL = it does not move). */
+/* The picture is taken at t0; the flow arrays compare with tPrev and tNext: the camera at those times (its animation,
+ * or cameraPrev / cameraNext where an application keeps separate camera objects per frame) and the places the hit
+ * points of animated instances have then (wurblpt.hpp:626-761). */
 inline GroundTruth getGroundTruth(const Sensor& sensor, const Camera& camera, const Camera* cameraPrev, const Camera* cameraNext,
-        const Scene& scene, unsigned int groundTruthBits = GroundTruth::All, const Parameters& params = Parameters())
+        const Scene& scene, float t0, float tPrev, float tNext, unsigned int groundTruthBits = GroundTruth::All,
+        const Parameters& params = Parameters())
 {
-    if (scene.bvhNeedsUpdate(0.0f, 0.0f))
+    if (scene.bvhNeedsUpdate(t0, t0))
         mcptFatal("Scene::updateBVH() must run before getGroundTruth()");
     wpt_camera cam, camPrev, camNext;
-    if (!camera.describe(cam) || (cameraPrev && !cameraPrev->describe(camPrev)) || (cameraNext && !cameraNext->describe(camNext)))
+    if (!camera.describe(cam, t0) || !(cameraPrev ? cameraPrev->describe(camPrev, tPrev) : camera.describe(camPrev, tPrev))
+            || !(cameraNext ? cameraNext->describe(camNext, tNext) : camera.describe(camNext, tNext)))
         mcptFatal("this camera cannot be described to the device path");
     FlatScene flat;
     std::string error;
@@ -258,12 +261,12 @@ inline GroundTruth getGroundTruth(const Sensor& sensor, const Camera& camera, co
     p.max_dist_to_light = std::numeric_limits<float>::max();
     p.min_path_len = 0.0f;
     p.max_path_len = std::numeric_limits<float>::max();
-    p.t0 = 0.0f;
-    p.t1 = 0.0f;
+    p.t0 = t0;
+    p.t1 = t0;
     const unsigned int width = sensor.width();
     const unsigned int height = sensor.height();
     GroundTruth gt(width, height, groundTruthBits);
-    fprintf(stderr, "Getting ground truth for %ux%u pixels... ", width, height);
+    fprintf(stderr, "Getting ground truth for %ux%u pixels at %.3fs... ", width, height, t0);
     if (wpt_device_count() <= 0)
         mcptFatal(std::string("no HIP device: ") + wpt_last_error());
     wpt_scene* dscene = nullptr;
@@ -271,8 +274,8 @@ inline GroundTruth getGroundTruth(const Sensor& sensor, const Camera& camera, co
         mcptFatal(wpt_last_error());
     void* arrays[WPT_GT_ARRAY_COUNT];
     gt.arrayPointers(arrays);
-    const wpt_status st = wpt_ground_truth(dscene, &cam, cameraPrev ? &camPrev : nullptr, cameraNext ? &camNext : nullptr, &p, width,
-            height, arrays);
+    const float times[3] = { t0, tPrev, tNext };
+    const wpt_status st = wpt_ground_truth(dscene, &cam, &camPrev, &camNext, times, &p, width, height, arrays);
     wpt_scene_free(dscene);
     if (st != WPT_OK)
         mcptFatal(wpt_last_error());
@@ -287,11 +290,10 @@ inline GroundTruth getGroundTruth(const Sensor& sensor, const Camera& camera, co
     return gt;
 }
 
-inline GroundTruth getGroundTruth(const Sensor& sensor, const Camera& camera, const Scene& scene, float t0, float /* tPrev */,
-        float /* tNext */, unsigned int groundTruthBits = GroundTruth::All, const Parameters& params = Parameters())
+inline GroundTruth getGroundTruth(const Sensor& sensor, const Camera& camera, const Scene& scene, float t0, float tPrev,
+        float tNext, unsigned int groundTruthBits = GroundTruth::All, const Parameters& params = Parameters())
 {
-    (void)t0; /* Camera::at(t) is the same for every t here */
-    return getGroundTruth(sensor, camera, nullptr, nullptr, scene, groundTruthBits, params);
+    return getGroundTruth(sensor, camera, nullptr, nullptr, scene, t0, tPrev, tNext, groundTruthBits, params);
 }
 
 inline GroundTruth getGroundTruth(const Sensor& sensor, const Camera& camera, const Scene& scene, float t0 = 0.0f,

@@ -115,7 +115,8 @@ typedef struct wpt_sphere {
     float radius;
     float rotation[4]; /* quaternion x, y, z, w */
     uint32_t material;
-    uint32_t reserved[3];
+    int32_t animation; /* HitableSphere::_animationIndex: index into wpt_scene_desc::animations, -1 = none */
+    uint32_t reserved[2];
 } wpt_sphere;
 
 /* A hot spot (scene.hpp:113-125).  WPT_HOTSPOT_TRIANGLE: `prim` is the triangle, plus what
@@ -363,7 +364,7 @@ enum {
     WPT_GT_CAMERA_SPACE_DEPTHS = 10,           /* 1: -z of the camera space position */
     WPT_GT_CAMERA_SPACE_DISTANCES = 11,        /* 1: its length */
     WPT_GT_TEXCOORDS = 12,                     /* 2 */
-    WPT_GT_WORLD_SPACE_OFFSET_TO_PREV = 13,    /* 3: zero, the device path holds static scenes */
+    WPT_GT_WORLD_SPACE_OFFSET_TO_PREV = 13,    /* 3: where the hit point of an animated instance is at tPrev / tNext, minus where it is */
     WPT_GT_WORLD_SPACE_OFFSET_TO_NEXT = 14,    /* 3 */
     WPT_GT_CAMERA_SPACE_OFFSET_TO_PREV = 15,   /* 3: from the camera at tPrev / tNext */
     WPT_GT_CAMERA_SPACE_OFFSET_TO_NEXT = 16,   /* 3 */
@@ -377,13 +378,14 @@ static const uint32_t wpt_gt_components[WPT_GT_ARRAY_COUNT] = { 3, 3, 3, 3, 3, 3
 
 /* arrays_device[k]: device array of width * height * wpt_gt_components[k] elements (row 0 = bottom), or
  * NULL for an array that is not wanted.  camera_prev / camera_next: the camera at tPrev / tNext (only the
- * transformation is read); NULL = the camera itself.  Asynchronous on `hip_stream`. */
+ * transformation is read); NULL = the camera itself.  times: t0, tPrev, tNext for the scene's animated
+ * instances (NULL = all zero); the picture is taken at t0.  Asynchronous on `hip_stream`. */
 wpt_status wpt_ground_truth_device(wpt_scene* scene, const wpt_camera* camera, const wpt_camera* camera_prev,
-        const wpt_camera* camera_next, const wpt_params* params, uint32_t width, uint32_t height,
+        const wpt_camera* camera_next, const float times[3], const wpt_params* params, uint32_t width, uint32_t height,
         void* const arrays_device[WPT_GT_ARRAY_COUNT], void* hip_stream);
 /* The same into host arrays (synchronous). */
 wpt_status wpt_ground_truth(wpt_scene* scene, const wpt_camera* camera, const wpt_camera* camera_prev,
-        const wpt_camera* camera_next, const wpt_params* params, uint32_t width, uint32_t height,
+        const wpt_camera* camera_next, const float times[3], const wpt_params* params, uint32_t width, uint32_t height,
         void* const arrays_host[WPT_GT_ARRAY_COUNT]);
 
 /* ---- output side (postproc.hpp:44-108): per-pixel operations on a rendered frame ----

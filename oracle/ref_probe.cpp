@@ -753,6 +753,86 @@ int main(int argc, char* argv[])
             seeds.push_back(1000 + i);
             push3(dirs, sphere.direction(origin, cache, prng));
         }
+        /* the same with an animation on every sphere (hitable_sphere.hpp:118-127,161-166,196-203): hit() and direction()
+         * add the animation's translation to the centre, pdfValue() applies the whole transformation to it */
+        {
+            std::vector<float> aSpheres, aKeys, aRays, aHits, aPdfs, aDirs;
+            std::vector<long long> aSeeds;
+            const float time = 0.37f;
+            std::mt19937 arng(777); /* its own generator: the vectors after this block keep their values */
+            auto su01 = [&arng]() { return float(arng() >> 8) * (1.0f / 16777216.0f); };
+            auto sdir = [&]() {
+                for (;;) {
+                    vec3 d(su01() * 2.0f - 1.0f, su01() * 2.0f - 1.0f, su01() * 2.0f - 1.0f);
+                    float l = dot(d, d);
+                    if (l > 1e-4f && l <= 1.0f)
+                        return normalize(d);
+                }
+            };
+            for (int i = 0; i < 768; i++) {
+                vec3 center = (i % 2 == 0) ? vec3(0.0f) : vec3(su01() - 0.5f, su01() - 0.5f, su01() - 0.5f);
+                float radius = (i % 2 == 0) ? 1.0f : 0.2f + su01();
+                quat rot = (i % 2 == 0) ? quat::null() : toQuat(radians(360.0f * su01()), sdir());
+                AnimationKeyframes* anim = new AnimationKeyframes(0.0f,
+                        Transformation(vec3(su01() * 2.0f - 1.0f, su01() * 2.0f - 1.0f, su01() * 2.0f - 1.0f), toQuat(radians(360.0f * su01()), sdir()),
+                            vec3(0.3f + su01(), 0.3f + su01(), 0.3f + su01())),
+                        1.0f,
+                        Transformation(vec3(su01() * 2.0f - 1.0f, su01() * 2.0f - 1.0f, su01() * 2.0f - 1.0f), toQuat(radians(360.0f * su01()), sdir()),
+                            vec3(0.3f + su01(), 0.3f + su01(), 0.3f + su01())));
+                std::vector<const Animation*> animations(1, anim);
+                AnimationCache acache(animations, time);
+                HitableSphere sphere(Transformation(center, rot, vec3(radius)), nullptr, 0);
+                const Transformation T = anim->at(time);
+                const vec3 movedCenter = center + T.translation;
+                const float movedRadius = radius * max(T.scaling);
+                vec3 origin;
+                switch (i % 6) {
+                case 0: origin = movedCenter + (movedRadius * 0.5f) * sdir(); break;
+                case 1: origin = T * center + (movedRadius * 0.3f) * sdir(); break;      /* inside as pdfValue() sees it */
+                default: origin = movedCenter + (movedRadius * (1.5f + 5.0f * su01())) * sdir(); break;
+                }
+                vec3 direction = (i % 4 == 3) ? sdir() : normalize(movedCenter + (movedRadius * 1.05f * su01()) * sdir() - origin + vec3(1e-6f));
+                float amin = 1e-5f, amax = maxval;
+                Ray ray(origin, direction, time, 1.0f);
+                Prng unused(0);
+                HitRecord hr = sphere.hit(ray, RayIntersectionHelper(ray), amin, amax, 0.0f, acache, unused);
+                push3(aSpheres, center);
+                aSpheres.push_back(radius);
+                aSpheres.push_back(rot.x); aSpheres.push_back(rot.y); aSpheres.push_back(rot.z); aSpheres.push_back(rot.w);
+                aSpheres.push_back(radius); aSpheres.push_back(radius); aSpheres.push_back(radius);
+                for (const AnimationKeyframes::Keyframe& k : anim->keyframes()) {
+                    aKeys.push_back(k.t);
+                    push3(aKeys, k.transformation.translation);
+                    aKeys.push_back(k.transformation.rotation.x); aKeys.push_back(k.transformation.rotation.y);
+                    aKeys.push_back(k.transformation.rotation.z); aKeys.push_back(k.transformation.rotation.w);
+                    push3(aKeys, k.transformation.scaling);
+                }
+                push3(aRays, origin);
+                push3(aRays, direction);
+                aRays.push_back(amin);
+                aRays.push_back(amax);
+                aHits.push_back(hr.haveHit ? 1.0f : 0.0f);
+                aHits.push_back(hr.haveHit ? hr.a : 0.0f);
+                push3(aHits, hr.haveHit ? hr.position : vec3(0.0f));
+                push3(aHits, hr.haveHit ? hr.normal : vec3(0.0f));
+                push3(aHits, hr.haveHit ? hr.tangent : vec3(0.0f));
+                aHits.push_back(hr.haveHit ? hr.texcoords.x() : 0.0f);
+                aHits.push_back(hr.haveHit ? hr.texcoords.y() : 0.0f);
+                aHits.push_back(hr.haveHit && hr.backside ? 1.0f : 0.0f);
+                aPdfs.push_back(sphere.pdfValue(origin, direction, acache, unused));
+                Prng prng(5000 + i);
+                aSeeds.push_back(5000 + i);
+                push3(aDirs, sphere.direction(origin, acache, prng));
+                delete anim;
+            }
+            floats("sphere_anim_records", aSpheres);    /* as sphere_records */
+            floats("sphere_anim_keyframes", aKeys);     /* two key frames per sphere, 11 floats each; evaluated at t = 0.37 */
+            floats("sphere_anim_rays", aRays);
+            floats("sphere_anim_hits", aHits);
+            floats("sphere_anim_pdf", aPdfs);
+            ints("sphere_anim_direction_seeds", aSeeds);
+            floats("sphere_anim_direction", aDirs);
+        }
         floats("sphere_records", spheres); /* centre(3) radius rotation(xyzw) scaling(3) */
         floats("sphere_rays", rays);       /* origin(3) direction(3) amin amax */
         floats("sphere_hits", hits);       /* haveHit a position(3) normal(3) tangent(3) texcoords(2) backside */

@@ -612,11 +612,31 @@ inline HitRecord sphereHitRecord(const Ray& ray, float a, V3 center, const float
     return hr;
 }
 
-/* hitable_sphere.hpp:104-147 (static scene: no animation) */
-inline HitRecord sphereHit(const wpt_sphere& sp, uint32_t index, const Ray& ray, float amin, float amax)
+inline float max3(const float* s) /* gvm.hpp:1284-1291 */
+{
+    float r = s[0];
+    for (int i = 1; i < 3; i++)
+        if (s[i] > r)
+            r = s[i];
+    return r;
+}
+
+/* hitable_sphere.hpp:104-147; `c` gives the animations and the time of the path (the AnimationCache) */
+inline HitRecord sphereHit(const Ctx& c, const wpt_sphere& sp, uint32_t index, const Ray& ray, float amin, float amax)
 {
     V3 center = v3(sp.center);
     float radius = sp.radius;
+    float rot[4] = { sp.rotation[0], sp.rotation[1], sp.rotation[2], sp.rotation[3] };
+    if (sp.animation >= 0) {
+        const wptanim::Trs T = animationAt(c, sp.animation, c.time);
+        center = center + v3(T.t);
+        radius *= max3(T.s);
+        const float x = sp.rotation[0], y = sp.rotation[1], z = sp.rotation[2], w = sp.rotation[3];
+        rot[0] = w * T.q[0] + x * T.q[3] + y * T.q[2] - z * T.q[1];
+        rot[1] = w * T.q[1] + y * T.q[3] + z * T.q[0] - x * T.q[2];
+        rot[2] = w * T.q[2] + z * T.q[3] + x * T.q[1] - y * T.q[0];
+        rot[3] = w * T.q[3] - x * T.q[0] - y * T.q[1] - z * T.q[2];
+    }
     V3 oc = ray.origin - center;
     float aq = -dot(oc, ray.direction);
     V3 tmp = oc - dot(oc, ray.direction) * ray.direction;
@@ -632,9 +652,9 @@ inline HitRecord sphereHit(const wpt_sphere& sp, uint32_t index, const Ray& ray,
             a2 = 2.0f * aq - a1;
         }
         if (a2 > amin && a2 < amax)
-            hr = sphereHitRecord(ray, a2, center, sp.rotation, PRIM_SPHERE | index);
+            hr = sphereHitRecord(ray, a2, center, rot, PRIM_SPHERE | index);
         else if (a1 > amin && a1 < amax)
-            hr = sphereHitRecord(ray, a1, center, sp.rotation, PRIM_SPHERE | index);
+            hr = sphereHitRecord(ray, a1, center, rot, PRIM_SPHERE | index);
     }
     return hr;
 }
@@ -646,6 +666,13 @@ inline float spherePdfValue(Ctx& c, uint32_t index, V3 origin, V3 direction)
     const wpt_sphere& sp = c.sc->spheres[index];
     V3 center = v3(sp.center);
     float radius = sp.radius;
+    if (sp.animation >= 0) { /* :161-166: the whole transformation, unlike hit() and direction() */
+        const wptanim::Trs T = animationAt(c, sp.animation, c.time);
+        float moved[3];
+        wptanim::applyTrs(T, sp.center, moved);
+        center = v3(moved);
+        radius *= max3(T.s);
+    }
     float value = 0.0f;
     V3 cmo = center - origin;
     float distanceSquared = dot(cmo, cmo);
@@ -653,7 +680,7 @@ inline float spherePdfValue(Ctx& c, uint32_t index, V3 origin, V3 direction)
     if (distanceSquared <= radiusSquared) {
         value = 0.25f * k_inv_pi;
     } else {
-        HitRecord hr = sphereHit(sp, index, Ray { origin, direction, 0.0f, v4(0.0f) }, 0.0f, k_maxval);
+        HitRecord hr = sphereHit(c, sp, index, Ray { origin, direction, c.time, v4(0.0f) }, 0.0f, k_maxval);
         if (hr.haveHit) {
             float discriminant = 1.0f - radiusSquared / distanceSquared;
             float cosThetaMax = (discriminant > 0.0f ? std::sqrt(discriminant) : 0.0f);
@@ -670,6 +697,11 @@ inline V3 sphereDirection(const Ctx& c, uint32_t index, V3 origin, Prng& prng)
     const wpt_sphere& sp = c.sc->spheres[index];
     V3 center = v3(sp.center);
     float radius = sp.radius;
+    if (sp.animation >= 0) { /* :196-203 */
+        const wptanim::Trs T = animationAt(c, sp.animation, c.time);
+        center = center + v3(T.t);
+        radius *= max3(T.s);
+    }
     V3 dir;
     V3 cmo = center - origin;
     float distanceSquared = dot(cmo, cmo);
@@ -749,7 +781,7 @@ inline HitRecord bvhHit(Ctx& c, const Ray& ray, const RayHelper& rh, float amin,
 {
     return bvhTraverse(c.sc->nodes, c.cnt, ray, rh, amin, amax, [&](uint32_t kind, uint32_t index, float lo, float hi) {
         if (kind == WPT_NODE_SPHERE)
-            return sphereHit(c.sc->spheres[index], index, ray, lo, hi);
+            return sphereHit(c, c.sc->spheres[index], index, ray, lo, hi);
         return triangleHit(c, index, ray, rh, lo, hi, true, nullptr, nullptr);
     });
 }
@@ -1765,7 +1797,8 @@ void wpt_oracle_to_sphere(int n, const float* in4, const float* u_xy, float* out
  * constructor computes it); rays = origin(3) direction(3) amin amax.
  * hits: haveHit a position(3) normal(3) tangent(3) texcoords(2) backside (14 floats);
  * pdf: pdfValue(origin, direction); dirs: direction(origin) with Prng(seed). */
-void wpt_oracle_sphere(int n, const float* records, const float* rays, const int64_t* seeds, float* hits, float* pdf, float* dirs)
+static void sphereProbe(int n, const float* records, const wpt_keyframe* keyframes, float time, const float* rays, const int64_t* seeds,
+        float* hits, float* pdf, float* dirs)
 {
     for (int i = 0; i < n; i++) {
         const float* rec = records + 11 * i;
@@ -1776,18 +1809,27 @@ void wpt_oracle_sphere(int n, const float* records, const float* rays, const int
         sp.radius = fmax_(fmax_(rec[8], rec[9]), rec[10]) == rec[3] ? rec[3] : fmax_(fmax_(rec[8], rec[9]), rec[10]);
         for (int k = 0; k < 4; k++)
             sp.rotation[k] = rec[4 + k];
+        sp.animation = keyframes ? 0 : -1;
         wpt_scene_desc sc;
         memset(&sc, 0, sizeof(sc));
         sc.spheres = &sp;
         sc.sphere_count = 1;
+        wpt_animation anim = { 0, 2 };
+        if (keyframes) { /* two key frames per sphere */
+            sc.animations = &anim;
+            sc.animation_count = 1;
+            sc.keyframes = keyframes + 2 * i;
+            sc.keyframe_count = 2;
+        }
         wpt_params pr;
         memset(&pr, 0, sizeof(pr));
         Ctx c;
         c.sc = &sc;
         c.pr = &pr;
+        c.time = time;
         memset(&c.cnt, 0, sizeof(c.cnt));
-        Ray r { v3(rays + 8 * i), v3(rays + 8 * i + 3), 0.0f, v4(1.0f) };
-        HitRecord hr = sphereHit(sp, 0, r, rays[8 * i + 6], rays[8 * i + 7]);
+        Ray r { v3(rays + 8 * i), v3(rays + 8 * i + 3), time, v4(1.0f) };
+        HitRecord hr = sphereHit(c, sp, 0, r, rays[8 * i + 6], rays[8 * i + 7]);
         float* o = hits + 14 * i;
         memset(o, 0, 14 * sizeof(float));
         if (hr.haveHit) {
@@ -1804,6 +1846,18 @@ void wpt_oracle_sphere(int n, const float* records, const float* rays, const int
         V3 d = sphereDirection(c, 0, r.origin, prng);
         dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
     }
+}
+
+void wpt_oracle_sphere(int n, const float* records, const float* rays, const int64_t* seeds, float* hits, float* pdf, float* dirs)
+{
+    sphereProbe(n, records, nullptr, 0.0f, rays, seeds, hits, pdf, dirs);
+}
+
+/* the same for spheres that carry an animation of two key frames each (44 bytes per key frame), seen at `time` */
+void wpt_oracle_sphere_animated(int n, const float* records, const wpt_keyframe* keyframes, float time, const float* rays,
+        const int64_t* seeds, float* hits, float* pdf, float* dirs)
+{
+    sphereProbe(n, records, keyframes, time, rays, seeds, hits, pdf, dirs);
 }
 
 /* powitacq_rgb::BRDF: in = wi(3) wo(3) u(2); sample_out = weight(3) wo(3) pdf; eval_out = f*cos(3) pdf */
@@ -1896,10 +1950,11 @@ void wpt_oracle_world_to_camera(const wpt_camera* cam, int n, const float* point
 
 /* getGroundTruth (wurblpt.hpp:626-761) for a static scene; arrays[k] (GroundTruth bit k, wurblpt_hip.h) may be NULL */
 int wpt_oracle_ground_truth(const wpt_scene_desc* scene, const wpt_camera* camera, const wpt_camera* camera_prev,
-        const wpt_camera* camera_next, const wpt_params* params, uint32_t width, uint32_t height, void* const* arrays)
+        const wpt_camera* camera_next, const float* times, const wpt_params* params, uint32_t width, uint32_t height, void* const* arrays)
 {
     if (!scene || !camera || !params || !arrays || width == 0 || height == 0)
         return 1;
+    const float t0 = times ? times[0] : 0.0f, tPrev = times ? times[1] : 0.0f, tNext = times ? times[2] : 0.0f;
     const wpt_camera& camPrev = camera_prev ? *camera_prev : *camera;
     const wpt_camera& camNext = camera_next ? *camera_next : *camera;
     wpt_camera rayCam = *camera;
@@ -1925,6 +1980,7 @@ int wpt_oracle_ground_truth(const wpt_scene_desc* scene, const wpt_camera* camer
         Ctx c;
         c.sc = scene;
         c.pr = params;
+        c.time = t0; /* animationCacheT0 */
         memset(&c.cnt, 0, sizeof(c.cnt));
 #pragma omp for schedule(dynamic, 64)
         for (unsigned int pixel = 0; pixel < pixels; pixel++) {
@@ -1933,6 +1989,7 @@ int wpt_oracle_ground_truth(const wpt_scene_desc* scene, const wpt_camera* camer
             Prng prng { pixel };
             V2 pixelCoord = V2 { (x + 0.5f) * invWidth, (y + 0.5f) * invHeight };
             Ray ray = cameraGetRay(rayCam, pixelCoord.x, pixelCoord.y, prng, width, height);
+            ray.time = t0;
             const HitRecord hr = bvhHit(c, ray, RayHelper(ray), params->min_hit_distance, k_maxval);
             V3 wsPos = v3(0.0f), wsGNrm = v3(0.0f), wsGTan = v3(0.0f), wsMNrm = v3(0.0f), wsMTan = v3(0.0f);
             V3 csPos = v3(0.0f), csGNrm = v3(0.0f), csGTan = v3(0.0f), csMNrm = v3(0.0f), csMTan = v3(0.0f);
@@ -1957,8 +2014,29 @@ int wpt_oracle_ground_truth(const wpt_scene_desc* scene, const wpt_camera* camer
                 csDepth = -csPos.z;
                 csDist = length(csPos);
                 txCor = hr.texcoords;
-                V3 wsPosPrev = wsPos; /* no animated hitables on this path */
+                V3 wsPosPrev = wsPos;
                 V3 wsPosNext = wsPos;
+                int ai = -1;
+                if (hr.prim & PRIM_SPHERE)
+                    ai = scene->spheres[hr.prim & ~PRIM_SPHERE].animation;
+                else if (scene->tri_geom[hr.prim].flags & WPT_TRI_ANIMATE)
+                    ai = scene->instances[scene->tri_geom[hr.prim].instance].animation;
+                if (ai >= 0) { /* wurblpt.hpp:695-699 */
+                    const wptanim::Trs T0 = animationAt(c, ai, t0);
+                    wptanim::Trs inv; /* inverse(Transformation), transformation.hpp:157-163 */
+                    inv.q[0] = -T0.q[0]; inv.q[1] = -T0.q[1]; inv.q[2] = -T0.q[2]; inv.q[3] = T0.q[3];
+                    V3 invS = 1.0f / v3(T0.s);
+                    V3 invT = quat_rotate(inv.q, (-v3(T0.t)) * invS);
+                    inv.s[0] = invS.x; inv.s[1] = invS.y; inv.s[2] = invS.z;
+                    inv.t[0] = invT.x; inv.t[1] = invT.y; inv.t[2] = invT.z;
+                    const float pos[3] = { wsPos.x, wsPos.y, wsPos.z };
+                    float posOrig[3], moved[3];
+                    wptanim::applyTrs(inv, pos, posOrig);
+                    wptanim::applyTrs(animationAt(c, ai, tPrev), posOrig, moved);
+                    wsPosPrev = v3(moved);
+                    wptanim::applyTrs(animationAt(c, ai, tNext), posOrig, moved);
+                    wsPosNext = v3(moved);
+                }
                 wsOP = wsPosPrev - wsPos;
                 wsON = wsPosNext - wsPos;
                 V3 csPosPrev = invPrev.point(wsPosPrev);

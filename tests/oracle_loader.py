@@ -50,17 +50,18 @@ class Oracle:
             raise RuntimeError("oracle render failed: %d" % rc)
         return frame, cnt.as_dict()
 
-    def ground_truth(self, scene, bits=(1 << 20) - 1, camera_prev=None, camera_next=None, params=None, width=None, height=None):
+    def ground_truth(self, scene, bits=(1 << 20) - 1, camera_prev=None, camera_next=None, params=None, width=None, height=None, times=None):
         """getGroundTruth restated: dict name -> numpy array, as wurblpt_amd.device.ground_truth returns it."""
         from wurblpt_amd import device, host
         w = width or scene.width
         h = height or scene.height
         p = params if params is not None else host.default_params()
         arrays, ptrs = device.gt_arrays(w, h, bits)
-        self.L.wpt_oracle_ground_truth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        self.L.wpt_oracle_ground_truth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        tm = (C.c_float * 3)(*times) if times is not None else None
         rc = self.L.wpt_oracle_ground_truth(C.cast(scene.desc, C.c_void_p), C.cast(scene.camera, C.c_void_p),
                                             C.addressof(camera_prev) if camera_prev is not None else None,
-                                            C.addressof(camera_next) if camera_next is not None else None, C.addressof(p), w, h, ptrs)
+                                            C.addressof(camera_next) if camera_next is not None else None, tm, C.addressof(p), w, h, ptrs)
         if rc != 0:
             raise RuntimeError("oracle ground truth failed: %d" % rc)
         return {device.GT_NAMES[k]: a for k, a in enumerate(arrays) if a is not None}

@@ -632,12 +632,13 @@ def test_get_ground_truth_host_api(dev, oracle):
     assert np.abs(got["camera_space_offset_to_prev"]).max() > 0.01 and (got["camera_space_offset_to_next"] == 0).all()
 
 
-@pytest.mark.parametrize("variant,t0,t1", [(0, 0.0, 1.0), (1, 0.2, 0.7), (2, 0.0, 1.0), (4, 0.0, 1.0), (0, 0.5, 0.5)])
+@pytest.mark.parametrize("variant,t0,t1", [(0, 0.0, 1.0), (1, 0.2, 0.7), (2, 0.0, 1.0), (4, 0.0, 1.0), (0, 0.5, 0.5), (8, 0.0, 1.0), (10, 0.3, 0.3)])
 def test_motion_blur_and_animated_instances_bit_exact(dev, oracle, variant, t0, t1):
     """The last part of scope row f4: an exposure interval (every camera ray draws its time, camera.hpp:175-184), a
     camera that moves along key frames, mesh instances with an animation on top of their transformation (corners,
     normals and tangents at the ray's time, hitable_triangle.hpp:209-218,296-317) and a moving light whose
-    pdfValue / direction follow it: GPU == oracle, frames and work counters.  t0 == t1 = 0.5: a still from the middle."""
+    pdfValue / direction follow it: GPU == oracle, frames and work counters.  t0 == t1 = 0.5: a still from the middle.
+    Variants 8 and 10 add rolling marbles: spheres placed by their animation alone, one of them a moving light."""
     sc = host.animated(64, 48, variant, t0, t1)
     p = host.default_params()
     p.t0, p.t1 = t0, t1
@@ -650,9 +651,6 @@ def test_motion_blur_and_animated_instances_bit_exact(dev, oracle, variant, t0, 
     assert gc == rc
     got2, _ = ds.render(4, params=p)  # the product kernel
     assert bits_equal(got2, ref)
-    if variant != 4:
-        with pytest.raises(RuntimeError):
-            dev.ground_truth(ds)      # not built for moving instances: refused, not wrong
 
 
 def test_exposure_interval_on_a_still_scene(dev, oracle):
@@ -689,3 +687,47 @@ def test_mcpt_host_api(dev, oracle):
         p.t0, p.t1 = t0, t1
         ref, _ = oracle.render(sc, 3, p)
         assert bits_equal(host.mcpt(sc, 3, t0, t1), ref), variant
+
+
+def test_ground_truth_of_an_animated_scene(dev, oracle):
+    """getGroundTruth with things that move (wurblpt.hpp:693-705): the picture at t0 = 0.4 with the instances where they
+    are then, world space flow from each hit point's place at tPrev / tNext, camera space and pixel space flow through
+    the cameras of those times; C ABI against the restatement, and the host API, which takes the cameras from the
+    camera's own animation."""
+    t0, t_prev, t_next = 0.4, 0.1, 0.9
+    sc = host.animated(96, 64, 0, t0, t0)
+    cam_prev = host.animated(96, 64, 0, t_prev, t_prev)
+    cam_next = host.animated(96, 64, 0, t_next, t_next)
+    times = (t0, t_prev, t_next)
+    ref = oracle.ground_truth(sc, camera_prev=cam_prev.camera.contents, camera_next=cam_next.camera.contents, times=times)
+    ds = dev.DeviceScene(sc)
+    got = dev.ground_truth(ds, camera_prev=cam_prev.camera.contents, camera_next=cam_next.camera.contents, times=times)
+    _assert_ground_truth_equal(got, ref)
+    moving = np.abs(got["world_space_offset_to_prev"]).max(axis=2) > 0
+    assert 0.02 < moving.mean() < 0.5                      # the cube, the panel and the light move, the room does not
+    assert np.abs(got["world_space_offset_to_next"][moving]).max() > 0.05
+    # the same picture at another moment is another picture
+    other = dev.ground_truth(dev.DeviceScene(cam_next), bits=1)
+    assert not bits_equal(other["world_space_positions"], got["world_space_positions"])
+    # host API: cameras at tPrev / tNext come from the camera's key frames
+    table = host.material_scene_index(sc)
+    api = host.get_ground_truth(sc, times=times)
+    flat = ref.pop("materials")
+    assert np.array_equal(api.pop("materials"), np.where(flat >= 0, table[np.maximum(flat, 0)], -1).astype(np.int32))
+    _assert_ground_truth_equal(api, ref)
+
+
+def test_measured_brdf_under_an_exposure_interval(dev, oracle):
+    """Measured BRDFs and motion blur together have their own kernel instantiation: the time draw changes every path of
+    the measured-BRDF scene; GPU == oracle."""
+    sc = host.rgl_scene(48, 32, 1)
+    p = host.default_params()
+    p.t0, p.t1 = 0.0, 0.5
+    ref, rc = oracle.render(sc, 3, p)
+    ds = dev.DeviceScene(sc)
+    got, gc = ds.render(3, params=p, with_counters=True)
+    assert bits_equal(got, ref) and gc == rc
+    got2, _ = ds.render(3, params=p)
+    assert bits_equal(got2, ref)
+    still, _ = ds.render(3)
+    assert not bits_equal(still, ref)

@@ -41,7 +41,7 @@ class Animation(C.Structure):
 
 class Sphere(C.Structure):
     _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("rotation", C.c_float * 4),
-                ("material", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("material", C.c_uint32), ("animation", C.c_int32), ("reserved", C.c_uint32 * 2)]
 
 
 class Hotspot(C.Structure):

@@ -99,7 +99,7 @@ WPT_D float hotSpotPdfValue(float4 g0, float4 g1, float4 g2, f3 org, f3 dir, con
 }
 
 /* HitableSphere::pdfValue (hitable_sphere.hpp:149-186) */
-WPT_D float spherePdfValue(const wpt_sphere& sp, f3 org, f3 dir)
+WPT_D float spherePdfValue(const wpt_sphere& sp, const wpt_sphere& spHit, f3 org, f3 dir)
 {
     const f3 cmo = sub(ld3(sp.center), org);
     const float distanceSquared = dot(cmo, cmo);
@@ -109,7 +109,7 @@ WPT_D float spherePdfValue(const wpt_sphere& sp, f3 org, f3 dir)
         value = 0.25f * k_inv_pi; /* inside: any direction hits */
     } else {
         float a;
-        if (sphereTest(sp, org, dir, 0.0f, k_maxval, a)) {
+        if (sphereTest(spHit, org, dir, 0.0f, k_maxval, a)) { /* this->hit(): an animated sphere is placed differently there */
             const float discriminant = 1.0f - radiusSquared / distanceSquared;
             const float cosThetaMax = discriminant > 0.0f ? __builtin_sqrtf(discriminant) : 0.0f;
             const float solidAngle = 2.0f * k_pi * (1.0f - cosThetaMax);
@@ -141,7 +141,7 @@ WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, floa
     for (uint32_t i = 0; i < sv.hotspotCount; i++) {
         const uint32_t p = sv.hotspots[i].prim;
         if ((F & FEAT_SPHERES) && sv.hotspots[i].kind == WPT_HOTSPOT_SPHERE) {
-            sum += spherePdfValue(sv.spheres[p], org, dir);
+            sum += spherePdfValue(sphereForPdf<F>(sv, sv.spheres[p], time), sphereAt<F>(sv, sv.spheres[p], time), org, dir);
         } else if ((F & FEAT_ANIM) && sv.hotspots[i].animation >= 0) {
             /* the light moves: its corners at the path's time (hitable_triangle.hpp:209-218,405-423) */
             float4 g0 = tri4(3 * p), g1 = tri4(3 * p + 1), g2 = tri4(3 * p + 2);
@@ -336,7 +336,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
         f3 directDir;
         uint32_t hotSpotPrim = hs.prim;
         if ((F & FEAT_SPHERES) && hs.kind == WPT_HOTSPOT_SPHERE) {
-            directDir = sphereDirection(sv.spheres[hs.prim], h.p, ps.prng);
+            directDir = sphereDirection(sphereAt<F>(sv, sv.spheres[hs.prim], ps.time), h.p, ps.prng);
             hotSpotPrim = PRIM_SPHERE | hs.prim;
         } else {
             /* HitableTriangle::direction (hitable_triangle.hpp:425-443) */
@@ -404,7 +404,7 @@ WPT_D int blockNeeEnd(const SceneView& sv, const wpt_params& par, PathState& ps,
 {
     if (ps.rayKind == RAY_NEE_LIGHT) {
         if (best.prim == ps.chosenPrim) {
-            Hit lh = finishHit<F>(sv, best, ps.ray.o, ps.ray.d);
+            Hit lh = finishHit<F>(sv, best, ps.ray.o, ps.ray.d, ps.time);
             const wpt_material& lm = resolveMaterial<F>(sv, lh.material, lh);
             f4 rad = mul(ps.neeFactor, materialEmitted<F>(sv, lm, lh));
             f3 oplLight = add(ps.opl, scl(lh.a, mk3(ps.ray.ri.x, ps.ray.ri.y, ps.ray.ri.z)));

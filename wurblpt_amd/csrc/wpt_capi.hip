@@ -201,6 +201,9 @@ uint32_t sceneFeatures(const wpt_scene_desc* d)
     for (uint32_t i = 0; i < d->instance_count; i++)
         if (d->instances[i].animation >= 0)
             f |= FEAT_ANIM;
+    for (uint32_t i = 0; i < d->sphere_count; i++)
+        if (d->spheres[i].animation >= 0)
+            f |= FEAT_ANIM;
     return f;
 }
 
@@ -296,9 +299,12 @@ wpt_status validate(const wpt_scene_desc* d)
     }
     if (d->sphere_count > 0 && !d->spheres)
         return fail(WPT_ERR_INVALID_ARGUMENT, "sphere array is NULL");
-    for (uint32_t i = 0; i < d->sphere_count; i++)
+    for (uint32_t i = 0; i < d->sphere_count; i++) {
         if (d->spheres[i].material >= d->material_count)
             return fail(WPT_ERR_INVALID_ARGUMENT, "sphere references a material outside the array");
+        if (d->spheres[i].animation >= int32_t(d->animation_count))
+            return fail(WPT_ERR_INVALID_ARGUMENT, "sphere refers to an animation outside the array");
+    }
     for (uint32_t i = 0; i < d->hotspot_count; i++) {
         const wpt_hotspot& h = d->hotspots[i];
         if (h.kind > WPT_HOTSPOT_SPHERE)
@@ -664,8 +670,6 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     if (params->t0 != params->t1)
         need |= FEAT_ANIM;
     const bool anim = (need & FEAT_ANIM) != 0;
-    if (anim && (need & FEAT_RGL))
-        return fail(WPT_ERR_UNSUPPORTED, "measured BRDFs together with motion blur / animated instances are not instantiated");
     dim3 grid((block_size + WG - 1) / WG);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const bool count = counters_device != nullptr;
@@ -697,10 +701,16 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     const bool rgl = (need & FEAT_RGL) != 0; /* measured BRDFs have their own instantiation of the product kernel */
     if (anim) {
         /* its own instantiation of the product kernel, like the measured BRDFs */
-        if (count)
+        if (need & FEAT_RGL) {
+            if (count)
+                launchFullRglAnimCount(args, grid, stream);
+            else
+                launchFullRglAnim(args, grid, stream);
+        } else if (count) {
             launchFullAnimCount(args, grid, stream);
-        else
+        } else {
             launchFullAnim(args, grid, stream);
+        }
     } else if (count) {
         if (basic)
             launchBasicCount(args, grid, stream);
@@ -814,7 +824,7 @@ wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera, const wp
 }
 
 wpt_status wpt_ground_truth_device(wpt_scene* scene, const wpt_camera* camera, const wpt_camera* camera_prev,
-        const wpt_camera* camera_next, const wpt_params* params, uint32_t width, uint32_t height,
+        const wpt_camera* camera_next, const float times[3], const wpt_params* params, uint32_t width, uint32_t height,
         void* const arrays_device[WPT_GT_ARRAY_COUNT], void* hip_stream)
 {
     if (!scene || !camera || !params || !arrays_device)
@@ -825,8 +835,6 @@ wpt_status wpt_ground_truth_device(wpt_scene* scene, const wpt_camera* camera, c
         return fail(WPT_ERR_UNSUPPORTED, "camera surround mode is not known to the kernel");
     if (camera->distortion_type > WPT_DISTORTION_OPENCV)
         return fail(WPT_ERR_UNSUPPORTED, "lens distortion model is not known to the kernel");
-    if (scene->features & FEAT_ANIM)
-        return fail(WPT_ERR_UNSUPPORTED, "ground truth of scenes with animated instances is not built");
     if ((arrays_device[WPT_GT_PIXEL_SPACE_OFFSET_TO_PREV] || arrays_device[WPT_GT_PIXEL_SPACE_OFFSET_TO_NEXT])
             && (camera->surround_mode != WPT_SURROUND_OFF || camera->stereoscopic_distance > 0.0f))
         return fail(WPT_ERR_UNSUPPORTED, "pixel space offsets exist for Surround_Off, non-stereoscopic cameras only (camera.hpp:207-208)");
@@ -836,6 +844,10 @@ wpt_status wpt_ground_truth_device(wpt_scene* scene, const wpt_camera* camera, c
     args.camPrev = camera_prev ? *camera_prev : *camera;
     args.camNext = camera_next ? *camera_next : *camera;
     args.par = *params;
+    args.t0 = times ? times[0] : 0.0f;
+    args.tPrev = times ? times[1] : 0.0f;
+    args.tNext = times ? times[2] : 0.0f;
+    args.par.t0 = args.par.t1 = args.t0; /* one moment, no exposure interval */
     args.width = width;
     args.height = height;
     bool any = false;
@@ -851,7 +863,7 @@ wpt_status wpt_ground_truth_device(wpt_scene* scene, const wpt_camera* camera, c
 }
 
 wpt_status wpt_ground_truth(wpt_scene* scene, const wpt_camera* camera, const wpt_camera* camera_prev,
-        const wpt_camera* camera_next, const wpt_params* params, uint32_t width, uint32_t height,
+        const wpt_camera* camera_next, const float times[3], const wpt_params* params, uint32_t width, uint32_t height,
         void* const arrays_host[WPT_GT_ARRAY_COUNT])
 {
     if (!arrays_host)
@@ -869,7 +881,7 @@ wpt_status wpt_ground_truth(wpt_scene* scene, const wpt_camera* camera, const wp
         }
     }
     if (st == WPT_OK)
-        st = wpt_ground_truth_device(scene, camera, camera_prev, camera_next, params, width, height, dev, nullptr);
+        st = wpt_ground_truth_device(scene, camera, camera_prev, camera_next, times, params, width, height, dev, nullptr);
     if (st == WPT_OK) {
         hipError_t e = hipDeviceSynchronize();
         for (int k = 0; k < WPT_GT_ARRAY_COUNT && e == hipSuccess; k++)

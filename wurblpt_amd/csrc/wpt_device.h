@@ -511,10 +511,52 @@ WPT_D bool sphereTest(const wpt_sphere& sp, f3 org, f3 dir, float amin, float am
     return hit;
 }
 
-/* HitableSphere::constructHitRecord (hitable_sphere.hpp:42-75) */
-WPT_D Hit finishSphereHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir)
+/* An animated sphere as hit() and direction() see it at a time (hitable_sphere.hpp:118-127,196-203): the animation's
+ * translation is added to the centre, its largest scaling multiplies the radius, its rotation follows the sphere's */
+template<uint32_t F> WPT_D wpt_sphere sphereAt(const SceneView& sv, const wpt_sphere& sp, float time)
 {
-    const wpt_sphere& sp = sv.spheres[c.prim & ~PRIM_SPHERE];
+    wpt_sphere r = sp;
+    if ((F & FEAT_ANIM) && sp.animation >= 0) {
+        const wptanim::Trs T = animationAt(sv, sp.animation, time);
+        float m = T.s[0];
+        if (T.s[1] > m)
+            m = T.s[1];
+        if (T.s[2] > m)
+            m = T.s[2];
+        for (int k = 0; k < 3; k++)
+            r.center[k] = sp.center[k] + T.t[k];
+        r.radius = sp.radius * m;
+        /* quaternion product sp.rotation * T.rotation (gvm.hpp:1687-1695) */
+        const float x = sp.rotation[0], y = sp.rotation[1], z = sp.rotation[2], w = sp.rotation[3];
+        const float qx = T.q[0], qy = T.q[1], qz = T.q[2], qw = T.q[3];
+        r.rotation[0] = w * qx + x * qw + y * qz - z * qy;
+        r.rotation[1] = w * qy + y * qw + z * qx - x * qz;
+        r.rotation[2] = w * qz + z * qw + x * qy - y * qx;
+        r.rotation[3] = w * qw - x * qx - y * qy - z * qz;
+    }
+    return r;
+}
+/* ... and as pdfValue() places it (:161-166): the whole transformation applied to the centre */
+template<uint32_t F> WPT_D wpt_sphere sphereForPdf(const SceneView& sv, const wpt_sphere& sp, float time)
+{
+    wpt_sphere r = sp;
+    if ((F & FEAT_ANIM) && sp.animation >= 0) {
+        const wptanim::Trs T = animationAt(sv, sp.animation, time);
+        float m = T.s[0];
+        if (T.s[1] > m)
+            m = T.s[1];
+        if (T.s[2] > m)
+            m = T.s[2];
+        wptanim::applyTrs(T, sp.center, r.center);
+        r.radius = sp.radius * m;
+    }
+    return r;
+}
+
+/* HitableSphere::constructHitRecord (hitable_sphere.hpp:42-75) */
+template<uint32_t F = 0> WPT_D Hit finishSphereHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir, float time = 0.0f)
+{
+    const wpt_sphere sp = sphereAt<F>(sv, sv.spheres[c.prim & ~PRIM_SPHERE], time);
     Hit h;
     h.a = c.a;
     h.prim = c.prim;
@@ -544,7 +586,7 @@ template<uint32_t F = 0>
 WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir, float time = 0.0f)
 {
     if ((F & FEAT_SPHERES) && (c.prim & PRIM_SPHERE))
-        return finishSphereHit(sv, c, org, dir);
+        return finishSphereHit<F>(sv, c, org, dir, time);
     Hit h;
     h.a = c.a;
     h.prim = c.prim;

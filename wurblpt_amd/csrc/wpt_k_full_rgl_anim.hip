@@ -1,0 +1,17 @@
+/* wpt_k_full_rgl_anim.hip -- instantiates wpt_pathtrace<FEAT_ALL | FEAT_RGL | FEAT_ANIM>: measured BRDFs in scenes with an
+ * exposure interval or animated hitables (with and without work counters; not a tuned combination) */
+#include "wpt_pathtrace.inc.h"
+
+namespace wptk {
+
+void launchFullRglAnim(const KernelArgs& args, dim3 grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL | FEAT_RGL | FEAT_ANIM, false, false, 2, false>), grid, dim3(WG), 0, stream, args);
+}
+
+void launchFullRglAnimCount(const KernelArgs& args, dim3 grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL | FEAT_RGL | FEAT_ANIM, true, false, 2, false>), grid, dim3(WG), 0, stream, args);
+}
+
+}

@@ -5,8 +5,8 @@
  * One lane = one pixel, one ray: the walk is the reference's BVH::hit in the stackless form the path
  * tracing kernels use, the hit record and the material tangent space are theirs too (wpt_device.h),
  * the ray comes from blockNew (wpt_blocks.h) with the pixel jitter and the lens sampling switched off.
- * The scene is static for the device path, so the world space offsets to the previous / next frame
- * are zero and the camera space / pixel space ones come from the camera's motion alone.
+ * The picture is taken at t0; the flow arrays compare the hit point's place at tPrev / tNext (it moves
+ * with an animated instance) as seen by the camera at those times.
  */
 #include "wpt_pathtrace.inc.h"
 
@@ -71,7 +71,7 @@ WPT_D void store1(void* array, uint32_t pixel, float v)
         static_cast<float*>(array)[pixel] = v;
 }
 
-constexpr uint32_t GT_FEATURES = FEAT_TEXTURES | FEAT_LENS | FEAT_SPHERES;
+constexpr uint32_t GT_FEATURES = FEAT_TEXTURES | FEAT_LENS | FEAT_SPHERES | FEAT_ANIM;
 
 __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs args)
 {
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs a
     fa.samplesSqrt = 1;
     PathState ps;
     pathStateInit(ps, pixel, args.width);
-    blockNew<GT_FEATURES>(fa, ps);
+    blockNew<GT_FEATURES>(fa, ps, &sv); /* par.t0 == par.t1: no time draw, ps.time = t0 */
 
     /* BVH::hit (bvh.hpp:270-329): closest candidate, later candidates win ties */
     const RayAux aux = rayAux(ps.ray.d);
@@ -110,11 +110,18 @@ __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs a
             bool accepted;
             if (prim & PRIM_SPHERE) {
                 c.invDet = c.U = c.V = c.W = 0.0f;
-                accepted = sphereTest(sv.spheres[prim & ~PRIM_SPHERE], ps.ray.o, ps.ray.d, args.par.min_hit_distance, amax, c.a);
+                accepted = sphereTest(sphereAt<GT_FEATURES>(sv, sv.spheres[prim & ~PRIM_SPHERE], ps.time), ps.ray.o, ps.ray.d, args.par.min_hit_distance, amax, c.a);
             } else {
                 const float4 g0 = sv.triGeom[3 * (size_t)prim], g1 = sv.triGeom[3 * (size_t)prim + 1], g2 = sv.triGeom[3 * (size_t)prim + 2];
-                accepted = triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), ps.ray.o, aux,
-                        args.par.min_hit_distance, amax, c);
+                f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
+                if (__float_as_uint(g2.w) & WPT_TRI_ANIMATE) {
+                    float animationM[16];
+                    wptanim::toMat4(animationAt(sv, sv.instances[__float_as_uint(g0.w)].animation, ps.time), animationM);
+                    v0 = animatePoint(animationM, v0);
+                    v1 = animatePoint(animationM, v1);
+                    v2 = animatePoint(animationM, v2);
+                }
+                accepted = triangleTest(v0, v1, v2, ps.ray.o, aux, args.par.min_hit_distance, amax, c);
             }
             if (accepted) {
                 c.prim = prim;
@@ -137,7 +144,7 @@ __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs a
     f2 psOP = txCor, psON = txCor;
     int matInd = -1;
     if (best.prim != NO_HIT) {
-        const Hit h = finishHit<GT_FEATURES>(sv, best, ps.ray.o, ps.ray.d);
+        const Hit h = finishHit<GT_FEATURES>(sv, best, ps.ray.o, ps.ray.d, ps.time);
         wsPos = h.p;
         wsGNrm = h.n;
         wsGTan = h.t;
@@ -154,7 +161,37 @@ __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs a
         csDepth = -csPos.z;
         csDist = __builtin_sqrtf(dot(csPos, csPos));
         txCor = h.tc;
-        const f3 wsPosPrev = wsPos, wsPosNext = wsPos;
+        f3 wsPosPrev = wsPos, wsPosNext = wsPos;
+        int ai = -1;
+        if (best.prim & PRIM_SPHERE) {
+            ai = sv.spheres[best.prim & ~PRIM_SPHERE].animation;
+        } else {
+            const uint32_t inst = __float_as_uint(sv.triGeom[3 * (size_t)best.prim].w);
+            if (__float_as_uint(sv.triGeom[3 * (size_t)best.prim + 2].w) & WPT_TRI_ANIMATE)
+                ai = sv.instances[inst].animation;
+        }
+        if (ai >= 0) {
+            /* wurblpt.hpp:695-699: back to where the instance keeps the point, then to where it is at tPrev / tNext */
+            const wptanim::Trs T0 = animationAt(sv, ai, args.t0);
+            wptanim::Trs inv;
+            inv.q[0] = -T0.q[0];
+            inv.q[1] = -T0.q[1];
+            inv.q[2] = -T0.q[2];
+            inv.q[3] = T0.q[3];
+            for (int k = 0; k < 3; k++)
+                inv.s[k] = 1.0f / T0.s[k];
+            const f3 invT = quatRotate(inv.q, mul(neg(ld3(T0.t)), ld3(inv.s)));
+            inv.t[0] = invT.x;
+            inv.t[1] = invT.y;
+            inv.t[2] = invT.z;
+            const float pos[3] = { wsPos.x, wsPos.y, wsPos.z };
+            float posOrig[3], moved[3];
+            wptanim::applyTrs(inv, pos, posOrig);
+            wptanim::applyTrs(animationAt(sv, ai, args.tPrev), posOrig, moved);
+            wsPosPrev = mk3(moved[0], moved[1], moved[2]);
+            wptanim::applyTrs(animationAt(sv, ai, args.tNext), posOrig, moved);
+            wsPosNext = mk3(moved[0], moved[1], moved[2]);
+        }
         wsOP = sub(wsPosPrev, wsPos);
         wsON = sub(wsPosNext, wsPos);
         const InverseTransformation invP = inverseOf(args.camPrev), invN = inverseOf(args.camNext);

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         if ((F & FEAT_SPHERES) && (leafPrim & PRIM_SPHERE)) {
                             /* HitableSphere::hit (hitable_sphere.hpp:104-147) */
                             c.invDet = c.U = c.V = c.W = 0.0f;
-                            accepted = sphereTest(sv.spheres[leafPrim & ~PRIM_SPHERE], ps.ray.o, ps.ray.d, par.min_hit_distance, bound, c.a);
+                            accepted = sphereTest(sphereAt<F>(sv, sv.spheres[leafPrim & ~PRIM_SPHERE], ps.time), ps.ray.o, ps.ray.d, par.min_hit_distance, bound, c.a);
                         } else {
                             const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
                             f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
@@ -410,6 +410,7 @@ struct GroundTruthArgs {
     SceneView scene;
     wpt_camera cam, camPrev, camNext;
     wpt_params par;
+    float t0, tPrev, tNext;
     uint32_t width, height;
     void* array[WPT_GT_ARRAY_COUNT];
 };
@@ -424,6 +425,8 @@ void launchFullRgl(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFullRglCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFullAnim(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFullAnimCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
+void launchFullRglAnim(const KernelArgs& args, dim3 grid, hipStream_t stream);
+void launchFullRglAnimCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 
 } /* namespace wptk */
 

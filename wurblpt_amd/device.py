@@ -146,18 +146,20 @@ def gt_arrays(width, height, bits=GT_ALL):
     return arrays, ptrs
 
 
-def ground_truth(scene, bits=GT_ALL, camera_prev=None, camera_next=None, params=None, width=None, height=None):
-    """wpt_ground_truth on a DeviceScene: dict name -> numpy array [h, w, comps] of the requested GroundTruth bits."""
+def ground_truth(scene, bits=GT_ALL, camera_prev=None, camera_next=None, params=None, width=None, height=None, times=None):
+    """wpt_ground_truth on a DeviceScene: dict name -> numpy array [h, w, comps] of the requested GroundTruth bits.
+    times = (t0, tPrev, tNext) for animated instances."""
     from . import host
     w = width or scene.host.width
     h = height or scene.host.height
     p = params if params is not None else host.default_params()
     arrays, ptrs = gt_arrays(w, h, bits)
     L = lib()
-    L.wpt_ground_truth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.wpt_ground_truth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    tm = (C.c_float * 3)(*times) if times is not None else None
     _check(L.wpt_ground_truth(scene._handle, C.cast(scene.host.camera, C.c_void_p),
                               C.addressof(camera_prev) if camera_prev is not None else None,
-                              C.addressof(camera_next) if camera_next is not None else None, C.addressof(p), w, h, ptrs))
+                              C.addressof(camera_next) if camera_next is not None else None, tm, C.addressof(p), w, h, ptrs))
     return {GT_NAMES[k]: a for k, a in enumerate(arrays) if a is not None}
 
 

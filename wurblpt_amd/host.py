@@ -252,7 +252,7 @@ def material_scene_index(scene):
     return out
 
 
-def get_ground_truth(scene, bits=(1 << 20) - 1, prev_from_at=None, next_from_at=None, width=None, height=None):
+def get_ground_truth(scene, bits=(1 << 20) - 1, prev_from_at=None, next_from_at=None, width=None, height=None, times=None):
     """getGroundTruth() of include/wurblpt/wurblpt.hpp (needs a device) for the scene's look-at camera without
     lens; prev_from_at / next_from_at: 6 floats, eye and target of the camera at tPrev / tNext."""
     from . import device
@@ -260,11 +260,12 @@ def get_ground_truth(scene, bits=(1 << 20) - 1, prev_from_at=None, next_from_at=
     h = height or scene.height
     arrays, ptrs = device.gt_arrays(w, h, bits)
     L = lib()
-    L.wpt_host_get_ground_truth.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.wpt_host_get_ground_truth.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    tm = (C.c_float * 3)(*times) if times is not None else None
     pf = np.ascontiguousarray(prev_from_at, np.float32) if prev_from_at is not None else None
     nf = np.ascontiguousarray(next_from_at, np.float32) if next_from_at is not None else None
     if not L.wpt_host_get_ground_truth(scene._handle, w, h, C.c_void_p(pf.ctypes.data) if pf is not None else None,
-                                       C.c_void_p(nf.ctypes.data) if nf is not None else None, ptrs):
+                                       C.c_void_p(nf.ctypes.data) if nf is not None else None, tm, ptrs):
         raise RuntimeError("getGroundTruth failed")
     return {device.GT_NAMES[k]: a for k, a in enumerate(arrays) if a is not None}
 

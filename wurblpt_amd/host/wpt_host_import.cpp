@@ -190,27 +190,28 @@ extern "C" int wpt_host_mcpt(wpt_host_scene* hs, unsigned int width, unsigned in
     return 1;
 }
 
-/* getGroundTruth() of include/wurblpt/wurblpt.hpp for a scene of this library with its look-at camera;
- * prevFromAt / nextFromAt: eye and target (6 floats) of the camera at tPrev / tNext, or NULL.  arrays[k]:
- * host array of GroundTruth bit k (width * height * components), or NULL.  1 on success. */
+/* getGroundTruth() of include/wurblpt/wurblpt.hpp for a scene of this library.  The camera is the one the scene was
+ * finished with (its animation gives the camera at tPrev / tNext); prevFromAt / nextFromAt, if given, replace it at
+ * those times by a look-at camera (eye and target, 6 floats).  times = t0, tPrev, tNext.  arrays[k]: host array of
+ * GroundTruth bit k (width * height * components), or NULL.  1 on success. */
 extern "C" int wpt_host_get_ground_truth(wpt_host_scene* hs, unsigned int width, unsigned int height, const float* prevFromAt,
-        const float* nextFromAt, void* const* arrays)
+        const float* nextFromAt, const float* times, void* const* arrays)
 {
-    float vfov;
-    vec3 from, at;
-    wptHostCameraOf(hs, vfov, from, at);
+    const Camera& camera = wptHostCameraObjectOf(hs);
     const vec3 up(0.0f, 1.0f, 0.0f);
-    Optics optics(Projection(vfov, float(width) / height), LensDistortion(), LensDepthOfField(0.0f, 1.0f));
-    Camera camera(optics, Transformation::fromLookAt(from, at, up));
-    Camera cameraPrev(optics, prevFromAt ? Transformation::fromLookAt(vec3(prevFromAt), vec3(prevFromAt + 3), up) : camera.transformation);
-    Camera cameraNext(optics, nextFromAt ? Transformation::fromLookAt(vec3(nextFromAt), vec3(nextFromAt + 3), up) : camera.transformation);
+    Camera cameraPrev(camera.optics, prevFromAt ? Transformation::fromLookAt(vec3(prevFromAt), vec3(prevFromAt + 3), up) : Transformation());
+    Camera cameraNext(camera.optics, nextFromAt ? Transformation::fromLookAt(vec3(nextFromAt), vec3(nextFromAt + 3), up) : Transformation());
     unsigned int bits = 0;
     for (int k = 0; k < WPT_GT_ARRAY_COUNT; k++)
         if (arrays[k])
             bits |= 1u << k;
     SensorRGB sensor(width, height);
-    GroundTruth gt = getGroundTruth(sensor, camera, prevFromAt ? &cameraPrev : nullptr, nextFromAt ? &cameraNext : nullptr,
-            wptHostSceneOf(hs), bits);
+    Scene& scene = wptHostSceneOf(hs);
+    const float t0 = times ? times[0] : 0.0f, tPrev = times ? times[1] : 0.0f, tNext = times ? times[2] : 0.0f;
+    if (scene.bvhNeedsUpdate(t0, t0))
+        scene.updateBVH(t0, t0);
+    GroundTruth gt = getGroundTruth(sensor, camera, prevFromAt ? &cameraPrev : nullptr, nextFromAt ? &cameraNext : nullptr, scene, t0, tPrev,
+            tNext, bits);
     void* src[WPT_GT_ARRAY_COUNT];
     gt.arrayPointers(src);
     for (int k = 0; k < WPT_GT_ARRAY_COUNT; k++)

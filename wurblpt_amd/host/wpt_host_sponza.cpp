@@ -454,7 +454,9 @@ wpt_host_scene* wptHostFinishAnimated(Scene* scene, unsigned int width, unsigned
  * (three key frames, scaled), a textured two-sided panel that swings about the z axis, a quad light that slides and
  * tilts (a hot spot, so its pdfValue / direction move too), a static glass block; the camera dollies sideways and
  * pans.  variant bit 0: thin lens as well; bit 1: the camera stands still (only the instances move);
- * bit 2: nothing but the camera moves. */
+ * bit 2: nothing but the camera moves; bit 3: rolling marbles as well (wurblpt-rolling-marbles.cpp: unit spheres
+ * placed, scaled and turned by their animation alone -- a checkered one, a glass one, and a glowing one that is a
+ * hot spot). */
 extern "C" wpt_host_scene* wpt_host_animated(int variant, float t0, float t1, unsigned int width, unsigned int height)
 {
     Scene* scenePtr = new Scene;
@@ -496,6 +498,21 @@ extern "C" wpt_host_scene* wpt_host_animated(int variant, float t0, float t1, un
         scene.take(new MeshInstance(scene.take(generateCube(Transformation(), 2)), metal, cubeMotion->at(0.3f)));
         scene.take(new MeshInstance(scene.take(generateQuad(Transformation(), 3)), panel, panelMotion->at(0.3f)));
         scene.take(new MeshInstance(scene.take(generateQuad()), light, lightMotion->at(0.3f)), HotSpot);
+    }
+    if (variant & 8) {
+        Texture* marbleTex = scene.take(new TextureChecker(vec3(0.1f, 0.5f, 0.2f), vec3(0.9f), 8, 4));
+        Material* marble = scene.take(new MaterialLambertian(vec3(0.8f), marbleTex));
+        Material* glow = scene.take(new LightDiffuse(vec3(6.0f, 5.0f, 3.0f)));
+        AnimationKeyframes* roll = new AnimationKeyframes;
+        for (int k = 0; k <= 4; k++) /* rolls along +x: the rotation matches the distance travelled */
+            roll->addKeyframe(0.25f * k, Transformation(vec3(-0.9f + 0.3f * k, 0.15f, 0.9f), toQuat(radians(-115.0f * k), vec3(0.0f, 0.0f, 1.0f)), vec3(0.15f)));
+        AnimationKeyframes* bounce = new AnimationKeyframes(0.0f, Transformation(vec3(0.2f, 0.2f, 1.0f), quat::null(), vec3(0.2f)),
+                1.0f, Transformation(vec3(0.35f, 0.6f, 0.8f), toQuat(radians(40.0f), vec3(1.0f, 0.0f, 0.0f)), vec3(0.16f, 0.22f, 0.16f)));
+        AnimationKeyframes* drift = new AnimationKeyframes(0.0f, Transformation(vec3(-0.8f, 1.2f, 0.3f), quat::null(), vec3(0.08f)),
+                1.0f, Transformation(vec3(-0.5f, 1.0f, 0.6f), quat::null(), vec3(0.1f)));
+        scene.take(new Sphere(marble, scene.take(roll)));
+        scene.take(new Sphere(glass, scene.take(bounce)));
+        scene.take(new Sphere(glow, scene.take(drift)), HotSpot);
     }
     AnimationKeyframes* cameraMotion = new AnimationKeyframes;
     const vec3 up(0.0f, 1.0f, 0.0f);
