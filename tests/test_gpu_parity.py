@@ -731,3 +731,49 @@ def test_measured_brdf_under_an_exposure_interval(dev, oracle):
     assert bits_equal(got2, ref)
     still, _ = ds.render(3)
     assert not bits_equal(still, ref)
+
+
+def test_full_size_config_4_rows_bit_exact(dev, oracle):
+    """BASELINE config 4 stand-in at its full size (10 M triangles, 71 tree levels, 1920 x 1080 x 121 spp; every
+    material two-sided, constant environment): two bands of eight rows of the frame against the CPU restatement,
+    bit for bit, with the work counters of those bands."""
+    w, h, s = 1920, 1080, 11
+    sc = host.courtyard_like(w, h)
+    assert sc.d.tri_count > 9_900_000 and sc.bvh_levels >= 60
+    ds = dev.DeviceScene(sc)
+    for row in (96, 808):
+        block = (row * w, 8 * w)
+        ref, rc = oracle.render(sc, s, block=block)
+        got, gc = ds.render(s, block=block, with_counters=True)
+        assert bits_equal(got[row:row + 8], ref[row:row + 8]) and gc == rc, "rows from %d" % row
+        assert not got[:row].any() and not got[row + 8:].any()      # nothing outside the block is written
+        got2, _ = ds.render(s, block=block)
+        assert bits_equal(got2, got)
+
+
+def test_full_size_config_5_rows_bit_exact(dev, oracle):
+    """BASELINE config 5 stand-in at its full size (measured BRDFs from tensor files with 32 x 32 warps and a 64 x 64
+    NDF, as bench.py makes them; 3840 x 2160 x 529 spp, environment importance sampling with N = 512): two rows of
+    the frame against the CPU restatement, bit for bit."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_rgl_fixture", os.path.join(root, "tests", "golden", "make_rgl_fixture.py"))
+    fx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fx)
+    import tempfile
+    d = tempfile.mkdtemp(prefix="wpt_rgl_")
+    f0, f1 = os.path.join(d, "iso.bsdf"), os.path.join(d, "aniso.bsdf")
+    fx.make(f0, 21, 1, 8, 32, 64, 1)
+    fx.make(f1, 22, 8, 8, 32, 64, 1)
+    w, h, s = 3840, 2160, 23
+    sc = host.measured_like(w, h, f0, f1, seed=3)
+    sc.set_envmap_tables(*oracle.envmap_tables(sc))
+    ds = dev.DeviceScene(sc)
+    for row in (700, 1500):
+        block = (row * w, w)
+        ref, rc = oracle.render(sc, s, block=block)
+        got, gc = ds.render(s, block=block, with_counters=True)
+        assert bits_equal(got[row], ref[row]) and gc == rc, "row %d" % row
+        got2, _ = ds.render(s, block=block)
+        assert bits_equal(got2[row], ref[row])
