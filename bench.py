@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--streams", type=int, default=8, help="concurrent block launches per GPU when N > 1")
     ap.add_argument("--force-blocks", type=int, default=0, metavar="RANKS",
                     help="N = 1 only (rehearsal): run the N > 1 code path -- block queue, worker threads, streams -- as if RANKS ranks shared the frame; this process renders every block")
+    ap.add_argument("--dynamic-blocks", action="store_true",
+                    help="N > 1: hand blocks out from a shared counter as MPICoordinator does (default: block i to rank i mod N)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant / scheduler tuning word for wpt_set_launch_config (experiments)")
     args = ap.parse_args()
 
@@ -200,7 +202,10 @@ def main():
             return
         frame.zero_()
         torch.cuda.synchronize()
-        queue = blocks.BlockQueue(pixels, block_size, store, "wpt_block_counter_%d" % index)
+        if args.dynamic_blocks or world == 1:
+            queue = blocks.BlockQueue(pixels, block_size, store, "wpt_block_counter_%d" % index)
+        else:
+            queue = blocks.InterleavedBlocks(pixels, block_size, rank, world)
 
         def render_block(worker, start, size):
             stream = streams[worker]
@@ -242,6 +247,11 @@ def main():
         avg_ms = sum(m for m, _ in launches) / max(1, len(launches))
         avg_samples = sum(s for _, s in launches) / max(1, len(launches))
         achieved = bps * avg_samples / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        basis = "algorithmic bytes of one launch / its duration (HIP events on the launch's stream)"
+        if sharded and launches:
+            # this rank's launches overlap on its streams: price its whole share against the timed region instead
+            achieved = bps * sum(s for _, s in launches) / elapsed / 1e9
+            basis = "algorithmic bytes of rank 0's %d overlapping launches / the timed region" % len(launches)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and world == 1:
@@ -258,9 +268,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": name, "width": width, "height": height, "spp": spp,
                        "triangles": int(scene.d.tri_count), "bvh_nodes": int(scene.d.node_count),
-                       "parallelism": "1 launch" if world == 1 else "pixel blocks of %d over %d GPUs (%d streams each) + RCCL reduce" % (block_size, world, args.streams)},
+                       "parallelism": "1 launch" if world == 1 else "pixel blocks of %d, %s, over %d GPUs (%d streams each) + RCCL reduce" % (
+                           block_size, "shared counter" if args.dynamic_blocks else "block i to rank i mod N", world, args.streams)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis,
                          "kernel": device.lib().wpt_kernel_name().decode(), "avg_launch_ms": avg_ms,
                          "launches": len(launches), "bytes_per_sample": bps,
                          "per_sample": {k: cnt[k] / float(cnt["samples"]) for k in ("rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")},

@@ -9,6 +9,7 @@ import sys
 import tempfile
 
 import numpy as np
+import pytest
 
 from wurblpt_amd import blocks, host
 
@@ -28,7 +29,7 @@ orc = oracle_loader.load("portable")
 frame = torch.zeros((H, W, 3), dtype=torch.float32)
 store = dist.distributed_c10d._get_default_store()
 bs = blocks.plan_block_size(W * H, W, world, 2, min_block=96)
-queue = blocks.BlockQueue(W * H, bs, store, "q0")
+queue = blocks.BlockQueue(W * H, bs, store, "q0") if sys.argv[2] == "counter" else blocks.InterleavedBlocks(W * H, bs, rank, world)
 def render_block(worker, start, size):
     part, _ = orc.render(sc, S, block=(start, size), threads=1)
     flat = frame.view(-1, 3)
@@ -75,14 +76,33 @@ def test_block_queue_covers_the_frame_exactly_once():
     assert (seen == 1).all() and q.get_block() is None
 
 
-def test_two_ranks_gloo_match_single_process(oracle):
+def test_interleaved_blocks_cover_the_frame_exactly_once():
+    seen = np.zeros(1000, np.int32)
+    per_rank = []
+    for rank in range(3):
+        q = blocks.InterleavedBlocks(1000, 96, rank, 3)
+        mine = []
+        while True:
+            b = q.get_block()
+            if b is None:
+                break
+            seen[b[0]:b[0] + b[1]] += 1
+            mine.append(b[0] // 96)
+        per_rank.append(mine)
+        assert q.get_block() is None
+    assert (seen == 1).all()
+    assert per_rank == [[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8]]      # a rank's blocks are spread over the picture
+
+
+@pytest.mark.parametrize("mode", ["counter", "interleaved"])
+def test_two_ranks_gloo_match_single_process(oracle, mode):
     with tempfile.TemporaryDirectory() as d:
         script = os.path.join(d, "worker.py")
         open(script, "w").write(WORKER % {"root": ROOT})
         out = os.path.join(d, "frame.npy")
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, out]
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, out, mode]
         subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
         got = np.load(out)
         counts = np.load(out + ".counts.npy")
