@@ -202,6 +202,20 @@ def main():
             return
         frame.zero_()
         torch.cuda.synchronize()
+        if world > 1 and not args.dynamic_blocks:
+            # this rank's interleaved share (band i to rank i mod N) in one launch
+            band_rows = max(1, block_size // width)
+            bands = -(-height // band_rows)
+            mine = sum(min(band_rows, height - b * band_rows) for b in range(rank, bands, world)) * width
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main_stream)
+            dscene.render_bands_into(frame, ssqrt, band_rows, rank, world, params, None, main_stream)
+            e1.record(main_stream)
+            torch.cuda.synchronize()
+            if timed:
+                kernel_ms.append((e0, e1, mine * spp))
+            blocks.reduce_frame(frame, dst=0)
+            return
         if args.dynamic_blocks or world == 1:
             queue = blocks.BlockQueue(pixels, block_size, store, "wpt_block_counter_%d" % index)
         else:
@@ -248,7 +262,7 @@ def main():
         avg_samples = sum(s for _, s in launches) / max(1, len(launches))
         achieved = bps * avg_samples / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         basis = "algorithmic bytes of one launch / its duration (HIP events on the launch's stream)"
-        if sharded and launches:
+        if sharded and launches and (args.dynamic_blocks or world == 1):
             # this rank's launches overlap on its streams: price its whole share against the timed region instead
             achieved = bps * sum(s for _, s in launches) / elapsed / 1e9
             basis = "algorithmic bytes of rank 0's %d overlapping launches / the timed region" % len(launches)
@@ -268,8 +282,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": name, "width": width, "height": height, "spp": spp,
                        "triangles": int(scene.d.tri_count), "bvh_nodes": int(scene.d.node_count),
-                       "parallelism": "1 launch" if world == 1 else "pixel blocks of %d, %s, over %d GPUs (%d streams each) + RCCL reduce" % (
-                           block_size, "shared counter" if args.dynamic_blocks else "block i to rank i mod N", world, args.streams)},
+                       "parallelism": "1 launch" if world == 1 else (
+                           "pixel blocks of %d from a shared counter over %d GPUs (%d streams each) + RCCL reduce" % (block_size, world, args.streams)
+                           if args.dynamic_blocks else
+                           "bands of %d rows, band i to rank i mod %d, one launch per GPU + RCCL reduce" % (max(1, block_size // width), world))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis,
                          "kernel": device.lib().wpt_kernel_name().decode(), "avg_launch_ms": avg_ms,

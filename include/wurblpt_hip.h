@@ -337,6 +337,15 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera,
         uint32_t block_start, uint32_t block_size,
         float* frame_device, wpt_counters* counters_device, void* hip_stream);
 
+/* One rank's interleaved share of the frame in ONE launch: the frame is cut into bands of `band_rows` rows and this
+ * call renders bands first_band, first_band + band_stride, first_band + 2 band_stride, ... (rank r of N: first_band = r,
+ * band_stride = N).  Same results as rendering those bands as blocks; a GPU keeps all of the rank's pixels resident
+ * without one stream per block.  band_rows a multiple of 8 (and width too) keeps the 8x8 pixel tiles per wave. */
+wpt_status wpt_render_bands_device(wpt_scene* scene, const wpt_camera* camera,
+        const wpt_params* params, uint32_t width, uint32_t height, uint32_t samples_sqrt,
+        uint32_t band_rows, uint32_t first_band, uint32_t band_stride,
+        float* frame_device, wpt_counters* counters_device, void* hip_stream);
+
 /* Synchronous form with MPICoordinator::submitBlock semantics (mpi.hpp:256-262):
  * writes block_size*3 floats for the block's pixels to host memory `block_rgb`. */
 wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera,

@@ -777,3 +777,31 @@ def test_full_size_config_5_rows_bit_exact(dev, oracle):
         assert bits_equal(got[row], ref[row]) and gc == rc, "row %d" % row
         got2, _ = ds.render(s, block=block)
         assert bits_equal(got2[row], ref[row])
+
+
+@pytest.mark.parametrize("w,h,band_rows,stride", [(64, 64, 16, 2), (64, 64, 8, 3), (96, 50, 8, 4), (50, 37, 5, 3), (64, 64, 64, 8)])
+def test_interleaved_bands_in_one_launch(dev, oracle, w, h, band_rows, stride):
+    """wpt_render_bands_device: a rank's share of the frame (band i to rank i mod N) in one launch.  Every rank's launch
+    writes exactly its bands with the values of the full frame; together the ranks cover the frame once.  Tiled and
+    untiled lane mappings, a last band that is shorter, more ranks than bands."""
+    import torch
+    sc = host.cornell(w, h, 1, 2)
+    ref, _ = oracle.render(sc, 3)
+    ds = dev.DeviceScene(sc)
+    total = np.zeros_like(ref)
+    covered = np.zeros((h, w), np.int32)
+    for rank in range(stride):
+        frame = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+        ds.render_bands_into(frame, 3, band_rows, rank, stride, stream=torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        ds.check()
+        got = frame.cpu().numpy()
+        mine = np.zeros(h, bool)
+        for band in range(rank, -(-h // band_rows), stride):
+            mine[band * band_rows:(band + 1) * band_rows] = True
+        assert bits_equal(got[mine], ref[mine]) and not got[~mine].any(), rank
+        covered[mine] += 1
+        total += got
+    assert (covered == 1).all() and bits_equal(total, ref)
+    with pytest.raises(RuntimeError):
+        ds.render_bands_into(torch.zeros((h, w, 3), dtype=torch.float32, device="cuda"), 3, band_rows, stride, stride)

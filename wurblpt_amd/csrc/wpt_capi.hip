@@ -628,19 +628,26 @@ wpt_status wpt_scene_get_envmap_tables(const wpt_scene* scene, float* M, int32_t
     return WPT_OK;
 }
 
-wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, const wpt_params* params,
+/* one launch: a block of consecutive pixels (band_stride == 0) or interleaved bands of band_pixels pixels */
+static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const wpt_params* params,
         uint32_t width, uint32_t height, uint32_t samples_sqrt, uint32_t block_start, uint32_t block_size,
+        uint32_t band_pixels, uint32_t band_first, uint32_t band_stride,
         float* frame_device, wpt_counters* counters_device, void* hip_stream)
 {
     if (!scene || !camera || !params || !frame_device)
         return fail(WPT_ERR_INVALID_ARGUMENT, "NULL argument");
     if (width == 0 || height == 0 || samples_sqrt == 0 || samples_sqrt > 65535)
         return fail(WPT_ERR_INVALID_ARGUMENT, "width, height and samples_sqrt must be positive");
-    if (uint64_t(width) * height > 0xffffffffull || uint64_t(block_start) + block_size > uint64_t(width) * height)
+    if (uint64_t(width) * height > 0xffffffffull || uint64_t(block_start) + (band_stride ? 0u : block_size) > uint64_t(width) * height)
         return fail(WPT_ERR_INVALID_ARGUMENT, "pixel block lies outside the frame");
     if (block_size == 0)
         return WPT_OK;
+    if (band_stride && (g_variant & 0x50u))
+        return fail(WPT_ERR_UNSUPPORTED, "interleaved bands are rendered by the product kernel only");
     KernelArgs args;
+    args.bandPixels = band_pixels;
+    args.bandFirst = band_first;
+    args.bandStride = band_stride;
     args.sv = scene->view;
     args.cam = *camera;
     args.par = *params;
@@ -657,7 +664,8 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     args.fuse = (g_variant & 0x20u) ? 0u : 1u; /* variant bit 0x20: separate SHADE / NEE-END / NEW rounds (the older scheduler) */
 
     /* a wave covers an 8x8 pixel tile when the block consists of whole groups of 8 rows */
-    args.tiled = (width % 8 == 0 && block_start % width == 0 && block_size % (8 * width) == 0) ? 1u : 0u;
+    args.tiled = (width % 8 == 0 && block_start % width == 0 && block_size % (8 * width) == 0
+            && (band_stride == 0 || band_pixels % (8 * width) == 0)) ? 1u : 0u;
     uint32_t need = scene->features | ((camera->lens_radius > 0.0f || camera->distortion_type != WPT_DISTORTION_NONE
                 || camera->surround_mode != WPT_SURROUND_OFF || camera->stereoscopic_distance > 0.0f) ? FEAT_LENS : 0u);
     if (camera->surround_mode > WPT_SURROUND_360)
@@ -796,6 +804,29 @@ wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, c
     }
     HIP_TRY(hipGetLastError());
     return WPT_OK;
+}
+
+wpt_status wpt_render_block_device(wpt_scene* scene, const wpt_camera* camera, const wpt_params* params,
+        uint32_t width, uint32_t height, uint32_t samples_sqrt, uint32_t block_start, uint32_t block_size,
+        float* frame_device, wpt_counters* counters_device, void* hip_stream)
+{
+    return renderLaunch(scene, camera, params, width, height, samples_sqrt, block_start, block_size, 0, 0, 0, frame_device, counters_device,
+            hip_stream);
+}
+
+wpt_status wpt_render_bands_device(wpt_scene* scene, const wpt_camera* camera, const wpt_params* params,
+        uint32_t width, uint32_t height, uint32_t samples_sqrt, uint32_t band_rows, uint32_t first_band, uint32_t band_stride,
+        float* frame_device, wpt_counters* counters_device, void* hip_stream)
+{
+    if (band_rows == 0 || band_stride == 0 || first_band >= band_stride || width == 0 || height == 0)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "bands need band_rows > 0 and first_band < band_stride");
+    const uint64_t bandPixels = uint64_t(band_rows) * width;
+    const uint64_t bands = (uint64_t(height) + band_rows - 1) / band_rows;
+    const uint64_t mine = first_band < bands ? (bands - first_band + band_stride - 1) / band_stride : 0;
+    if (bandPixels > 0xffffffffull || mine * bandPixels > 0xffffffffull)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "bands too large");
+    return renderLaunch(scene, camera, params, width, height, samples_sqrt, 0, uint32_t(mine * bandPixels), uint32_t(bandPixels), first_band,
+            band_stride, frame_device, counters_device, hip_stream);
 }
 
 wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera, const wpt_params* params, uint32_t width,

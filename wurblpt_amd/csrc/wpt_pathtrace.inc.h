@@ -58,6 +58,10 @@ struct KernelArgs {
     uint32_t width, height, samplesSqrt;
     uint32_t blockStart, blockSize;
     uint32_t tiled; /* 1: a wave covers an 8x8 pixel tile (block is whole rows, multiple of 8) */
+    /* bands (product kernel only): with bandStride > 0 the launch covers the bands of bandPixels consecutive pixels
+     * whose index is bandFirst, bandFirst + bandStride, ... -- one rank's interleaved share of the frame in one launch;
+     * blockStart is 0 and blockSize the number of lanes (pixels behind the end of the frame stay idle) */
+    uint32_t bandPixels, bandFirst, bandStride;
     uint32_t leaveEighths; /* scheduler: leave the NODE loop when fewer than this many eighths of the entering lanes remain */
     uint32_t heavyMin;     /* scheduler: lanes a long block needs before it runs */
     uint32_t leafBias;     /* scheduler: leaf tests run when waiting lanes * leafBias >= walking lanes * 8 */
@@ -110,16 +114,26 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 
     /* lane -> pixel */
     const uint32_t gid = blockIdx.x * WG + threadIdx.x;
-    const bool inBlock = gid < args.blockSize;
+    bool inBlock = gid < args.blockSize;
     uint32_t pixel;
     if (args.tiled) {
         const uint32_t tilesPerRow = args.width >> 3;
         const uint32_t tile = gid >> 6, lane = gid & 63u;
-        const uint32_t tx = tile % tilesPerRow, ty = tile / tilesPerRow;
+        const uint32_t tx = tile % tilesPerRow;
+        uint32_t ty = tile / tilesPerRow;
+        if (args.bandStride) {
+            /* tile rows of this launch -> tile rows of the frame (bands are whole groups of 8 rows here) */
+            const uint32_t tileRowsPerBand = args.bandPixels / (args.width << 3);
+            ty = (args.bandFirst + (ty / tileRowsPerBand) * args.bandStride) * tileRowsPerBand + ty % tileRowsPerBand;
+        }
         pixel = args.blockStart + ((ty << 3) + (lane >> 3)) * args.width + (tx << 3) + (lane & 7u);
+    } else if (args.bandStride) {
+        pixel = (args.bandFirst + (gid / args.bandPixels) * args.bandStride) * args.bandPixels + gid % args.bandPixels;
     } else {
         pixel = args.blockStart + gid;
     }
+    if (args.bandStride && pixel >= args.width * args.height)
+        inBlock = false; /* the last band may be shorter */
     if (!inBlock)
         pixel = args.blockStart;
     const uint32_t samples = args.samplesSqrt * args.samplesSqrt;

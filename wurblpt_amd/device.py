@@ -17,7 +17,7 @@ def lib_path():
 
 EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_scene_upload", "wpt_scene_free", "wpt_scene_check",
            "wpt_postproc_to_srgb", "wpt_postproc_max_luminance", "wpt_postproc_uniform_rational_quantization",
-           "wpt_postproc_scale_luminance", "wpt_postproc_host", "wpt_ground_truth_device", "wpt_ground_truth",
+           "wpt_postproc_scale_luminance", "wpt_postproc_host", "wpt_ground_truth_device", "wpt_ground_truth", "wpt_render_bands_device",
            "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_kernel_name",
            "wpt_last_error"]
 
@@ -95,6 +95,23 @@ class DeviceScene:
         cptr = C.c_void_p(counters.data_ptr()) if counters is not None else None
         _check(lib().wpt_render_block_device(self._handle, self.host.camera, C.byref(p), w, h, samples_sqrt,
                                               start, size, C.c_void_p(frame.data_ptr()), cptr, sptr))
+
+    def render_bands_into(self, frame, samples_sqrt, band_rows, first_band, band_stride, params=None, counters=None, stream=None,
+                          width=None, height=None):
+        """Asynchronously renders bands first_band, first_band + band_stride, ... of `band_rows` rows each into `frame`
+        (one launch: a rank's interleaved share of the frame)."""
+        from . import host
+        w = width or self.host.width
+        h = height or self.host.height
+        assert frame.is_cuda and frame.is_contiguous() and frame.numel() == w * h * 3
+        p = params if params is not None else host.default_params()
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        cptr = C.c_void_p(counters.data_ptr()) if counters is not None else None
+        L = lib()
+        L.wpt_render_bands_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.wpt_render_bands_device(self._handle, C.cast(self.host.camera, C.c_void_p), C.addressof(p), w, h, samples_sqrt,
+                                         band_rows, first_band, band_stride, C.c_void_p(frame.data_ptr()), cptr, sptr))
 
     def render(self, samples_sqrt, block=None, params=None, with_counters=False, width=None, height=None):
         """Synchronous convenience: returns (frame as numpy [h, w, 3], counters dict or None)."""
