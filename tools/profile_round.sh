@@ -1,8 +1,11 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/profile_round.sh <tag>
-# kernel-trace statistics of the default bench command, then PMC passes (each its own run)
+# usage (on the GPU box): bash tools/profile_round.sh <tag> [1|2]
+# kernel-trace statistics of the default bench command, then PMC passes (each its own run);
+# part 1 = Cornell + Sponza-class, part 2 = the 10 M triangle scene (default: both)
 export TMPDIR=/tmp
 TAG=$1
+PART=${2:-12}
+if [[ $PART == *1* ]]; then
 S="--workload sponza_like_1920x1080_256spp_envmap_is --steps 2 --warmup 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_${TAG}_cornell -o stats --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/stats_${TAG}_cornell.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_${TAG}_sponza -o stats --output-format csv -- python3 bench.py $S --no-cpu-baseline > gpurun_out/stats_${TAG}_sponza.log 2>&1 || exit 1
@@ -13,6 +16,8 @@ done
 bash tools/pmc_mem.sh ${TAG}s $S || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_${TAG}s_WRITE_SIZE -o pmc --output-format csv -- python3 bench.py $S --no-cpu-baseline > gpurun_out/pmc_${TAG}s_WRITE_SIZE.log 2>&1 || exit 1
 echo done cornell+sponza
+fi
+if [[ $PART == *2* ]]; then
 Y="--workload courtyard_like_10M_1920x1080_121spp --steps 1 --warmup 1"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_${TAG}_courtyard -o stats --output-format csv -- python3 bench.py $Y --no-cpu-baseline > gpurun_out/stats_${TAG}_courtyard.log 2>&1 || exit 1
 for P in "FETCH_SIZE" "WRITE_SIZE" "VALUBusy VALUUtilization" "TCC_HIT_sum TCC_MISS_sum"; do
@@ -20,3 +25,4 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "VALUBusy VALUUtilization" "TCC_HIT_sum TCC_M
   timeout -k 10 500 rocprofv3 --pmc $P --kernel-trace -d gpurun_out/pmc_${TAG}y_$N -o pmc --output-format csv -- python3 bench.py $Y --no-cpu-baseline > gpurun_out/pmc_${TAG}y_$N.log 2>&1 || exit 1
 done
 echo done courtyard
+fi
