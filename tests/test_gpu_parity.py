@@ -310,7 +310,7 @@ def test_furnace_scenes_bit_exact(dev, oracle, material):
         assert float(np.median(got[18:30, 18:30])) == pytest.approx(0.42, rel=1e-6)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_sphere_scenes_bit_exact(dev, oracle, variant):
     """Analytic spheres (HitableSphere::hit / pdfValue / direction, pinned to the reference's own
     code by tests/test_oracle_golden.py): mixed sphere + triangle hot spots, textured sphere with a
@@ -320,8 +320,14 @@ def test_sphere_scenes_bit_exact(dev, oracle, variant):
     p = host.default_params()
     if variant == 2:
         p.randomize_ray_over_pixel = 0
+    if variant == 4:    # importance sampled cube map: the device builds the tables at upload, the oracle gets its own
+        assert sc.d.envmap.N == 24
+        tables = oracle.envmap_tables(sc)
+        ds = dev.DeviceScene(sc)
+        sc.set_envmap_tables(*tables)
+    else:
+        ds = dev.DeviceScene(sc)
     ref, rc = oracle.render(sc, 4, p)
-    ds = dev.DeviceScene(sc)
     got, gc = ds.render(4, params=p, with_counters=True)
     assert np.isfinite(got).all() and got.sum() > 0
     nbad = int((got.view(np.uint32) != ref.view(np.uint32)).sum())

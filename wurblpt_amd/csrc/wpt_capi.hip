@@ -343,8 +343,6 @@ wpt_status validate(const wpt_scene_desc* d)
         for (int k = 0; k < 6; k++)
             if (d->envmap.cube_tex[k] < 0 || uint32_t(d->envmap.cube_tex[k]) >= d->texture_count)
                 return fail(WPT_ERR_INVALID_ARGUMENT, "environment cube map references a texture outside the array");
-        if (d->envmap.N > 0)
-            return fail(WPT_ERR_UNSUPPORTED, "importance sampling of a cube environment map is not built");
     }
     return WPT_OK;
 }

@@ -531,7 +531,8 @@ extern "C" wpt_host_scene* wpt_host_animated(int variant, float t0, float t1, un
  * variant 1  the same objects without lights under a cube environment map (envmap.hpp:250-285)
  * variant 2  wurblpt-furnace-test.cpp as written: analytic sphere, Lambertian 0.42, constant
  *            equirect environment -- every pixel on the sphere is exactly 0.42
- * variant 3  camera inside a large emitting sphere that is a hot spot (pdfValue's inside branch) */
+ * variant 3  camera inside a large emitting sphere that is a hot spot (pdfValue's inside branch)
+ * variant 4  variant 1 with importance sampling of the cube map (next-event estimation towards it) */
 extern "C" wpt_host_scene* wpt_host_spheres(int variant, unsigned int width, unsigned int height)
 {
     Scene* scenePtr = new Scene;
@@ -560,12 +561,14 @@ extern "C" wpt_host_scene* wpt_host_spheres(int variant, unsigned int width, uns
         scene.take(new Sphere(vec3(0.0f, 4.0f, 0.5f), 0.4f, light), HotSpot);
         Material* light2 = scene.take(new LightDiffuse(vec3(2.0f, 3.0f, 5.0f)));
         scene.take(new MeshInstance(scene.take(generateQuad(Transformation(vec3(-4.0f, 2.0f, -2.0f), toQuat(radians(60.0f), vec3(0.0f, 1.0f, 0.0f)), vec3(0.8f, 0.8f, 1.0f)), 1)), light2), HotSpot);
-    } else if (variant == 1) {
+    } else if (variant == 1 || variant == 4) {
         Texture* side[6] = {
             scene.take(new TextureConstant(vec4(0.9f, 0.3f, 0.2f, 0.5f))), scene.take(new TextureConstant(vec4(0.2f, 0.8f, 0.3f, 0.4f))),
             scene.take(new TextureChecker(vec3(1.5f, 1.5f, 2.0f), vec3(0.4f, 0.5f, 0.9f), 6, 6)), scene.take(new TextureConstant(vec4(0.15f, 0.12f, 0.1f, 0.1f))),
             scene.take(new TextureChecker(vec3(0.9f, 0.9f, 0.2f), vec3(0.2f, 0.2f, 0.9f), 3, 5)), scene.take(new TextureConstant(vec4(0.6f, 0.6f, 0.6f, 0.6f))) };
-        scene.take(new EnvironmentMapCube(side[0], side[1], side[2], side[3], side[4], side[5]));
+        EnvironmentMap* env = scene.take(new EnvironmentMapCube(side[0], side[1], side[2], side[3], side[4], side[5]));
+        if (variant == 4) /* importance sampled: the importance maps are independent of the parameterisation (envmap.hpp:40-42) */
+            env->initializeImportanceSampling(24);
     } else {
         Material* glow = scene.take(new LightDiffuse(vec3(0.8f, 0.9f, 1.0f)));
         Material* glowTwoSided = scene.take(new MaterialTwoSided(glow, glow));
