@@ -228,6 +228,14 @@ template<typename T, int C, int R> struct matrix {
             for (int r = 0; r < 4; r++)
                 values[c * 4 + r] *= s[c];
     }
+    /* post-multiplies a translation: the last column moves along the first three (reference gvm.hpp:1571-1577) */
+    void translate(const vector<T, 3>& t) requires(C == 4 && R == 4)
+    {
+        for (int r = 0; r < 4; r++)
+            values[12 + r] = dot(vector<T, 3>(values[r], values[4 + r], values[8 + r]), t) + values[12 + r];
+    }
+    friend matrix translate(const matrix& m, const vector<T, 3>& v) requires(C == 4 && R == 4) { matrix M = m; M.translate(v); return M; }
+    friend matrix scale(const matrix& m, const vector<T, 3>& v) requires(C == 4 && R == 4) { matrix M = m; M.scale(v); return M; }
 };
 typedef matrix<float, 3, 3> mat3;
 typedef matrix<float, 4, 4> mat4;
@@ -346,5 +354,7 @@ template<typename T> matrix<T, 4, 4> toMat4(const quaternion<T>& q)
             m[c][r] = r3[c][r];
     return m;
 }
+
+template<typename T> matrix<T, 4, 4> rotate(const matrix<T, 4, 4>& m, const quaternion<T>& q) { return m * toMat4(q); }
 
 }

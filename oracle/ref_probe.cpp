@@ -966,6 +966,45 @@ int main(int argc, char* argv[])
         floats("obj_material_floats", matFloats);  /* per material: Kd Ks Ke Tf (3 each) Ns d Ni, then per texture scale(3) offset(3) bm */
     }
 
+    /* ---- the transformations of the reference's own tests/test-transformation.cpp: translate / rotate / scale in every
+     * order and two products of three; each as Transformation (10 floats), its toMat4() (16) and the same chain made
+     * with mat4 operations (16), which that test asserts to agree within 1e-4 ---- */
+    {
+        auto chain = [](int order, Transformation& T, mat4& M, const vec3& tr, const quat& q, const vec3& sc) {
+            for (int step = 0; step < 3; step++) {
+                const int what = (order >> (2 * step)) & 3; /* 0 translate, 1 rotate, 2 scale */
+                if (what == 0) { T = translate(T, tr); M = translate(M, tr); }
+                else if (what == 1) { T = rotate(T, q); M = rotate(M, q); }
+                else { T = scale(T, sc); M = scale(M, sc); }
+            }
+        };
+        Transformation T[8];
+        mat4 M[8];
+        for (int i = 0; i < 8; i++)
+            M[i] = mat4(1.0f);
+        const quat q27 = toQuat(radians(27.0f), vec3(1.0f, 0.0f, 0.0f));
+        chain(0 | (1 << 2) | (2 << 4), T[0], M[0], vec3(1, 2, 3), toQuat(radians(15.0f), vec3(1.0f, 1.0f, 0.0f)), vec3(0.5f));
+        chain(2 | (1 << 2) | (0 << 4), T[1], M[1], vec3(3, 2, 1), q27, vec3(0.4f));
+        chain(0 | (2 << 2) | (1 << 4), T[2], M[2], vec3(3, 2, 1), q27, vec3(0.4f));
+        chain(1 | (0 << 2) | (2 << 4), T[3], M[3], vec3(3, 2, 1), q27, vec3(0.4f));
+        chain(1 | (2 << 2) | (0 << 4), T[4], M[4], vec3(3, 2, 1), q27, vec3(0.4f));
+        chain(2 | (0 << 2) | (1 << 4), T[5], M[5], vec3(3, 2, 1), q27, vec3(0.4f));
+        T[6] = T[0] * T[1] * T[2];
+        M[6] = M[0] * M[1] * M[2];
+        T[7] = T[2] * T[1] * T[0];
+        M[7] = M[2] * M[1] * M[0];
+        std::vector<float> res;
+        for (int i = 0; i < 8; i++) {
+            push3(res, T[i].translation);
+            res.push_back(T[i].rotation.x); res.push_back(T[i].rotation.y); res.push_back(T[i].rotation.z); res.push_back(T[i].rotation.w);
+            push3(res, T[i].scaling);
+            mat4 TM = T[i].toMat4();
+            for (int k = 0; k < 16; k++) res.push_back(TM.values[k]);
+            for (int k = 0; k < 16; k++) res.push_back(M[i].values[k]);
+        }
+        floats("transformation_chains", res);
+    }
+
     /* ---- AnimationKeyframes::at, Transformation::toMat4 / toNormalMatrix / operator* (animation_keyframes.hpp:186-214,
      * transformation.hpp:80-83,105-122,199-205, quaternion slerp gvm.hpp:1765-1797) ---- */
     {

@@ -340,6 +340,48 @@ void wpt_host_default_params(wpt_params* p)
 
 /* ---- building blocks, exposed for parity tests against the reference's golden vectors ---- */
 
+/* The transformations of the reference's tests/test-transformation.cpp made with include/wurblpt/transformation.hpp
+ * and gvm.hpp: per chain the Transformation (10 floats), its toMat4() (16) and the same chain in mat4 operations (16) */
+void wpt_host_transformation_chains(float* out)
+{
+    auto chain = [](int order, Transformation& T, mat4& M, const vec3& tr, const quat& q, const vec3& sc) {
+        for (int step = 0; step < 3; step++) {
+            const int what = (order >> (2 * step)) & 3; /* 0 translate, 1 rotate, 2 scale */
+            if (what == 0) { T = translate(T, tr); M = translate(M, tr); }
+            else if (what == 1) { T = rotate(T, q); M = rotate(M, q); }
+            else { T = scale(T, sc); M = scale(M, sc); }
+        }
+    };
+    Transformation T[8];
+    mat4 M[8];
+    for (int i = 0; i < 8; i++)
+        M[i] = mat4(1.0f);
+    const quat q27 = toQuat(radians(27.0f), vec3(1.0f, 0.0f, 0.0f));
+    chain(0 | (1 << 2) | (2 << 4), T[0], M[0], vec3(1, 2, 3), toQuat(radians(15.0f), vec3(1.0f, 1.0f, 0.0f)), vec3(0.5f));
+    chain(2 | (1 << 2) | (0 << 4), T[1], M[1], vec3(3, 2, 1), q27, vec3(0.4f));
+    chain(0 | (2 << 2) | (1 << 4), T[2], M[2], vec3(3, 2, 1), q27, vec3(0.4f));
+    chain(1 | (0 << 2) | (2 << 4), T[3], M[3], vec3(3, 2, 1), q27, vec3(0.4f));
+    chain(1 | (2 << 2) | (0 << 4), T[4], M[4], vec3(3, 2, 1), q27, vec3(0.4f));
+    chain(2 | (0 << 2) | (1 << 4), T[5], M[5], vec3(3, 2, 1), q27, vec3(0.4f));
+    T[6] = T[0] * T[1] * T[2];
+    M[6] = M[0] * M[1] * M[2];
+    T[7] = T[2] * T[1] * T[0];
+    M[7] = M[2] * M[1] * M[0];
+    for (int i = 0; i < 8; i++) {
+        float* o = out + 42 * i;
+        for (int k = 0; k < 3; k++) {
+            o[k] = T[i].translation[k];
+            o[7 + k] = T[i].scaling[k];
+        }
+        o[3] = T[i].rotation.x; o[4] = T[i].rotation.y; o[5] = T[i].rotation.z; o[6] = T[i].rotation.w;
+        const mat4 TM = T[i].toMat4();
+        for (int k = 0; k < 16; k++) {
+            o[10 + k] = TM.values[k];
+            o[26 + k] = M[i].values[k];
+        }
+    }
+}
+
 /* AnimationKeyframes of include/wurblpt/animation.hpp from `count` key frames (11 floats each: t, translation,
  * rotation xyzw, scaling), evaluated for n cases (t, point): per case the transformation (10 floats), toMat4 (16),
  * toNormalMatrix (9), M * p, N * p, T * p -- the layout of the anim_out golden vector */
