@@ -77,7 +77,10 @@ class HostScene:
 
     def __del__(self):
         if getattr(self, "_handle", None):
-            lib().wpt_host_scene_free(self._handle)
+            try:
+                lib().wpt_host_scene_free(self._handle)
+            except TypeError:   # interpreter shutdown: the module globals are gone already
+                pass
             self._handle = None
 
     @property
