@@ -51,7 +51,34 @@ struct PathState {
     f3 srDir;
     uint32_t chosenPrim;
     float time; /* FEAT_ANIM: the path's time (Ray::time; the thread's AnimationCache is set to it, wurblpt.hpp:361) */
+    /* FEAT_ANIM: the lane's AnimationCache, one entry deep -- the matrix of the animation it used last at ps.time.
+     * Consecutive leaf tests of a walk mostly hit triangles of one instance, and the lights share few animations. */
+    int animCached;
+    float animM[16];
 };
+
+/* AnimationCache::getM(ai) at the path's time.  Spheres do not go through it: measured on the test scene, sharing the
+ * entry with them lets sphere and triangle leaves evict each other (162 -> 141 Msamples/s) and an entry of their own
+ * is evicted by the next sphere (158), so their transformation is evaluated where it is needed. */
+WPT_D wptanim::Trs animationTrs(const SceneView& sv, PathState& ps, int ai)
+{
+    return animationAt(sv, ai, ps.time);
+}
+WPT_D const float* animationMatrix(const SceneView& sv, PathState& ps, int ai)
+{
+    if (ps.animCached != ai) {
+        wptanim::toMat4(animationAt(sv, ai, ps.time), ps.animM);
+        ps.animCached = ai;
+    }
+    return ps.animM;
+}
+/* an animated sphere at the path's time, through the lane's cache: as hit() / direction() place it */
+template<uint32_t F> WPT_D wpt_sphere sphereNow(const SceneView& sv, PathState& ps, const wpt_sphere& sp)
+{
+    if ((F & FEAT_ANIM) && sp.animation >= 0)
+        return sphereMoved(sp, animationTrs(sv, ps, sp.animation));
+    return sp;
+}
 
 struct FrameArgs {
     wpt_camera cam;
@@ -78,6 +105,7 @@ WPT_D void pathStateInit(PathState& ps, uint32_t pixel, uint32_t width)
     ps.srDir = ps.ray.d;
     ps.chosenPrim = NO_HIT;
     ps.time = 0.0f;
+    ps.animCached = -1;
 }
 
 /* HitableTriangle::pdfValue (hitable_triangle.hpp:405-423) for one hot spot */
@@ -134,19 +162,24 @@ WPT_D f3 sphereDirection(const wpt_sphere& sp, f3 org, Prng& prng)
 
 /* mean pdf over all hot spots of hitting them from org along dir (wurblpt.hpp:181-184) */
 template<uint32_t F, bool COUNT, class Tri4>
-WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, float time, LaneCounters& lc)
+WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, PathState& ps, LaneCounters& lc)
 {
     const RayAux h = rayAux(dir);
     float sum = 0.0f;
     for (uint32_t i = 0; i < sv.hotspotCount; i++) {
         const uint32_t p = sv.hotspots[i].prim;
         if ((F & FEAT_SPHERES) && sv.hotspots[i].kind == WPT_HOTSPOT_SPHERE) {
-            sum += spherePdfValue(sphereForPdf<F>(sv, sv.spheres[p], time), sphereAt<F>(sv, sv.spheres[p], time), org, dir);
+            const wpt_sphere& sp = sv.spheres[p];
+            if ((F & FEAT_ANIM) && sp.animation >= 0) {
+                const wptanim::Trs T = animationTrs(sv, ps, sp.animation);
+                sum += spherePdfValue(sphereMovedForPdf(sp, T), sphereMoved(sp, T), org, dir);
+            } else {
+                sum += spherePdfValue(sp, sp, org, dir);
+            }
         } else if ((F & FEAT_ANIM) && sv.hotspots[i].animation >= 0) {
             /* the light moves: its corners at the path's time (hitable_triangle.hpp:209-218,405-423) */
             float4 g0 = tri4(3 * p), g1 = tri4(3 * p + 1), g2 = tri4(3 * p + 2);
-            float animationM[16];
-            wptanim::toMat4(animationAt(sv, sv.hotspots[i].animation, time), animationM);
+            const float* animationM = animationMatrix(sv, ps, sv.hotspots[i].animation);
             const f3 v0 = animatePoint(animationM, mk3(g0.x, g0.y, g0.z)), v1 = animatePoint(animationM, mk3(g1.x, g1.y, g1.z)),
                      v2 = animatePoint(animationM, mk3(g2.x, g2.y, g2.z));
             g0.x = v0.x; g0.y = v0.y; g0.z = v0.z;
@@ -255,6 +288,7 @@ WPT_D int blockNew(const FrameArgs& fa, PathState& ps, const SceneView* sv = nul
         /* camera.hpp:175-184: the ray draws its time in the exposure interval; a moving camera is taken at that time */
         const float t = fa.par.t0 + in01(ps.prng) * (fa.par.t1 - fa.par.t0);
         ps.time = t;
+        ps.animCached = -1; /* AnimationCache::init(r.time) */
         if (fa.cam.animation >= 0 && sv) {
             const wptanim::Trs T = animationAt(*sv, fa.cam.animation, t);
             ps.ray.o = add(ld3(T.t), quatRotate(T.q, mul(O, ld3(T.s))));
@@ -327,7 +361,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
     ps.srDir = sr.dir;
     if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
         /* light sampling with MIS (wurblpt.hpp:179-220) */
-        const float hotSpotsPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, sr.dir, ps.time, lc);
+        const float hotSpotsPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, sr.dir, ps, lc);
         ps.nextAtt = sclr(ps.nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
         section(3);
         uint32_t idx = (uint32_t)(in01(ps.prng) * (float)sv.hotspotCount);
@@ -336,7 +370,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
         f3 directDir;
         uint32_t hotSpotPrim = hs.prim;
         if ((F & FEAT_SPHERES) && hs.kind == WPT_HOTSPOT_SPHERE) {
-            directDir = sphereDirection(sphereAt<F>(sv, sv.spheres[hs.prim], ps.time), h.p, ps.prng);
+            directDir = sphereDirection(sphereNow<F>(sv, ps, sv.spheres[hs.prim]), h.p, ps.prng);
             hotSpotPrim = PRIM_SPHERE | hs.prim;
         } else {
             /* HitableTriangle::direction (hitable_triangle.hpp:425-443) */
@@ -344,15 +378,12 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
             f3 p = add(add(scl(bary.x, ld3(hs.p0)), scl(bary.y, ld3(hs.p1))), scl(bary.z, ld3(hs.p2)));
             if (hs.transform)
                 p = mat4mulPoint(hs.M, p);
-            if ((F & FEAT_ANIM) && hs.animation >= 0) {
-                float animationM[16];
-                wptanim::toMat4(animationAt(sv, hs.animation, ps.time), animationM);
-                p = animatePoint(animationM, p);
-            }
+            if ((F & FEAT_ANIM) && hs.animation >= 0)
+                p = animatePoint(animationMatrix(sv, ps, hs.animation), p);
             directDir = normalize(sub(p, h.p));
         }
         section(4);
-        const float directPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, directDir, ps.time, lc);
+        const float directPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, directDir, ps, lc);
         section(5);
         if (directPdf > 0.0f) {
             float dpdf;

@@ -513,43 +513,43 @@ WPT_D bool sphereTest(const wpt_sphere& sp, f3 org, f3 dir, float amin, float am
 
 /* An animated sphere as hit() and direction() see it at a time (hitable_sphere.hpp:118-127,196-203): the animation's
  * translation is added to the centre, its largest scaling multiplies the radius, its rotation follows the sphere's */
-template<uint32_t F> WPT_D wpt_sphere sphereAt(const SceneView& sv, const wpt_sphere& sp, float time)
+WPT_D wpt_sphere sphereMoved(const wpt_sphere& sp, const wptanim::Trs& T)
 {
     wpt_sphere r = sp;
-    if ((F & FEAT_ANIM) && sp.animation >= 0) {
-        const wptanim::Trs T = animationAt(sv, sp.animation, time);
-        float m = T.s[0];
-        if (T.s[1] > m)
-            m = T.s[1];
-        if (T.s[2] > m)
-            m = T.s[2];
-        for (int k = 0; k < 3; k++)
-            r.center[k] = sp.center[k] + T.t[k];
-        r.radius = sp.radius * m;
-        /* quaternion product sp.rotation * T.rotation (gvm.hpp:1687-1695) */
-        const float x = sp.rotation[0], y = sp.rotation[1], z = sp.rotation[2], w = sp.rotation[3];
-        const float qx = T.q[0], qy = T.q[1], qz = T.q[2], qw = T.q[3];
-        r.rotation[0] = w * qx + x * qw + y * qz - z * qy;
-        r.rotation[1] = w * qy + y * qw + z * qx - x * qz;
-        r.rotation[2] = w * qz + z * qw + x * qy - y * qx;
-        r.rotation[3] = w * qw - x * qx - y * qy - z * qz;
-    }
+    float m = T.s[0];
+    if (T.s[1] > m)
+        m = T.s[1];
+    if (T.s[2] > m)
+        m = T.s[2];
+    for (int k = 0; k < 3; k++)
+        r.center[k] = sp.center[k] + T.t[k];
+    r.radius = sp.radius * m;
+    /* quaternion product sp.rotation * T.rotation (gvm.hpp:1687-1695) */
+    const float x = sp.rotation[0], y = sp.rotation[1], z = sp.rotation[2], w = sp.rotation[3];
+    const float qx = T.q[0], qy = T.q[1], qz = T.q[2], qw = T.q[3];
+    r.rotation[0] = w * qx + x * qw + y * qz - z * qy;
+    r.rotation[1] = w * qy + y * qw + z * qx - x * qz;
+    r.rotation[2] = w * qz + z * qw + x * qy - y * qx;
+    r.rotation[3] = w * qw - x * qx - y * qy - z * qz;
     return r;
 }
+template<uint32_t F> WPT_D wpt_sphere sphereAt(const SceneView& sv, const wpt_sphere& sp, float time)
+{
+    if ((F & FEAT_ANIM) && sp.animation >= 0)
+        return sphereMoved(sp, animationAt(sv, sp.animation, time));
+    return sp;
+}
 /* ... and as pdfValue() places it (:161-166): the whole transformation applied to the centre */
-template<uint32_t F> WPT_D wpt_sphere sphereForPdf(const SceneView& sv, const wpt_sphere& sp, float time)
+WPT_D wpt_sphere sphereMovedForPdf(const wpt_sphere& sp, const wptanim::Trs& T)
 {
     wpt_sphere r = sp;
-    if ((F & FEAT_ANIM) && sp.animation >= 0) {
-        const wptanim::Trs T = animationAt(sv, sp.animation, time);
-        float m = T.s[0];
-        if (T.s[1] > m)
-            m = T.s[1];
-        if (T.s[2] > m)
-            m = T.s[2];
-        wptanim::applyTrs(T, sp.center, r.center);
-        r.radius = sp.radius * m;
-    }
+    float m = T.s[0];
+    if (T.s[1] > m)
+        m = T.s[1];
+    if (T.s[2] > m)
+        m = T.s[2];
+    wptanim::applyTrs(T, sp.center, r.center);
+    r.radius = sp.radius * m;
     return r;
 }
 

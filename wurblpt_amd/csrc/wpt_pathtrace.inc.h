@@ -272,14 +272,13 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         if ((F & FEAT_SPHERES) && (leafPrim & PRIM_SPHERE)) {
                             /* HitableSphere::hit (hitable_sphere.hpp:104-147) */
                             c.invDet = c.U = c.V = c.W = 0.0f;
-                            accepted = sphereTest(sphereAt<F>(sv, sv.spheres[leafPrim & ~PRIM_SPHERE], ps.time), ps.ray.o, ps.ray.d, par.min_hit_distance, bound, c.a);
+                            accepted = sphereTest(sphereNow<F>(sv, ps, sv.spheres[leafPrim & ~PRIM_SPHERE]), ps.ray.o, ps.ray.d, par.min_hit_distance, bound, c.a);
                         } else {
                             const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
                             f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
                             if ((F & FEAT_ANIM) && (__float_as_uint(g2.w) & WPT_TRI_ANIMATE)) {
                                 /* the instance moves: its corners at the ray's time (hitable_triangle.hpp:209-218) */
-                                float animationM[16];
-                                wptanim::toMat4(animationAt(sv, sv.instances[__float_as_uint(g0.w)].animation, ps.time), animationM);
+                                const float* animationM = animationMatrix(sv, ps, sv.instances[__float_as_uint(g0.w)].animation);
                                 v0 = animatePoint(animationM, v0);
                                 v1 = animatePoint(animationM, v1);
                                 v2 = animatePoint(animationM, v2);
