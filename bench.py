@@ -131,6 +131,8 @@ def main():
                     help="N = 1 only (rehearsal): run the N > 1 code path -- block queue, worker threads, streams -- as if RANKS ranks shared the frame; this process renders every block")
     ap.add_argument("--dynamic-blocks", action="store_true",
                     help="N > 1: hand blocks out from a shared counter as MPICoordinator does (default: block i to rank i mod N)")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed steps rank 0 renders the frame once more in a single launch and compares (bit for bit)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant / scheduler tuning word for wpt_set_launch_config (experiments)")
     args = ap.parse_args()
 
@@ -255,6 +257,13 @@ def main():
         elapsed = float(t.item())
 
     ok = bool(torch.isfinite(frame).all().item()) if rank == 0 else True
+    verified = None
+    if args.verify and rank == 0:
+        # the sharded frame (rank 0 holds the sum of all ranks' bands) against one launch over all pixels
+        whole = torch.zeros_like(frame)
+        dscene.render_block_into(whole, ssqrt, None, params, None, main_stream)
+        torch.cuda.synchronize()
+        verified = bool(torch.equal(whole.view(torch.int32), frame.view(torch.int32)))
     launches = [(a.elapsed_time(b), s) for a, b, s in kernel_ms]
     if rank == 0:
         total_samples = float(pixels) * spp * args.steps
@@ -294,6 +303,8 @@ def main():
                          "counted_on": "%dx%d x %d spp" % (width, height, count_sqrt ** 2)},
             "frame_finite": ok,
         }
+        if verified is not None:
+            out["frame_equals_single_launch"] = verified
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, w, args.cpu_seconds)
         elif world > 1:
