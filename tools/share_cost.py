@@ -9,6 +9,8 @@ import torch
 from wurblpt_amd import blocks, device, host
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if len(sys.argv) > 2:
+    device.lib().wpt_set_launch_config(0, int(sys.argv[2], 0))
 W = H = 1024
 S = 32
 sc = host.cornell(W, H, 1, 2)
