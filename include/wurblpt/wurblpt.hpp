@@ -17,11 +17,14 @@
 #include <vector>
 
 #include "../wurblpt_hip.h"
+#include "animation.hpp"
 #include "camera.hpp"
 #include "constants.hpp"
 #include "envmap.hpp"
 #include "generator.hpp"
 #include "gvm.hpp"
+#include "imageio.hpp"
+#include "import.hpp"
 #include "material.hpp"
 #include "mesh.hpp"
 #include "mpi.hpp"
