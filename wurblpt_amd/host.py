@@ -245,6 +245,25 @@ def mcpt(scene, samples_sqrt, t0=0.0, t1=0.0, width=None, height=None):
     return frame
 
 
+MESH_KINDS = {"quad": 0, "cube": 1, "cube_side": 2, "disk": 3, "sphere": 4, "cylinder": 5, "closed_cylinder": 6, "cone": 7,
+              "closed_cone": 8, "torus": 9, "tetrahedron": 10, "octahedron": 11, "icosahedron": 12}
+
+
+def generate_mesh(kind, a=1, b=1, f=0.0):
+    """A mesh of include/wurblpt/generator.hpp: (vertices float32 [n, 11] = position, normal, texcoord, tangent; indices
+    uint32 [triangles, 3])."""
+    L = lib()
+    L.wpt_host_generate_mesh.restype = C.c_uint
+    L.wpt_host_generate_mesh.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_uint)]
+    cap = 1 << 16
+    v = np.zeros((cap, 11), np.float32)
+    ind = np.zeros(3 * cap, np.uint32)
+    ni = C.c_uint(0)
+    n = L.wpt_host_generate_mesh(MESH_KINDS[kind], a, b, f, C.c_void_p(v.ctypes.data), C.c_void_p(ind.ctypes.data), cap, C.byref(ni))
+    assert n <= cap and ni.value <= 3 * cap
+    return v[:n].copy(), ind[:ni.value].reshape(-1, 3).copy()
+
+
 def material_scene_index(scene):
     """Scene::materialIndex() of every flattened material (what getGroundTruth reports for it)."""
     out = np.zeros(scene.d.material_count, np.int32)

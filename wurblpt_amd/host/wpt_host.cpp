@@ -340,6 +340,51 @@ void wpt_host_default_params(wpt_params* p)
 
 /* ---- building blocks, exposed for parity tests against the reference's golden vectors ---- */
 
+/* A generated mesh (include/wurblpt/generator.hpp) as arrays: kind 0 quad, 1 cube, 2 cube side (a = side), 3 disk (f = inner
+ * radius), 4 sphere, 5 cylinder, 6 closed cylinder, 7 cone, 8 closed cone, 9 torus (f = inner radius), 10 tetrahedron,
+ * 11 octahedron, 12 icosahedron; a, b = slices / stacks (or sides / rings) where the shape has them.  Writes up to
+ * `capacity` vertices (11 floats: position, normal, texcoord, tangent) and 3 * capacity indices; returns the vertex
+ * count and stores the index count. */
+unsigned int wpt_host_generate_mesh(int kind, int a, int b, float f, float* vertices, unsigned int* indices, unsigned int capacity,
+        unsigned int* indexCount)
+{
+    const Transformation T;
+    std::unique_ptr<Mesh> mesh;
+    switch (kind) {
+    case 0: mesh.reset(generateQuad(T, a)); break;
+    case 1: mesh.reset(generateCube(T, a)); break;
+    case 2: mesh.reset(generateCubeSide(a, T, b)); break;
+    case 3: mesh.reset(generateDisk(T, f, a)); break;
+    case 4: mesh.reset(generateSphere(T, a, b)); break;
+    case 5: mesh.reset(generateCylinder(T, a)); break;
+    case 6: mesh.reset(generateClosedCylinder(T, a)); break;
+    case 7: mesh.reset(generateCone(T, a, b)); break;
+    case 8: mesh.reset(generateClosedCone(T, a, b)); break;
+    case 9: mesh.reset(generateTorus(T, f, a, b)); break;
+    case 10: mesh.reset(generateTetrahedron(T)); break;
+    case 11: mesh.reset(generateOctahedron(T)); break;
+    default: mesh.reset(generateIcosahedron(T)); break;
+    }
+    const unsigned int n = mesh->vertexCount();
+    *indexCount = mesh->indices.size();
+    for (unsigned int i = 0; i < n && i < capacity; i++) {
+        float* o = vertices + 11 * i;
+        const vec3 p = mesh->position(i), nr = mesh->normal(i);
+        const vec2 tc = mesh->haveTexCoords ? mesh->texcoord(i) : vec2(0.0f);
+        const vec3 tg = mesh->haveTangents ? mesh->tangent(i) : vec3(0.0f);
+        for (int k = 0; k < 3; k++) {
+            o[k] = p[k];
+            o[3 + k] = nr[k];
+            o[8 + k] = tg[k];
+        }
+        o[6] = tc[0];
+        o[7] = tc[1];
+    }
+    for (size_t i = 0; i < mesh->indices.size() && i < size_t(3) * capacity; i++)
+        indices[i] = mesh->indices[i];
+    return n;
+}
+
 /* The transformations of the reference's tests/test-transformation.cpp made with include/wurblpt/transformation.hpp
  * and gvm.hpp: per chain the Transformation (10 floats), its toMat4() (16) and the same chain in mat4 operations (16) */
 void wpt_host_transformation_chains(float* out)
