@@ -29,6 +29,12 @@ def lib():
         if not os.path.exists(path):
             raise RuntimeError("%s is missing: the HIP extension must be built (python -c 'import __graft_entry__ as g; g.build()'); "
                                "there is no CPU fallback" % path)
+        try:
+            # the HIP runtime this process uses must be one: PyTorch ships its own libamdhip64, and when the system's copy
+            # gets loaded first (this library links it) the two runtimes do not both see the device
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         L.wpt_device_count.restype = C.c_int
         L.wpt_select_device.argtypes = [C.c_int]

@@ -22,6 +22,12 @@ def lib():
         path = lib_path()
         if not os.path.exists(path):
             raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        try:
+            # the HIP runtime this process uses must be one: PyTorch ships its own libamdhip64, and when the system's copy
+            # gets loaded first (this library links it) the two runtimes do not both see the device
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         L.wpt_host_cornell.restype = C.c_void_p
         L.wpt_host_cornell.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint]
