@@ -8,6 +8,7 @@
  */
 #pragma once
 
+#include <algorithm>
 #include <limits>
 #include <vector>
 
@@ -36,26 +37,12 @@ public:
     };
 
 private:
-    std::vector<Keyframe> _keyframes; /* ascending time */
+    std::vector<Keyframe> _keyframes; /* strictly ascending in time */
 
-    /* the neighbours of t among the key frames; both indices are equal on an exact match */
-    void findKeyframeIndices(float t, int& lowerIndex, int& higherIndex) const
+    /* first key frame that is not earlier than t */
+    std::vector<Keyframe>::const_iterator notBefore(float t) const
     {
-        int a = 0;
-        int b = int(_keyframes.size()) - 1;
-        while (b >= a) {
-            int c = (a + b) / 2;
-            if (_keyframes[c].t < t) {
-                a = c + 1;
-            } else if (_keyframes[c].t > t) {
-                b = c - 1;
-            } else {
-                lowerIndex = higherIndex = c;
-                return;
-            }
-        }
-        lowerIndex = b;
-        higherIndex = a;
+        return std::lower_bound(_keyframes.begin(), _keyframes.end(), t, [](const Keyframe& k, float time) { return k.t < time; });
     }
 
 public:
@@ -69,27 +56,22 @@ public:
 
     const std::vector<Keyframe>& keyframes() const { return _keyframes; }
 
-    /* a key frame with the same time stamp is replaced */
+    /* keeps the list sorted; a key frame with the same time stamp is replaced */
     void addKeyframe(const Keyframe& keyframe)
     {
-        if (_keyframes.empty() || keyframe.t > endTime()) {
-            _keyframes.push_back(keyframe);
-        } else if (keyframe.t < startTime()) {
-            _keyframes.insert(_keyframes.begin(), keyframe);
-        } else {
-            int lowerIndex, higherIndex;
-            findKeyframeIndices(keyframe.t, lowerIndex, higherIndex);
-            if (lowerIndex == higherIndex)
-                _keyframes[lowerIndex] = keyframe;
-            else
-                _keyframes.insert(_keyframes.begin() + higherIndex, keyframe);
-        }
+        auto where = notBefore(keyframe.t);
+        const size_t index = where - _keyframes.begin();
+        if (where != _keyframes.end() && where->t == keyframe.t)
+            _keyframes[index] = keyframe;
+        else
+            _keyframes.insert(_keyframes.begin() + index, keyframe);
     }
     void addKeyframe(float time, const Transformation& transf) { addKeyframe(Keyframe(time, transf)); }
 
     float startTime() const { return _keyframes.empty() ? 0.0f : _keyframes.front().t; }
     float endTime() const { return _keyframes.empty() ? 0.0f : _keyframes.back().t; }
 
+    /* the first / last key frame outside their range, a key frame at its own time, mix() of the neighbours between */
     virtual Transformation at(float t) const override
     {
         if (_keyframes.empty())
@@ -98,70 +80,62 @@ public:
             return _keyframes.front().transformation;
         if (t >= endTime())
             return _keyframes.back().transformation;
-        int lowerIndex, higherIndex;
-        findKeyframeIndices(t, lowerIndex, higherIndex);
-        if (lowerIndex == higherIndex)
-            return _keyframes[lowerIndex].transformation;
-        float alpha = 1.0f - (_keyframes[higherIndex].t - t) / (_keyframes[higherIndex].t - _keyframes[lowerIndex].t);
-        return mix(_keyframes[lowerIndex].transformation, _keyframes[higherIndex].transformation, alpha);
+        auto higher = notBefore(t);
+        if (higher->t == t)
+            return higher->transformation;
+        auto lower = higher - 1;
+        const float alpha = 1.0f - (higher->t - t) / (higher->t - lower->t);
+        return mix(lower->transformation, higher->transformation, alpha);
     }
 };
 
-/* The transformations of all animations of a scene at one time, with their matrices */
+/* The transformations of a scene's animations at one moment, each with its matrix and normal matrix; an entry is
+ * evaluated when it is first asked for (reference: AnimationCache, animation.hpp:52-125) */
 class AnimationCache
 {
 private:
-    const std::vector<const Animation*>* _animations;
-    float _t;
-    std::vector<Transformation> _transformations;
-    std::vector<mat4> _transformationMs;
-    std::vector<mat3> _transformationNs;
-    std::vector<bool> _initialized;
+    struct Entry {
+        Transformation transformation;
+        mat4 M;
+        mat3 N;
+        bool valid = false;
+    };
+    const std::vector<const Animation*>* _animations = nullptr;
+    float _t = std::numeric_limits<float>::max();
+    std::vector<Entry> _entries;
 
-    void initIndexIfNecessary(int i)
+    const Entry& entry(int animationIndex)
     {
-        if (!_initialized[i]) {
-            _transformations[i] = (*_animations)[i]->at(_t);
-            _transformationMs[i] = _transformations[i].toMat4();
-            _transformationNs[i] = _transformations[i].toNormalMatrix();
-            _initialized[i] = true;
+        Entry& e = _entries[animationIndex];
+        if (!e.valid) {
+            e.transformation = (*_animations)[animationIndex]->at(_t);
+            e.M = e.transformation.toMat4();
+            e.N = e.transformation.toNormalMatrix();
+            e.valid = true;
         }
+        return e;
     }
 
 public:
-    AnimationCache() : _animations(nullptr), _t(std::numeric_limits<float>::max()) {}
-    AnimationCache(const std::vector<const Animation*>& animations) :
-        _animations(&animations), _t(std::numeric_limits<float>::max()), _transformations(animations.size()),
-        _transformationMs(animations.size()), _transformationNs(animations.size()), _initialized(animations.size(), false)
-    {
-    }
+    AnimationCache() {}
+    AnimationCache(const std::vector<const Animation*>& animations) : _animations(&animations), _entries(animations.size()) {}
+    /* every animation evaluated at t right away */
     AnimationCache(const std::vector<const Animation*>& animations, float t) : AnimationCache(animations)
     {
         _t = t;
-        for (size_t i = 0; i < _animations->size(); i++)
-            initIndexIfNecessary(i);
+        for (size_t i = 0; i < _entries.size(); i++)
+            entry(int(i));
     }
+    /* another moment: all entries are stale */
     void init(float t)
     {
         _t = t;
-        for (size_t i = 0; i < _initialized.size(); i++)
-            _initialized[i] = false;
+        for (Entry& e : _entries)
+            e.valid = false;
     }
-    const Transformation& get(int animationIndex)
-    {
-        initIndexIfNecessary(animationIndex);
-        return _transformations[animationIndex];
-    }
-    const mat4& getM(int animationIndex)
-    {
-        initIndexIfNecessary(animationIndex);
-        return _transformationMs[animationIndex];
-    }
-    const mat3& getN(int animationIndex)
-    {
-        initIndexIfNecessary(animationIndex);
-        return _transformationNs[animationIndex];
-    }
+    const Transformation& get(int animationIndex) { return entry(animationIndex).transformation; }
+    const mat4& getM(int animationIndex) { return entry(animationIndex).M; }
+    const mat3& getN(int animationIndex) { return entry(animationIndex).N; }
     float t() const { return _t; }
 };
 
