@@ -1,0 +1,71 @@
+"""usage (GPU box): python tools/fuzz_parity.py [rounds [seed]]
+Seeded random scenes of every family through the GPU and the CPU restatement: frames and work counters must agree bit for bit.
+Prints one line per mismatch and a summary; exit code 1 if anything differed."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from wurblpt_amd import device, host
+from tests import oracle_loader
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+orc = oracle_loader.load("portable")
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+bad = 0
+done = 0
+t_start = time.time()
+
+
+def check(label, sc, s, p=None, tables=False):
+    global bad, done
+    if tables and sc.d.envmap.N > 0:
+        t = orc.envmap_tables(sc)
+        ds = device.DeviceScene(sc)       # the device builds its own tables at upload
+        sc.set_envmap_tables(*t)
+    else:
+        ds = device.DeviceScene(sc)
+    ref, rc = orc.render(sc, s, p)
+    got, gc = ds.render(s, params=p, with_counters=True)
+    got2, _ = ds.render(s, params=p)
+    n1 = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
+    n2 = int((got2.view(np.uint32) != ref.view(np.uint32)).sum())
+    done += 1
+    if n1 or n2 or gc != rc:
+        bad += 1
+        print("MISMATCH %s: %d / %d values differ (counting / product kernel), counters equal: %s" % (label, n1, n2, gc == rc), flush=True)
+
+
+for r in range(rounds):
+    seed = int(rng.integers(1, 1 << 30))
+    w, h = int(rng.integers(17, 72)), int(rng.integers(9, 56))
+    s = int(rng.integers(1, 4))
+    p = host.default_params()
+    p.max_path_components = int(rng.choice([2, 3, 8, 128]))
+    p.rr_threshold = float(rng.choice([1.0, 0.5, 0.0]))
+    p.randomize_ray_over_pixel = int(rng.integers(0, 2))
+    check("triangles seed %d" % seed, host.random_triangles(int(rng.integers(1, 3000)), seed, with_texcoords=bool(rng.integers(0, 2)), width=w, height=h,
+                                                         aperture=float(rng.choice([0.0, 0.05]))), s, p)
+    check("sponza-like seed %d" % seed, host.sponza_like(w, h, seed=seed % 1000 + 1, detail=0.03, tex_size=16, env_width=32,
+                                                        importance_n=int(rng.choice([0, 8, 16]))), s, p, tables=True)
+    check("courtyard-like seed %d" % seed, host.courtyard_like(w, h, seed=seed % 1000 + 1, triangles=int(rng.integers(2000, 20000)), tex_size=16), s, p)
+    check("measured-like seed %d" % seed, host.measured_like(w, h, host.rgl_fixture("iso"), host.rgl_fixture("aniso"), seed=seed % 1000 + 1, detail=0.03,
+                                                            tex_size=16, env_width=32, importance_n=8), s, p, tables=True)
+    t0 = float(rng.random())
+    t1 = t0 if rng.integers(0, 3) == 0 else t0 + float(rng.random()) * (1.2 - t0)
+    p.t0, p.t1 = t0, t1
+    check("animated variant %d [%g, %g]" % (r % 16, t0, t1), host.animated(w, h, int(r % 16), t0, t1), s, p)
+    p.t0 = p.t1 = 0.0
+    check("spheres variant %d" % (r % 5), host.spheres(w, h, r % 5), s, p, tables=(r % 5 == 4))
+    sc = host.cornell(w, h, int(rng.integers(0, 2)), int(rng.choice([0, 2])))
+    k = int(rng.integers(0, 4))
+    if k:
+        host.set_distortion(sc, k, k1=-0.2 * float(rng.random()), k2=0.05 * float(rng.random()), k3=-0.01 * float(rng.random()) if k != 1 else 0.0,
+                            p1=0.001 * float(rng.random()) if k != 2 else 0.0, p2=-0.001 * float(rng.random()) if k != 2 else 0.0)
+    host.set_camera_mode(sc, int(rng.integers(0, 3)), float(rng.choice([0.0, 0.065])))
+    check("cornell lens %d" % k, sc, s, p)
+    if (r + 1) % 5 == 0:
+        print("%d scenes, %d mismatches, %.0f s" % (done, bad, time.time() - t_start), flush=True)
+print("fuzz parity: %d scenes, %d mismatches" % (done, bad))
+sys.exit(1 if bad else 0)
