@@ -1,5 +1,6 @@
 """usage (GPU box): python tools/fuzz_parity.py [rounds [seed]]
-Seeded random scenes of every family through the GPU and the CPU restatement: frames and work counters must agree bit for bit.
+Seeded random scenes of every family through the GPU and the CPU restatement: frames, work counters and the ground truth
+arrays must agree bit for bit.
 Prints one line per mismatch and a summary; exit code 1 if anything differed."""
 import os
 import sys
@@ -31,10 +32,19 @@ def check(label, sc, s, p=None, tables=False):
     got2, _ = ds.render(s, params=p)
     n1 = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
     n2 = int((got2.view(np.uint32) != ref.view(np.uint32)).sum())
+    # the ground truth pass of the same scene (pixel space flow only where the camera has an image plane)
+    cam = sc.camera.contents
+    bits = device.GT_ALL if (cam.surround_mode == 0 and cam.stereoscopic_distance <= 0.0) else device.GT_ALL & ~((1 << 17) | (1 << 18))
+    t0 = p.t0 if p is not None else 0.0
+    times = (t0, max(0.0, t0 - 0.2), t0 + 0.3)
+    gref = orc.ground_truth(sc, bits=bits, times=times)
+    ggot = device.ground_truth(ds, bits=bits, times=times)
+    n3 = sum(int((ggot[k].view(np.uint32) != gref[k].view(np.uint32)).sum()) for k in gref)
     done += 1
-    if n1 or n2 or gc != rc:
+    if n1 or n2 or n3 or gc != rc:
         bad += 1
-        print("MISMATCH %s: %d / %d values differ (counting / product kernel), counters equal: %s" % (label, n1, n2, gc == rc), flush=True)
+        print("MISMATCH %s: %d / %d values differ (counting / product kernel), counters equal: %s, ground truth values differing: %d" % (
+            label, n1, n2, gc == rc, n3), flush=True)
 
 
 for r in range(rounds):
