@@ -163,8 +163,84 @@ static std::vector<float> randomBoxes(unsigned int n, unsigned int seed, bool de
     return b;
 }
 
+/* what the vendored tinyobjloader makes of an OBJ file, configured as the importer configures it (import.hpp:214-218) */
+static void dumpObj(const std::string& objFile)
+{
+    {
+        tinyobj::ObjReaderConfig conf;
+        conf.triangulate = true;
+        conf.vertex_color = false;
+        tinyobj::ObjReader reader;
+        reader.ParseFromFile(objFile, conf);
+        std::vector<long long> valid(1, reader.Valid() ? 1 : 0);
+        ints("obj_valid", valid);
+        const tinyobj::attrib_t& attrib = reader.GetAttrib();
+        floats("obj_vertices", std::vector<float>(attrib.vertices.begin(), attrib.vertices.end()));
+        floats("obj_normals", std::vector<float>(attrib.normals.begin(), attrib.normals.end()));
+        floats("obj_texcoords", std::vector<float>(attrib.texcoords.begin(), attrib.texcoords.end()));
+        auto chars = [](std::vector<long long>& dst, const std::string& str) {
+            dst.push_back((long long)str.size());
+            for (char ch : str)
+                dst.push_back((unsigned char)ch);
+        };
+        std::vector<long long> shapeNames, shapeSizes, indices, materialIds;
+        for (const tinyobj::shape_t& sh : reader.GetShapes()) {
+            chars(shapeNames, sh.name);
+            shapeSizes.push_back((long long)sh.mesh.indices.size());
+            for (const tinyobj::index_t& ix : sh.mesh.indices) {
+                indices.push_back(ix.vertex_index);
+                indices.push_back(ix.normal_index);
+                indices.push_back(ix.texcoord_index);
+            }
+            for (int id : sh.mesh.material_ids)
+                materialIds.push_back(id);
+        }
+        ints("obj_shape_names", shapeNames);       /* per shape: length, bytes */
+        ints("obj_shape_index_counts", shapeSizes);
+        ints("obj_indices", indices);              /* vertex, normal, texcoord per corner */
+        ints("obj_material_ids", materialIds);     /* per triangle */
+        std::vector<long long> matStrings;
+        std::vector<float> matFloats;
+        for (const tinyobj::material_t& M : reader.GetMaterials()) {
+            chars(matStrings, M.name);
+            const std::string* names[7] = { &M.diffuse_texname, &M.specular_texname, &M.specular_highlight_texname, &M.bump_texname,
+                &M.alpha_texname, &M.emissive_texname, &M.normal_texname };
+            const tinyobj::texture_option_t* opts[7] = { &M.diffuse_texopt, &M.specular_texopt, &M.specular_highlight_texopt, &M.bump_texopt,
+                &M.alpha_texopt, &M.emissive_texopt, &M.normal_texopt };
+            for (int k = 0; k < 3; k++) matFloats.push_back(M.diffuse[k]);
+            for (int k = 0; k < 3; k++) matFloats.push_back(M.specular[k]);
+            for (int k = 0; k < 3; k++) matFloats.push_back(M.emission[k]);
+            for (int k = 0; k < 3; k++) matFloats.push_back(M.transmittance[k]);
+            matFloats.push_back(M.shininess);
+            matFloats.push_back(M.dissolve);
+            matFloats.push_back(M.ior);
+            for (int t = 0; t < 7; t++) {
+                chars(matStrings, *names[t]);
+                for (int k = 0; k < 3; k++) matFloats.push_back(opts[t]->scale[k]);
+                for (int k = 0; k < 3; k++) matFloats.push_back(opts[t]->origin_offset[k]);
+                matFloats.push_back(opts[t]->bump_multiplier);
+            }
+        }
+        ints("obj_material_strings", matStrings);  /* per material: name, then 7 texture names (diffuse specular shininess bump alpha emissive normal) */
+        floats("obj_material_floats", matFloats);  /* per material: Kd Ks Ke Tf (3 each) Ns d Ni, then per texture scale(3) offset(3) bm */
+    }
+
+}
+
 int main(int argc, char* argv[])
 {
+    if (argc == 4 && std::string(argv[1]) == "--obj") { /* ref_probe --obj file.obj out.json: only the obj_* entries, for any file */
+        out = fopen(argv[3], "w");
+        if (!out)
+            return 1;
+        fprintf(out, "{");
+        key("generator");
+        fprintf(out, "\"oracle/ref_probe.cpp --obj\"");
+        dumpObj(argv[2]);
+        fprintf(out, "\n}\n");
+        fclose(out);
+        return 0;
+    }
     out = argc > 1 ? fopen(argv[1], "w") : stdout;
     if (!out)
         return 1;
@@ -905,66 +981,9 @@ int main(int argc, char* argv[])
         }
     }
 
-    /* ---- the vendored tinyobjloader on the fixture files of tests/golden/obj (argv[2]/obj),
-     * configured as the importer configures it (import.hpp:214-218) ---- */
-    if (argc > 2) {
-        tinyobj::ObjReaderConfig conf;
-        conf.triangulate = true;
-        conf.vertex_color = false;
-        tinyobj::ObjReader reader;
-        reader.ParseFromFile(std::string(argv[2]) + "/obj/cases.obj", conf);
-        std::vector<long long> valid(1, reader.Valid() ? 1 : 0);
-        ints("obj_valid", valid);
-        const tinyobj::attrib_t& attrib = reader.GetAttrib();
-        floats("obj_vertices", std::vector<float>(attrib.vertices.begin(), attrib.vertices.end()));
-        floats("obj_normals", std::vector<float>(attrib.normals.begin(), attrib.normals.end()));
-        floats("obj_texcoords", std::vector<float>(attrib.texcoords.begin(), attrib.texcoords.end()));
-        auto chars = [](std::vector<long long>& dst, const std::string& str) {
-            dst.push_back((long long)str.size());
-            for (char ch : str)
-                dst.push_back((unsigned char)ch);
-        };
-        std::vector<long long> shapeNames, shapeSizes, indices, materialIds;
-        for (const tinyobj::shape_t& sh : reader.GetShapes()) {
-            chars(shapeNames, sh.name);
-            shapeSizes.push_back((long long)sh.mesh.indices.size());
-            for (const tinyobj::index_t& ix : sh.mesh.indices) {
-                indices.push_back(ix.vertex_index);
-                indices.push_back(ix.normal_index);
-                indices.push_back(ix.texcoord_index);
-            }
-            for (int id : sh.mesh.material_ids)
-                materialIds.push_back(id);
-        }
-        ints("obj_shape_names", shapeNames);       /* per shape: length, bytes */
-        ints("obj_shape_index_counts", shapeSizes);
-        ints("obj_indices", indices);              /* vertex, normal, texcoord per corner */
-        ints("obj_material_ids", materialIds);     /* per triangle */
-        std::vector<long long> matStrings;
-        std::vector<float> matFloats;
-        for (const tinyobj::material_t& M : reader.GetMaterials()) {
-            chars(matStrings, M.name);
-            const std::string* names[7] = { &M.diffuse_texname, &M.specular_texname, &M.specular_highlight_texname, &M.bump_texname,
-                &M.alpha_texname, &M.emissive_texname, &M.normal_texname };
-            const tinyobj::texture_option_t* opts[7] = { &M.diffuse_texopt, &M.specular_texopt, &M.specular_highlight_texopt, &M.bump_texopt,
-                &M.alpha_texopt, &M.emissive_texopt, &M.normal_texopt };
-            for (int k = 0; k < 3; k++) matFloats.push_back(M.diffuse[k]);
-            for (int k = 0; k < 3; k++) matFloats.push_back(M.specular[k]);
-            for (int k = 0; k < 3; k++) matFloats.push_back(M.emission[k]);
-            for (int k = 0; k < 3; k++) matFloats.push_back(M.transmittance[k]);
-            matFloats.push_back(M.shininess);
-            matFloats.push_back(M.dissolve);
-            matFloats.push_back(M.ior);
-            for (int t = 0; t < 7; t++) {
-                chars(matStrings, *names[t]);
-                for (int k = 0; k < 3; k++) matFloats.push_back(opts[t]->scale[k]);
-                for (int k = 0; k < 3; k++) matFloats.push_back(opts[t]->origin_offset[k]);
-                matFloats.push_back(opts[t]->bump_multiplier);
-            }
-        }
-        ints("obj_material_strings", matStrings);  /* per material: name, then 7 texture names (diffuse specular shininess bump alpha emissive normal) */
-        floats("obj_material_floats", matFloats);  /* per material: Kd Ks Ke Tf (3 each) Ns d Ni, then per texture scale(3) offset(3) bm */
-    }
+    /* ---- the vendored tinyobjloader on the fixture file of tests/golden/obj (argv[2]/obj) ---- */
+    if (argc > 2)
+        dumpObj(std::string(argv[2]) + "/obj/cases.obj");
 
     /* ---- the transformations of the reference's own tests/test-transformation.cpp: translate / rotate / scale in every
      * order and two products of three; each as Transformation (10 floats), its toMat4() (16) and the same chain made

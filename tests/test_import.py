@@ -436,3 +436,166 @@ def test_exr_reader_on_the_mitsuba_render_of_the_reference():
     blocks = img[::-1].reshape(64, 16, 64, 16, 3).mean(axis=(1, 3)).astype(np.float32)
     ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cbox_mitsuba_64x64.npy"))
     assert np.allclose(blocks, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_jpeg_decoder_fuzz_against_pillow(tmp_path):
+    """120 random images (sizes 1..70, grey and colour, noise to smooth) saved with random quality, chroma subsampling,
+    progressive / optimised coding and restart intervals: every byte equals libjpeg-turbo's decode."""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(11)
+    for case in range(120):
+        w, h = int(rng.integers(1, 71)), int(rng.integers(1, 71))
+        grey = bool(rng.integers(0, 4) == 0)
+        smooth = rng.random()
+        y, x = np.mgrid[0:h, 0:w]
+        base = np.stack([(x * rng.integers(1, 9) + y * rng.integers(1, 9)) % 256 for _ in range(3)], axis=2).astype(np.float64)
+        img = np.clip(smooth * base + (1 - smooth) * rng.integers(0, 256, base.shape), 0, 255).astype(np.uint8)
+        opts = dict(quality=int(rng.integers(1, 101)))
+        if not grey:
+            opts["subsampling"] = [0, 1, 2, "4:1:1"][int(rng.integers(0, 4))]
+        if rng.integers(0, 2):
+            opts["progressive"] = True
+        if rng.integers(0, 2):
+            opts["optimize"] = True
+        k = int(rng.integers(0, 3))
+        if k == 1:
+            opts["restart_marker_blocks"] = int(rng.integers(1, 6))
+        elif k == 2:
+            opts["restart_marker_rows"] = int(rng.integers(1, 3))
+        p = str(tmp_path / "f.jpg")
+        PIL.fromarray(img[:, :, 0] if grey else img).save(p, "JPEG", **opts)
+        ref = np.asarray(PIL.open(p))
+        ref = ref[:, :, None] if ref.ndim == 2 else ref
+        got = host.image_load(p)
+        assert got is not None and np.array_equal(got[::-1], ref), (case, w, h, grey, opts)
+
+
+def _random_number(rng):
+    """a float in one of the spellings OBJ files use"""
+    v = float(rng.normal(0, 3)) * (10.0 ** int(rng.integers(-3, 4)) if rng.integers(0, 6) == 0 else 1.0)
+    style = int(rng.integers(0, 7))
+    if style == 0:
+        return "%d" % int(v)
+    if style == 1:
+        return "%.6f" % v
+    if style == 2:
+        return "%e" % v
+    if style == 3:
+        return ("%+.4f" % v)
+    if style == 4:
+        return ("%.3f" % v).replace("0.", ".", 1) if abs(v) < 1 else "%.3f" % v
+    if style == 5:
+        return "%.9g" % v
+    return "%.1fE%+d" % (v, int(rng.integers(-2, 3)))
+
+
+def _random_obj(rng, d, name):
+    """An OBJ + MTL pair with random number spellings, index forms (absolute and relative, with and without normals and
+    texture coordinates), planar polygons of 3 to 7 corners (convex and with one notch), groups, objects, material
+    switches, comments, blank lines and trailing spaces."""
+    nm = int(rng.integers(0, 4))
+    mats = ["m%d" % i for i in range(nm)]
+    with open(os.path.join(d, name + ".mtl"), "w") as f:
+        for m in mats:
+            f.write("newmtl %s\n" % m)
+            for key in ("Kd", "Ks", "Ke", "Tf"):
+                if rng.integers(0, 3):
+                    f.write("%s %s %s %s\n" % (key, *[("%.4f" % rng.random()) for _ in range(3)]))
+            if rng.integers(0, 2):
+                f.write("Ns %s\n" % _random_number(rng))
+            k = int(rng.integers(0, 4))
+            if k == 1:
+                f.write("d %.3f\n" % rng.random())
+            elif k == 2:
+                f.write("Tr %.3f\n" % rng.random())
+            elif k == 3:
+                f.write("d %.3f\nTr %.3f\n" % (rng.random(), rng.random()))
+            if rng.integers(0, 2):
+                f.write("Ni %.3f\n" % (1 + rng.random()))
+            for key in ("map_Kd", "map_Ks", "map_Ns", "map_bump", "bump", "map_d", "map_Ke", "norm"):
+                if rng.integers(0, 5) == 0:
+                    opt = ""
+                    if rng.integers(0, 2):
+                        opt += "-s %.2f %.2f %.2f " % tuple(rng.random(3) + 0.5)
+                    if rng.integers(0, 2):
+                        opt += "-o %.2f %.2f %.2f " % tuple(rng.random(3))
+                    if key in ("map_bump", "bump") and rng.integers(0, 2):
+                        opt += "-bm %.2f " % rng.random()
+                    f.write("%s %stex_%s.png\n" % (key, opt, key))
+            f.write("\n")
+    nv, nn, nt = int(rng.integers(8, 40)), int(rng.integers(0, 10)), int(rng.integers(0, 10))
+    lines = ["# fuzz case", "mtllib %s.mtl" % name, ""]
+    # vertices in a plane per polygon would need care; polygons below are made from fresh planar rings instead
+    for _ in range(nv):
+        lines.append("v %s %s %s" % (_random_number(rng), _random_number(rng), _random_number(rng)))
+    for _ in range(nn):
+        lines.append("vn %s %s %s" % (_random_number(rng), _random_number(rng), _random_number(rng)))
+    for _ in range(nt):
+        lines.append("vt %s %s" % (_random_number(rng), _random_number(rng)) + (" 0" if rng.integers(0, 3) == 0 else ""))
+    count = nv
+    for shape in range(int(rng.integers(1, 5))):
+        k = int(rng.integers(0, 3))
+        if k == 0:
+            lines.append("g group%d" % shape)
+        elif k == 1:
+            lines.append("o object%d" % shape)
+        for face in range(int(rng.integers(1, 7))):
+            if rng.integers(0, 3) == 0 and (mats or rng.integers(0, 2)):
+                lines.append("usemtl %s" % (mats[int(rng.integers(0, len(mats)))] if mats and rng.integers(0, 5) else "unknown"))
+            corners = int(rng.choice([3, 3, 3, 4, 4, 5, 6, 7]))
+            if corners > 3:
+                # a planar ring in a random axis plane, one corner pulled inwards now and then
+                axis = int(rng.integers(0, 3))
+                ang = np.sort(rng.random(corners)) * 2 * np.pi
+                rad = np.full(corners, 1.0 + rng.random())
+                if corners > 4 and rng.integers(0, 2):
+                    rad[int(rng.integers(0, corners))] *= 0.35
+                ring = np.zeros((corners, 3))
+                ring[:, (axis + 1) % 3] = rad * np.cos(ang)
+                ring[:, (axis + 2) % 3] = rad * np.sin(ang)
+                ring[:, axis] = rng.normal()
+                for q in ring:
+                    lines.append("v %.5f %.5f %.5f" % tuple(q))
+                ids = list(range(count + 1, count + corners + 1))
+                count += corners
+            else:
+                ids = [int(i) + 1 for i in rng.choice(count, 3, replace=False)]
+            form = int(rng.integers(0, 4)) if (nn or nt) else 0
+            toks = []
+            for i in ids:
+                vi = i if rng.integers(0, 4) else i - count - 1          # relative index now and then
+                ti = int(rng.integers(1, nt + 1)) if nt else 0
+                ni = int(rng.integers(1, nn + 1)) if nn else 0
+                if form == 1 and nt:
+                    toks.append("%d/%d" % (vi, ti))
+                elif form == 2 and nn:
+                    toks.append("%d//%d" % (vi, ni if rng.integers(0, 4) else ni - nn - 1))
+                elif form == 3 and nn and nt:
+                    toks.append("%d/%d/%d" % (vi, ti, ni))
+                else:
+                    toks.append("%d" % vi)
+            lines.append("f " + " ".join(toks) + ("  " if rng.integers(0, 4) == 0 else ""))
+        if rng.integers(0, 3) == 0:
+            lines.append("")
+    with open(os.path.join(d, name + ".obj"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return os.path.join(d, name + ".obj")
+
+
+def test_obj_reader_fuzz_against_the_vendored_tinyobjloader(tmp_path):
+    """60 random OBJ / MTL pairs through include/wurblpt/objreader.hpp and through the reference's own parser
+    (oracle/_ref/ref_probe --obj, built from the reference tree where this machine has it): every float bit, index,
+    triangle, shape boundary, material id and MTL value equal."""
+    import subprocess
+    probe = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
+    if not os.path.exists(probe) or not os.path.exists("/root/reference"):
+        pytest.skip("the reference tree is not on this machine")
+    rng = np.random.default_rng(31)
+    for case in range(60):
+        obj = _random_obj(rng, str(tmp_path), "case%d" % case)
+        ref_json, my_json = str(tmp_path / "ref.json"), str(tmp_path / "mine.json")
+        subprocess.run([probe, "--obj", obj, ref_json], check=True, timeout=60, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert host.lib().wpt_host_obj_dump(obj.encode(), my_json.encode()) == 0
+        ref, mine = json.load(open(ref_json)), json.load(open(my_json))
+        for key, value in mine.items():
+            assert value == ref[key], (case, key, obj)
