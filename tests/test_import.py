@@ -599,3 +599,54 @@ def test_obj_reader_fuzz_against_the_vendored_tinyobjloader(tmp_path):
         ref, mine = json.load(open(ref_json)), json.load(open(my_json))
         for key, value in mine.items():
             assert value == ref[key], (case, key, obj)
+
+
+def test_png_tga_pnm_decoders_fuzz_against_pillow(tmp_path):
+    """Files written by Pillow (its own zlib settings, filters, palettes, RLE) through the importer's decoders:
+    PNG grey / grey + alpha / RGB / RGBA / palette (with and without transparency) / 16 bit grey, TGA plain and RLE,
+    binary PGM / PPM; every value equal."""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(23)
+    for case in range(80):
+        w, h = int(rng.integers(1, 50)), int(rng.integers(1, 50))
+        smooth = rng.random() < 0.5
+        def pixels(c, hi=256, dtype=np.uint8):
+            if smooth:
+                y, x = np.mgrid[0:h, 0:w]
+                return np.stack([((x * (k + 2) + y * (5 - k)) % hi) for k in range(c)], axis=2).astype(dtype)
+            return rng.integers(0, hi, (h, w, c)).astype(dtype)
+        kind = int(rng.integers(0, 10))
+        p = str(tmp_path / ("f%d" % case))
+        if kind == 0:
+            ref = pixels(1); PIL.fromarray(ref[:, :, 0], "L").save(p + ".png", compress_level=int(rng.integers(0, 10)))
+        elif kind == 1:
+            ref = pixels(2); PIL.fromarray(ref, "LA").save(p + ".png")
+        elif kind == 2:
+            ref = pixels(3); PIL.fromarray(ref, "RGB").save(p + ".png", optimize=bool(rng.integers(0, 2)))
+        elif kind == 3:
+            ref = pixels(4); PIL.fromarray(ref, "RGBA").save(p + ".png")
+        elif kind == 4:
+            idx = pixels(1, hi=int(rng.integers(2, 257)))[:, :, 0]
+            pal = rng.integers(0, 256, (256, 3)).astype(np.uint8)
+            im = PIL.fromarray(idx, "P"); im.putpalette(pal.reshape(-1).tolist())
+            if rng.integers(0, 2):
+                alpha = rng.integers(0, 256, 256).astype(np.uint8)
+                im.save(p + ".png", transparency=bytes(alpha.tolist()))
+                ref = np.concatenate([pal[idx], alpha[idx][:, :, None]], axis=2)
+            else:
+                im.save(p + ".png")
+                ref = pal[idx]
+        elif kind == 5:
+            ref = pixels(1, hi=65536, dtype=np.uint16); PIL.fromarray(ref[:, :, 0]).save(p + ".png")
+        elif kind == 6:
+            ref = pixels(3); PIL.fromarray(ref, "RGB").save(p + ".tga", compression="tga_rle" if rng.integers(0, 2) else None)
+        elif kind == 7:
+            ref = pixels(4); PIL.fromarray(ref, "RGBA").save(p + ".tga", compression="tga_rle" if rng.integers(0, 2) else None)
+        elif kind == 8:
+            ref = pixels(1); PIL.fromarray(ref[:, :, 0], "L").save(p + ".pgm")
+        else:
+            ref = pixels(3); PIL.fromarray(ref, "RGB").save(p + ".ppm")
+        ext = [".png", ".png", ".png", ".png", ".png", ".png", ".tga", ".tga", ".pgm", ".ppm"][kind]
+        got = host.image_load(p + ext)
+        assert got is not None and got.shape == ref.shape and got.dtype == ref.dtype, (case, kind, w, h)
+        assert np.array_equal(got[::-1], ref), (case, kind, w, h)
