@@ -3,7 +3,7 @@
  * TGD::load() (import.hpp:288-299, texture_image.hpp:352-372), an external library that is not
  * part of this build.  Decoded are the formats the scenes of the reference's examples use for
  * textures and environment maps and that need no further library: PNG (8 and 16 bit, grey, grey +
- * alpha, RGB, RGBA, palette; not interlaced), TGA (types 2, 3, 10, 11; 8/24/32 bit), binary PNM
+ * alpha, RGB, RGBA, palette; plain and Adam7 interlaced), TGA (types 2, 3, 10, 11; 8/24/32 bit), binary PNM
  * (P5, P6; 8 and 16 bit), PFM (Pf, PF), Radiance HDR (RLE and flat), JPEG (jpeg.hpp) and OpenEXR
  * scanline files (exr.hpp).  A file that cannot be decoded is reported and the importer substitutes
  * its dummy texture, as the reference does for any file libtgd cannot load (import.hpp:131-134).
@@ -239,8 +239,8 @@ inline bool loadPng(const std::vector<unsigned char>& b, ArrayContainer& img, st
         }
         pos += 12 + len;
     }
-    if (w == 0 || h == 0 || interlace != 0 || !(depth == 8 || depth == 16 || (colorType == 3 && depth <= 8) || (colorType == 0 && depth < 8))) {
-        error = "PNG variant not handled (interlaced or unusual bit depth)";
+    if (w == 0 || h == 0 || interlace > 1 || !(depth == 8 || depth == 16 || (colorType == 3 && depth <= 8) || (colorType == 0 && depth < 8))) {
+        error = "PNG variant not handled (unusual bit depth or interlace method)";
         return false;
     }
     const int channels = colorType == 0 ? 1 : colorType == 2 ? 3 : colorType == 3 ? 1 : colorType == 4 ? 2 : colorType == 6 ? 4 : 0;
@@ -253,56 +253,77 @@ inline bool loadPng(const std::vector<unsigned char>& b, ArrayContainer& img, st
         error = "PNG data cannot be inflated";
         return false;
     }
-    const size_t bpp = size_t(channels * depth + 7) / 8;          /* filter unit in bytes, at least 1 */
-    const size_t stride = (size_t(w) * channels * depth + 7) / 8; /* bytes per scanline */
-    if (raw.size() < (stride + 1) * h) {
-        error = "PNG data too short";
-        return false;
-    }
-    std::vector<unsigned char> prev(stride, 0), cur(stride);
+    const size_t bpp = size_t(channels * depth + 7) / 8; /* filter unit in bytes, at least 1 */
     const bool sixteen = depth == 16;
     const int outComps = colorType == 3 ? (trns.empty() ? 3 : 4) : channels;
     img = ArrayContainer(w, h, outComps, sixteen ? uint16 : uint8);
-    for (uint32_t y = 0; y < h; y++) {
-        const unsigned char* line = raw.data() + (stride + 1) * y;
-        const int filter = line[0];
-        for (size_t i = 0; i < stride; i++) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, bb = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            int pred = 0;
-            switch (filter) {
-            case 1: pred = a; break;
-            case 2: pred = bb; break;
-            case 3: pred = (a + bb) >> 1; break;
-            case 4: {
-                const int p = a + bb - c, pa = std::abs(p - a), pb = std::abs(p - bb), pc = std::abs(p - c);
-                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c);
-                break;
+    /* One reduced image: passW x passH pixels that go to (x0 + i dx, y0 + j dy).  A plain file is one such image over
+     * all pixels, an interlaced one (Adam7) seven of them, each filtered on its own. */
+    size_t at = 0;
+    auto pass = [&](uint32_t passW, uint32_t passH, uint32_t x0, uint32_t dx, uint32_t y0, uint32_t dy) {
+        if (passW == 0 || passH == 0)
+            return true;
+        const size_t stride = (size_t(passW) * channels * depth + 7) / 8; /* bytes per scanline */
+        if (raw.size() < at + (stride + 1) * passH)
+            return false;
+        std::vector<unsigned char> prev(stride, 0), cur(stride);
+        for (uint32_t j = 0; j < passH; j++) {
+            const unsigned char* line = raw.data() + at + (stride + 1) * j;
+            const int filter = line[0];
+            for (size_t i = 0; i < stride; i++) {
+                const int a = i >= bpp ? cur[i - bpp] : 0, bb = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                int pred = 0;
+                switch (filter) {
+                case 1: pred = a; break;
+                case 2: pred = bb; break;
+                case 3: pred = (a + bb) >> 1; break;
+                case 4: {
+                    const int p = a + bb - c, pa = std::abs(p - a), pb = std::abs(p - bb), pc = std::abs(p - c);
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c);
+                    break;
+                }
+                default: break;
+                }
+                cur[i] = (unsigned char)(line[1 + i] + pred);
             }
-            default: break;
+            const size_t dstRow = h - 1 - (y0 + size_t(j) * dy); /* PNG stores the top row first */
+            for (uint32_t i = 0; i < passW; i++) {
+                const size_t x = x0 + size_t(i) * dx;
+                if (sixteen) {
+                    uint16_t* dst = img.get<uint16_t>(x, dstRow);
+                    for (int c = 0; c < channels; c++)
+                        dst[c] = uint16_t((cur[(size_t(i) * channels + c) * 2] << 8) | cur[(size_t(i) * channels + c) * 2 + 1]);
+                } else if (colorType == 3) {
+                    const unsigned int index = depth == 8 ? cur[i] : (cur[(size_t(i) * depth) / 8] >> (8 - depth - (i * depth) % 8)) & ((1u << depth) - 1u);
+                    uint8_t* dst = img.get<uint8_t>(x, dstRow);
+                    for (int c = 0; c < 3; c++)
+                        dst[c] = 3 * index + c < palette.size() ? palette[3 * index + c] : 0;
+                    if (outComps == 4)
+                        dst[3] = index < trns.size() ? trns[index] : 255;
+                } else if (depth < 8) {
+                    const unsigned int v = (cur[(size_t(i) * depth) / 8] >> (8 - depth - (i * depth) % 8)) & ((1u << depth) - 1u);
+                    img.get<uint8_t>(x, dstRow)[0] = uint8_t(v * 255u / ((1u << depth) - 1u));
+                } else {
+                    memcpy(img.get<uint8_t>(x, dstRow), cur.data() + size_t(i) * channels, channels);
+                }
             }
-            cur[i] = (unsigned char)(line[1 + i] + pred);
+            prev.swap(cur);
         }
-        const size_t dstRow = h - 1 - y; /* PNG stores the top row first */
-        for (uint32_t x = 0; x < w; x++) {
-            if (sixteen) {
-                uint16_t* dst = img.get<uint16_t>(x, dstRow);
-                for (int c = 0; c < channels; c++)
-                    dst[c] = uint16_t((cur[(size_t(x) * channels + c) * 2] << 8) | cur[(size_t(x) * channels + c) * 2 + 1]);
-            } else if (colorType == 3) {
-                const unsigned int index = depth == 8 ? cur[x] : (cur[(size_t(x) * depth) / 8] >> (8 - depth - (x * depth) % 8)) & ((1u << depth) - 1u);
-                uint8_t* dst = img.get<uint8_t>(x, dstRow);
-                for (int c = 0; c < 3; c++)
-                    dst[c] = 3 * index + c < palette.size() ? palette[3 * index + c] : 0;
-                if (outComps == 4)
-                    dst[3] = index < trns.size() ? trns[index] : 255;
-            } else if (depth < 8) {
-                const unsigned int v = (cur[(size_t(x) * depth) / 8] >> (8 - depth - (x * depth) % 8)) & ((1u << depth) - 1u);
-                img.get<uint8_t>(x, dstRow)[0] = uint8_t(v * 255u / ((1u << depth) - 1u));
-            } else {
-                memcpy(img.get<uint8_t>(x, dstRow), cur.data() + size_t(x) * channels, channels);
-            }
-        }
-        prev.swap(cur);
+        at += (stride + 1) * passH;
+        return true;
+    };
+    bool ok = true;
+    if (interlace == 0) {
+        ok = pass(w, h, 0, 1, 0, 1);
+    } else {
+        static const uint32_t x0[7] = { 0, 4, 0, 2, 0, 1, 0 }, y0[7] = { 0, 0, 4, 0, 2, 0, 1 }, dx[7] = { 8, 8, 4, 4, 2, 2, 1 },
+                              dy[7] = { 8, 8, 8, 4, 4, 2, 2 };
+        for (int k = 0; k < 7 && ok; k++)
+            ok = pass(w > x0[k] ? (w - x0[k] + dx[k] - 1) / dx[k] : 0, h > y0[k] ? (h - y0[k] + dy[k] - 1) / dy[k] : 0, x0[k], dx[k], y0[k], dy[k]);
+    }
+    if (!ok) {
+        error = "PNG data too short";
+        return false;
     }
     return true;
 }

@@ -29,13 +29,9 @@ def test_obj_reader_matches_the_vendored_tinyobjloader(golden, tmp_path):
 
 # ---- image decoders: files written here with numpy / zlib, decoded by include/wurblpt/imageio.hpp ----
 
-def _png_bytes(img, depth, palette=None, trns=None):
-    """img: [h, w, c] top row first; a random filter type per scanline exercises all five predictors"""
-    import struct
-    import zlib
+def _png_rows(img, depth, rng):
+    """the filtered scanlines of one (reduced) image; a random filter type per scanline exercises all five predictors"""
     h, w, c = img.shape
-    color_type = {1: 0, 2: 4, 3: 2, 4: 6}[c] if palette is None else 3
-    rng = np.random.RandomState(w * 131 + h)
     bpp = max(1, c * depth // 8)
     rows = []
     prev = np.zeros(w * c * depth // 8, np.int32)
@@ -61,10 +57,28 @@ def _png_bytes(img, depth, palette=None, trns=None):
             pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, cc))
         rows.append(bytes([f]) + ((cur - pred) & 255).astype(np.uint8).tobytes())
         prev = cur
+    return rows
+
+
+def _png_bytes(img, depth, palette=None, trns=None, interlace=False):
+    """img: [h, w, c] top row first; plain, or the seven reduced images of Adam7 one after the other"""
+    import struct
+    import zlib
+    h, w, c = img.shape
+    color_type = {1: 0, 2: 4, 3: 2, 4: 6}[c] if palette is None else 3
+    rng = np.random.RandomState(w * 131 + h)
+    if interlace:
+        rows = []
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = img[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                rows += _png_rows(sub, depth, rng)
+    else:
+        rows = _png_rows(img, depth, rng)
 
     def chunk(t, d):
         return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
-    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 0))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 1 if interlace else 0))
     if palette is not None:
         out += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
         if trns is not None:
@@ -91,6 +105,31 @@ def test_png_decoder(tmp_path):
     got = host.image_load(str(f))
     want = np.concatenate([pal[idx[..., 0]], np.where(idx < 10, idx * 20, 255)], axis=-1).astype(np.uint8)
     assert np.array_equal(got, want[::-1])
+
+
+def test_png_decoder_adam7(tmp_path):
+    """Interlaced PNG: seven reduced images, each filtered on its own; sizes from 1 x 1 (six empty passes) to ones
+    that are no multiple of 8.  Where Pillow is present it reads the test's own files the same way."""
+    rng = np.random.RandomState(4)
+    try:
+        from PIL import Image
+    except ImportError:
+        Image = None
+    for (h, w) in ((1, 1), (2, 3), (5, 1), (8, 8), (9, 17), (23, 31), (40, 16)):
+        for comps, depth in ((1, 8), (3, 8), (4, 8), (2, 16), (3, 16)):
+            img = rng.randint(0, 256 if depth == 8 else 65536, (h, w, comps)).astype(np.uint16 if depth == 16 else np.uint8)
+            f = tmp_path / "i.png"
+            f.write_bytes(_png_bytes(img, depth, interlace=True))
+            got = host.image_load(str(f))
+            assert got is not None and got.dtype == img.dtype and np.array_equal(got, img[::-1]), (h, w, comps, depth)
+            if Image is not None and depth == 8 and comps != 2:
+                ref = np.asarray(Image.open(str(f)))
+                assert np.array_equal(ref.reshape(img.shape), img), "the test's writer"
+    pal = rng.randint(0, 256, (16, 3))
+    idx = rng.randint(0, 16, (19, 21, 1)).astype(np.uint8)
+    f = tmp_path / "ipal.png"
+    f.write_bytes(_png_bytes(idx, 8, palette=pal, interlace=True))
+    assert np.array_equal(host.image_load(str(f)), pal[idx[..., 0]].astype(np.uint8)[::-1])
 
 
 def test_tga_pnm_pfm_hdr_decoders(tmp_path):
