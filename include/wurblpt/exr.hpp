@@ -167,6 +167,8 @@ inline bool loadExr(const std::vector<unsigned char>& b, ArrayContainer& img, st
     const size_t chunks = (height + linesPerChunk - 1) / linesPerChunk;
     if (pos + chunks * 8 > b.size())
         return fail("truncated OpenEXR offset table");
+    if (uint64_t(bytesPerLine) * height > 1100ull * b.size() + 65536ull) /* zlib expands at most 1032-fold */
+        return fail("truncated OpenEXR data");
     img = ArrayContainer(width, height, comps, float32);
     float* dst = static_cast<float*>(img.data());
     std::vector<unsigned char> raw, tmp;

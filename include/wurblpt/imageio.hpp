@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -256,6 +257,11 @@ inline bool loadPng(const std::vector<unsigned char>& b, ArrayContainer& img, st
     const size_t bpp = size_t(channels * depth + 7) / 8; /* filter unit in bytes, at least 1 */
     const bool sixteen = depth == 16;
     const int outComps = colorType == 3 ? (trns.empty() ? 3 : 4) : channels;
+    /* a damaged header must not make us allocate what the data cannot fill: every scanline has its filter byte */
+    if (uint64_t(h) > raw.size() || (uint64_t(w) * channels * depth + 7) / 8 * uint64_t(h) > uint64_t(raw.size())) {
+        error = "PNG data too short";
+        return false;
+    }
     img = ArrayContainer(w, h, outComps, sixteen ? uint16 : uint8);
     /* One reduced image: passW x passH pixels that go to (x0 + i dx, y0 + j dy).  A plain file is one such image over
      * all pixels, an interlaced one (Adam7) seven of them, each filtered on its own. */
@@ -342,6 +348,10 @@ inline bool loadTga(const std::vector<unsigned char>& b, ArrayContainer& img, st
         return false;
     }
     const int bytes = bits / 8;
+    if (uint64_t(w) * h * bytes > 130ull * b.size()) { /* run-length packets expand at most 128-fold */
+        error = "truncated TGA data";
+        return false;
+    }
     std::vector<unsigned char> px(size_t(w) * h * bytes);
     size_t pos = 18 + size_t(idLen);
     if (type == 2 || type == 3) {
@@ -499,6 +509,10 @@ inline bool loadHdr(const std::vector<unsigned char>& b, ArrayContainer& img, st
     int w = 0, h = 0;
     if (sscanf(s.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) {
         error = "HDR orientation not handled";
+        return false;
+    }
+    if (uint64_t(w) * uint64_t(h) > 130ull * b.size()) { /* run-length coding expands at most 64-fold */
+        error = "truncated HDR data";
         return false;
     }
     img = ArrayContainer(w, h, 3, float32);
@@ -748,6 +762,7 @@ inline ArrayContainer loadImage(const std::string& filename, std::string* error 
     ArrayContainer img;
     std::vector<unsigned char> b;
     bool ok = false;
+    try {
     if (!readFile(filename, b)) {
         err = "cannot open file";
     } else if (b.size() >= 8 && !memcmp(b.data(), "\x89PNG\r\n\x1a\n", 8)) {
@@ -769,6 +784,11 @@ inline ArrayContainer loadImage(const std::string& filename, std::string* error 
             ok = loadTga(b, img, err);
         else
             err = "unknown image format";
+    }
+    } catch (const std::exception& e) {
+        /* a damaged header can ask for more memory than there is */
+        ok = false;
+        err = std::string("cannot decode: ") + e.what();
     }
     if (!ok) {
         if (error)

@@ -33,7 +33,8 @@ struct HuffmanTable {
     int mincode[17], maxcode[18], valptr[17];
     uint16_t look[512]; /* 9 bit lookahead: (length << 8) | value, 0 = longer code */
 
-    void build(const unsigned char* bits /* [1..16] */, const unsigned char* values, int count)
+    /* false for lengths that do not form a prefix code (more codes of a length than there is room for) */
+    bool build(const unsigned char* bits /* [1..16] */, const unsigned char* values, int count)
     {
         memcpy(vals, values, count);
         int code = 0, k = 0;
@@ -41,6 +42,8 @@ struct HuffmanTable {
         for (int l = 1; l <= 16; l++) {
             valptr[l] = k;
             mincode[l] = code;
+            if (code + bits[l] > (1 << l))
+                return false;
             for (int i = 0; i < bits[l]; i++, k++, code++) {
                 if (l <= 9) {
                     const int first = code << (9 - l);
@@ -53,6 +56,7 @@ struct HuffmanTable {
         }
         maxcode[17] = 0x7fffffff;
         defined = true;
+        return true;
     }
 };
 
@@ -276,6 +280,10 @@ struct Decoder {
             comp[0].h = comp[0].v = hmax = vmax = 1;
         mcusX = (width + 8 * hmax - 1) / (8 * hmax);
         mcusY = (height + 8 * vmax - 1) / (8 * vmax);
+        /* every block costs at least one bit in every scan that touches it: a damaged size must not make us allocate
+         * what the file cannot fill */
+        if (uint64_t(mcusX) * mcusY > 8ull * size)
+            return fail("truncated JPEG data");
         for (int c = 0; c < ncomp; c++) {
             Component& k = comp[c];
             if (hmax % k.h != 0 || vmax % k.v != 0)
@@ -304,7 +312,8 @@ struct Decoder {
             }
             if (tc > 1 || th > 3 || count > 256 || len < 17 + count)
                 return fail("bad Huffman table");
-            (tc == 0 ? dc[th] : ac[th]).build(bits, p + 17, count);
+            if (!(tc == 0 ? dc[th] : ac[th]).build(bits, p + 17, count))
+                return fail("bad Huffman table");
             p += 17 + count;
             len -= 17 + count;
         }
