@@ -22,8 +22,10 @@
 
 #if defined(__HIPCC__)
 #define WPT_RGL_HD __host__ __device__ __forceinline__
+#define WPT_RGL_ENTRY __host__ __device__ __attribute__((noinline))
 #else
 #define WPT_RGL_HD inline
+#define WPT_RGL_ENTRY inline
 #endif
 
 namespace wptrgl {
@@ -286,7 +288,7 @@ WPT_RGL_HD V3 rglColour(const wpt_rgl_brdf& b, const float* pool, V2 sample, flo
 
 /* BRDF::pdf (powitacq_rgb.inl:1016-1050) */
 template<class M>
-WPT_RGL_HD float rglPdf(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
+WPT_RGL_ENTRY float rglPdf(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
 {
     if (wi.z <= 0 || wo.z <= 0)
         return 0.0f;
@@ -312,7 +314,7 @@ WPT_RGL_HD float rglPdf(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
 
 /* BRDF::eval (powitacq_rgb.inl:1056-1100): f_r * cos */
 template<class M>
-WPT_RGL_HD V3 rglEval(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
+WPT_RGL_ENTRY V3 rglEval(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
 {
     V3 zero;
     zero.x = zero.y = zero.z = 0.0f;
@@ -347,7 +349,7 @@ WPT_RGL_HD V3 rglEval(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
 /* BRDF::sample (powitacq_rgb.inl:1106-1183): returns f_r * cos / pdf, the outgoing direction
  * (zero when the sample fails) and the pdf */
 template<class M>
-WPT_RGL_HD V3 rglSample(const wpt_rgl_brdf& b, const float* pool, V2 u, V3 wi, V3& woOut, float& pdfOut)
+WPT_RGL_ENTRY V3 rglSample(const wpt_rgl_brdf& b, const float* pool, V2 u, V3 wi, V3& woOut, float& pdfOut)
 {
     V3 zero;
     zero.x = zero.y = zero.z = 0.0f;
