@@ -127,7 +127,7 @@ WPT_D float hotSpotPdfValue(float4 g0, float4 g1, float4 g2, f3 org, f3 dir, con
 }
 
 /* HitableSphere::pdfValue (hitable_sphere.hpp:149-186) */
-WPT_D float spherePdfValue(const wpt_sphere& sp, const wpt_sphere& spHit, f3 org, f3 dir)
+WPT_CALL float spherePdfValue(const wpt_sphere& sp, const wpt_sphere& spHit, f3 org, f3 dir)
 {
     const f3 cmo = sub(ld3(sp.center), org);
     const float distanceSquared = dot(cmo, cmo);
@@ -148,7 +148,7 @@ WPT_D float spherePdfValue(const wpt_sphere& sp, const wpt_sphere& spHit, f3 org
 }
 
 /* HitableSphere::direction (hitable_sphere.hpp:188-219) */
-WPT_D f3 sphereDirection(const wpt_sphere& sp, f3 org, Prng& prng)
+WPT_CALL f3 sphereDirection(const wpt_sphere& sp, f3 org, Prng& prng)
 {
     const f3 cmo = sub(ld3(sp.center), org);
     const float distanceSquared = dot(cmo, cmo);

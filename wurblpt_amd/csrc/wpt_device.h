@@ -30,6 +30,8 @@
 namespace wptd {
 
 #define WPT_D __device__ __forceinline__
+/* code that few lanes run and that is large: a real call, so that it does not take registers from the common path */
+#define WPT_CALL static inline __device__ __attribute__((noinline))
 
 constexpr float k_pi = 3.1415926535897932384626433832795029L;
 constexpr float k_pi_2 = 1.5707963267948966192313216916397514L;
@@ -554,7 +556,7 @@ WPT_D wpt_sphere sphereMovedForPdf(const wpt_sphere& sp, const wptanim::Trs& T)
 }
 
 /* HitableSphere::constructHitRecord (hitable_sphere.hpp:42-75) */
-template<uint32_t F = 0> WPT_D Hit finishSphereHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir, float time = 0.0f)
+template<uint32_t F = 0> static __device__ __attribute__((noinline)) Hit finishSphereHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir, float time = 0.0f)
 {
     const wpt_sphere sp = sphereAt<F>(sv, sv.spheres[c.prim & ~PRIM_SPHERE], time);
     Hit h;

@@ -12,8 +12,10 @@
 
 #if defined(__HIPCC__)
 #define WPT_LENS_HD __host__ __device__ __forceinline__
+#define WPT_LENS_ENTRY static inline __host__ __device__ __attribute__((noinline))
 #else
 #define WPT_LENS_HD inline
+#define WPT_LENS_ENTRY inline
 #endif
 
 namespace wptlens {
@@ -39,7 +41,7 @@ WPT_LENS_HD void distort(const wpt_camera& c, float& p, float& q)
 }
 
 /* optics.hpp:241-308; width and height are the frame's (the iteration's error is measured in pixels) */
-WPT_LENS_HD void undistort(const wpt_camera& c, float& p, float& q, uint32_t width, uint32_t height)
+WPT_LENS_ENTRY void undistort(const wpt_camera& c, float& p, float& q, uint32_t width, uint32_t height)
 {
     if (c.distortion_type == WPT_DISTORTION_RADIAL_AND_PLANAR) {
         const float s = (p - c.dist_center[0]) * c.dist_inverse_focal_length[0];
