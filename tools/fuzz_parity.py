@@ -1,4 +1,4 @@
-"""usage (GPU box): python tools/fuzz_parity.py [rounds [seed]]
+"""usage (GPU box): python tools/fuzz_parity.py [rounds [seed [scale]]]
 Seeded random scenes of every family through the GPU and the CPU restatement: frames, work counters and the ground truth
 arrays must agree bit for bit.
 Prints one line per mismatch and a summary; exit code 1 if anything differed."""
@@ -14,6 +14,7 @@ from tests import oracle_loader
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 orc = oracle_loader.load("portable")
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # frames `scale` times wider and higher
 bad = 0
 done = 0
 t_start = time.time()
@@ -49,7 +50,7 @@ def check(label, sc, s, p=None, tables=False):
 
 for r in range(rounds):
     seed = int(rng.integers(1, 1 << 30))
-    w, h = int(rng.integers(17, 72)), int(rng.integers(9, 56))
+    w, h = scale * int(rng.integers(17, 72)), scale * int(rng.integers(9, 56))
     s = int(rng.integers(1, 4))
     p = host.default_params()
     p.max_path_components = int(rng.choice([2, 3, 8, 128]))
