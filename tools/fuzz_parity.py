@@ -1,6 +1,6 @@
 """usage (GPU box): python tools/fuzz_parity.py [rounds [seed [scale]]]
 Seeded random scenes of every family through the GPU and the CPU restatement: frames, work counters and the ground truth
-arrays must agree bit for bit.
+arrays must agree bit for bit; a random pixel block and a random split into interleaved bands must give the same frame.
 Prints one line per mismatch and a summary; exit code 1 if anything differed."""
 import os
 import sys
@@ -33,6 +33,22 @@ def check(label, sc, s, p=None, tables=False):
     got2, _ = ds.render(s, params=p)
     n1 = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
     n2 = int((got2.view(np.uint32) != ref.view(np.uint32)).sum())
+    # the same frame through a random block and through interleaved bands (one launch per "rank")
+    import torch
+    h_, w_ = got.shape[:2]
+    start = int(rng.integers(0, w_ * h_))
+    size = int(rng.integers(1, w_ * h_ - start + 1))
+    part, _ = ds.render(s, block=(start, size), params=p)
+    n4 = int((part.reshape(-1, 3)[start:start + size].view(np.uint32) != ref.reshape(-1, 3)[start:start + size].view(np.uint32)).sum())
+    n4 += int(np.count_nonzero(part.reshape(-1, 3)[:start])) + int(np.count_nonzero(part.reshape(-1, 3)[start + size:]))
+    band_rows, stride = int(rng.integers(1, 20)), int(rng.integers(1, 6))
+    total = np.zeros_like(ref)
+    for rank in range(stride):
+        fr = torch.zeros((h_, w_, 3), dtype=torch.float32, device="cuda")
+        ds.render_bands_into(fr, s, band_rows, rank, stride, params=p, stream=torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        total += fr.cpu().numpy()
+    n4 += int((total.view(np.uint32) != ref.view(np.uint32)).sum())
     # the ground truth pass of the same scene (pixel space flow only where the camera has an image plane)
     cam = sc.camera.contents
     bits = device.GT_ALL if (cam.surround_mode == 0 and cam.stereoscopic_distance <= 0.0) else device.GT_ALL & ~((1 << 17) | (1 << 18))
@@ -42,10 +58,10 @@ def check(label, sc, s, p=None, tables=False):
     ggot = device.ground_truth(ds, bits=bits, times=times)
     n3 = sum(int((ggot[k].view(np.uint32) != gref[k].view(np.uint32)).sum()) for k in gref)
     done += 1
-    if n1 or n2 or n3 or gc != rc:
+    if n1 or n2 or n3 or n4 or gc != rc:
         bad += 1
-        print("MISMATCH %s: %d / %d values differ (counting / product kernel), counters equal: %s, ground truth values differing: %d" % (
-            label, n1, n2, gc == rc, n3), flush=True)
+        print("MISMATCH %s: %d / %d values differ (counting / product kernel), counters equal: %s, ground truth values differing: %d, "
+              "block / bands values differing: %d" % (label, n1, n2, gc == rc, n3, n4), flush=True)
 
 
 for r in range(rounds):
