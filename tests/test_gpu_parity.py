@@ -682,6 +682,11 @@ def test_mcpt_host_api(dev, oracle):
     sc = host.cornell(64, 64, 1, 2)
     ref, _ = oracle.render(sc, 3)
     assert bits_equal(host.mcpt(sc, 3), ref)
+    # the several-devices path: an MPICoordinator with three worker threads (the one GPU named three times), blocks from
+    # the shared counter, every worker with its own upload of the scene
+    big = host.cornell(160, 120, 1, 2)
+    ref_big, _ = oracle.render(big, 2)
+    assert bits_equal(host.mcpt(big, 2, workers=3), ref_big)
     sc = host.sponza_like(64, 36, detail=0.05, tex_size=32, env_width=64, importance_n=16)
     sc.set_envmap_tables(*oracle.envmap_tables(sc))
     ref, _ = oracle.render(sc, 2)

@@ -238,15 +238,15 @@ def image_load(filename):
     return out
 
 
-def mcpt(scene, samples_sqrt, t0=0.0, t1=0.0, width=None, height=None):
+def mcpt(scene, samples_sqrt, t0=0.0, t1=0.0, width=None, height=None, workers=1):
     """mcpt() of include/wurblpt/wurblpt.hpp (needs a device): the scene, its camera and a SensorRGB through the C++
     host API an application uses; returns the frame [h, w, 3]."""
     w = width or scene.width
     h = height or scene.height
     frame = np.zeros((h, w, 3), np.float32)
     L = lib()
-    L.wpt_host_mcpt.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_float, C.c_float, C.c_void_p]
-    if not L.wpt_host_mcpt(scene._handle, w, h, samples_sqrt, t0, t1, C.c_void_p(frame.ctypes.data)):
+    L.wpt_host_mcpt.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_float, C.c_float, C.c_void_p, C.c_uint]
+    if not L.wpt_host_mcpt(scene._handle, w, h, samples_sqrt, t0, t1, C.c_void_p(frame.ctypes.data), workers):
         raise RuntimeError("mcpt failed")
     return frame
 

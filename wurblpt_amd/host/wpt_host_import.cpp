@@ -176,15 +176,22 @@ extern "C" int wpt_host_postproc(int op, unsigned int width, unsigned int height
 
 /* mcpt() of include/wurblpt/wurblpt.hpp -- the call an application makes -- for a scene of this library and the
  * camera it was finished with: renders width x height x samplesSqrt^2 over the exposure interval [t0, t1] on the
- * device(s) and copies the sensor's frame (row 0 = bottom) to `frame`.  devices: how many GPUs the MPICoordinator
- * may use (0 = all).  1 on success; failures inside mcpt() abort like the reference's asserts. */
+ * device and copies the sensor's frame (row 0 = bottom) to `frame`.  workers > 1: through an MPICoordinator with that
+ * many worker threads.  1 on success; failures inside mcpt() abort like the reference's asserts. */
 extern "C" int wpt_host_mcpt(wpt_host_scene* hs, unsigned int width, unsigned int height, unsigned int samplesSqrt, float t0, float t1,
-        float* frame)
+        float* frame, unsigned int workers)
 {
     Scene& scene = wptHostSceneOf(hs);
     if (scene.bvhNeedsUpdate(t0, t1))
         scene.updateBVH(t0, t1);
     SensorRGB sensor(width, height);
+    if (workers > 1) {
+        /* the several-devices path of mcpt() (one worker thread per entry, blocks from the shared counter), with the
+         * current device named `workers` times where there is only one GPU */
+        int device = 0;
+        MPICoordinator coordinator(4096, std::vector<int>(workers, device));
+        mcpt(coordinator, sensor, wptHostCameraObjectOf(hs), scene, samplesSqrt, t0, t1);
+    } else
     mcpt(sensor, wptHostCameraObjectOf(hs), scene, samplesSqrt, t0, t1);
     memcpy(frame, sensor.result().data(), size_t(width) * height * 3 * sizeof(float));
     return 1;
