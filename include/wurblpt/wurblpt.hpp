@@ -116,6 +116,17 @@ inline void mcpt(MPICoordinator& mpiCoordinator, Sensor& sensor, const Camera& c
             workerErrors[w] = wpt_last_error();
             return;
         }
+        if (mpiCoordinator.devices().size() > 1) {
+            /* several devices: a lane owns a pixel for all its samples, so a device is only as busy as it has pixels in
+             * flight.  Each device takes its share in ONE launch -- the bands of 16 rows whose index is w modulo the number
+             * of devices -- and writes them into the shared frame (wurblpt_hip.h: wpt_render_bands). */
+            const unsigned int count = mpiCoordinator.devices().size();
+            fprintf(stderr, "%s: device %d renders bands %zu, %zu, ... of 16 rows\n", mpiCoordinator.processId(), device, w, w + count);
+            if (wpt_render_bands(dscene, &cam, &p, width, height, samplesSqrt, 16, w, count, mpiCoordinator.blockData(0)) != WPT_OK)
+                workerErrors[w] = wpt_last_error();
+            wpt_scene_free(dscene);
+            return;
+        }
         for (;;) {
             unsigned int blockStart, blockSize;
             mpiCoordinator.getBlock(&blockStart, &blockSize);

@@ -346,6 +346,12 @@ wpt_status wpt_render_bands_device(wpt_scene* scene, const wpt_camera* camera,
         uint32_t band_rows, uint32_t first_band, uint32_t band_stride,
         float* frame_device, wpt_counters* counters_device, void* hip_stream);
 
+/* Synchronous form for host frames: renders the same bands and writes their pixels into `frame_host`, the FULL frame
+ * float[height][width][3] in host memory; the other bands are left as they are (several devices fill one frame). */
+wpt_status wpt_render_bands(wpt_scene* scene, const wpt_camera* camera, const wpt_params* params,
+        uint32_t width, uint32_t height, uint32_t samples_sqrt, uint32_t band_rows, uint32_t first_band, uint32_t band_stride,
+        float* frame_host);
+
 /* Synchronous form with MPICoordinator::submitBlock semantics (mpi.hpp:256-262):
  * writes block_size*3 floats for the block's pixels to host memory `block_rgb`. */
 wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera,

@@ -682,8 +682,8 @@ def test_mcpt_host_api(dev, oracle):
     sc = host.cornell(64, 64, 1, 2)
     ref, _ = oracle.render(sc, 3)
     assert bits_equal(host.mcpt(sc, 3), ref)
-    # the several-devices path: an MPICoordinator with three worker threads (the one GPU named three times), blocks from
-    # the shared counter, every worker with its own upload of the scene
+    # the several-devices path: an MPICoordinator with three worker threads (the one GPU named three times), every worker
+    # with its own upload of the scene and its interleaved bands in one launch (wpt_render_bands)
     big = host.cornell(160, 120, 1, 2)
     ref_big, _ = oracle.render(big, 2)
     assert bits_equal(host.mcpt(big, 2, workers=3), ref_big)

@@ -827,6 +827,33 @@ wpt_status wpt_render_bands_device(wpt_scene* scene, const wpt_camera* camera, c
             band_stride, frame_device, counters_device, hip_stream);
 }
 
+wpt_status wpt_render_bands(wpt_scene* scene, const wpt_camera* camera, const wpt_params* params,
+        uint32_t width, uint32_t height, uint32_t samples_sqrt, uint32_t band_rows, uint32_t first_band, uint32_t band_stride,
+        float* frame_host)
+{
+    if (!frame_host)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "frame_host is NULL");
+    if (width == 0 || height == 0 || band_rows == 0 || band_stride == 0)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "bands need a frame, band_rows > 0 and band_stride > 0");
+    float* dFrame = nullptr;
+    const size_t rowBytes = size_t(width) * 3 * sizeof(float);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dFrame), rowBytes * height));
+    wpt_status st = wpt_render_bands_device(scene, camera, params, width, height, samples_sqrt, band_rows, first_band, band_stride, dFrame, nullptr,
+            nullptr);
+    if (st == WPT_OK)
+        st = wpt_scene_check(scene);
+    for (uint64_t band = first_band; st == WPT_OK && band * band_rows < height; band += band_stride) {
+        const size_t row0 = size_t(band) * band_rows;
+        const size_t rows = row0 + band_rows <= height ? band_rows : height - row0;
+        hipError_t e = hipMemcpy(reinterpret_cast<char*>(frame_host) + row0 * rowBytes, reinterpret_cast<char*>(dFrame) + row0 * rowBytes, rows * rowBytes,
+                hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            st = fail(WPT_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(dFrame);
+    return st;
+}
+
 wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera, const wpt_params* params, uint32_t width,
         uint32_t height, uint32_t samples_sqrt, uint32_t block_start, uint32_t block_size, float* block_rgb)
 {
