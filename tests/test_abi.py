@@ -156,3 +156,11 @@ def test_product_does_not_touch_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "include")):
         for f in files:
             assert "liboracle" not in open(os.path.join(dirpath, f)).read()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/wurblpt_hip.h is the boundary for any language with a C FFI: it compiles as C99 with -pedantic."""
+    src = tmp_path / "cabi.c"
+    src.write_text('#include "wurblpt_hip.h"\nint main(void) { wpt_params p; wpt_camera c; (void)p; (void)c; return (int)wpt_gt_components[0] - 3; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", str(src), "-o",
+                    str(tmp_path / "cabi.o")], check=True, timeout=120)
