@@ -94,7 +94,7 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 0x20, 0x22, 0x10, 0x11, 0x12, 0x40, 0x41, 0x42, 0x48, 0x4a])
+@pytest.mark.parametrize("variant", [0, 1, 2, 0x80, 0x82, 0xa0, 0x20, 0x22, 0x10, 0x11, 0x12, 0x40, 0x41, 0x42, 0x48, 0x4a])
 def test_kernel_variants_agree_bit_for_bit(dev, oracle, variant):
     """0 = scene in LDS, 1 = scene fetched from HBM/L2, 2 = the all-features kernel;
     +0x20 = separate SHADE / NEE-END / NEW rounds instead of the fused long round;

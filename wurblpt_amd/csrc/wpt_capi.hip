@@ -783,7 +783,11 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
         else
             launchWfFull(args, wfGrid, wfBytes, stream);
     } else if (singleRole) {
-        if (basic && lds)
+        /* a launch that cannot put more than two waves on a SIMD takes the paired-step build (variant bit 0x80: never) */
+        const bool starved = uint64_t(block_size) <= uint64_t(scene->cuCount) * 4u * 2u * 64u && (g_variant & 0x80u) == 0;
+        if (basic && lds && starved)
+            launchBasicLdsPairs(args, grid, ldsBytes, stream);
+        else if (basic && lds)
             launchBasicLds(args, grid, ldsBytes, stream);
         else if (basic)
             launchBasic(args, grid, stream);

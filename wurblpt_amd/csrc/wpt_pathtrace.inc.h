@@ -430,6 +430,7 @@ struct GroundTruthArgs {
 void launchGroundTruth(const GroundTruthArgs& args, hipStream_t stream);
 
 void launchBasicLds(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream);
+void launchBasicLdsPairs(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream);
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream);
