@@ -84,6 +84,8 @@ def _corruptions():
     cases = [
         (cornell, "abi version", lambda d: setattr(d, "abi_version", d.abi_version + 1), "ABI"),
         (cornell, "inner node link", lambda d: setattr(d.nodes[0], "link", 10 ** 6), "BVH"),
+        (cornell, "shared child (both children of the root are node 1)", lambda d: setattr(d.nodes[0], "link", 1), "depth-first"),
+        (cornell, "unreachable node (the root's second child starts one node late)", lambda d: setattr(d.nodes[0], "link", d.nodes[0].link + 1), "depth-first"),
         (cornell, "leaf triangle", lambda d: setattr(first(d, d.nodes, d.node_count, lambda n: n.kind == 1), "link", d.tri_count), "BVH"),
         (cornell, "node kind", lambda d: setattr(d.nodes[1], "kind", 9), "BVH"),
         (cornell, "triangle instance", lambda d: setattr(d.tri_geom[3], "instance", d.instance_count), "instance"),
@@ -117,7 +119,7 @@ def _corruptions():
     return cases
 
 
-@pytest.mark.parametrize("case", range(31))
+@pytest.mark.parametrize("case", range(33))
 def test_upload_validation_rejects_bad_scene(case):
     """Every index and size the kernels follow is checked on the host before anything reaches the GPU: a description
     with one of them out of range is refused with a message that names the table (no device needed to find out)."""

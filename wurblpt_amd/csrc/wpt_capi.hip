@@ -232,6 +232,25 @@ wpt_status validate(const wpt_scene_desc* d)
             return fail(WPT_ERR_UNSUPPORTED, "BVH node kind is not known to the kernel");
         }
     }
+    {
+        /* ... and the links must describe ONE depth-first tree over all nodes: the first child of an inner node is the
+         * next node, its second child (link) starts where the first child's subtree ends.  Links that are merely in
+         * range could share children (the device form would grow without bound) or leave nodes unreachable (the walk
+         * would run into records nobody wrote).  One reverse pass: end[i] = first node behind the subtree of node i. */
+        std::vector<uint32_t> end(d->node_count);
+        for (uint32_t i = d->node_count; i-- > 0;) {
+            const wpt_bvh_node& n = d->nodes[i];
+            if (n.kind == WPT_NODE_INNER) {
+                if (n.link != end[i + 1])
+                    return fail(WPT_ERR_INVALID_ARGUMENT, "BVH nodes are not one depth-first tree (second child does not follow the first child's subtree)");
+                end[i] = end[n.link];
+            } else {
+                end[i] = i + 1;
+            }
+        }
+        if (end[0] != d->node_count)
+            return fail(WPT_ERR_INVALID_ARGUMENT, "BVH nodes are not one depth-first tree (nodes behind the root's subtree)");
+    }
     for (uint32_t i = 0; i < d->tri_count; i++) {
         if (d->tri_geom[i].instance >= d->instance_count || d->tri_geom[i].material >= d->material_count)
             return fail(WPT_ERR_INVALID_ARGUMENT, "triangle references an instance or material outside the arrays");
@@ -425,6 +444,10 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
                     out[2 * size_t(it.pos) + 1].z = sk;
                     continue;
                 }
+                if (cursor >= n) { /* cannot happen after validate(); keeps the conversion inside `dev` whatever comes in */
+                    wpt_scene_free(s);
+                    return fail(WPT_ERR_INVALID_ARGUMENT, "BVH conversion: the links describe more nodes than the array holds");
+                }
                 const uint32_t pos = cursor++;
                 const uint32_t prim = nd.kind == WPT_NODE_INNER ? NODE_INNER : nd.kind == WPT_NODE_TRIANGLE ? nd.link
                     : nd.kind == WPT_NODE_SPHERE ? (PRIM_SPHERE | nd.link) : NODE_EMPTY;
@@ -447,6 +470,10 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
                     stack.push_back(Item { second, 0, false }); /* popped after the first subtree */
                     stack.push_back(Item { first, 0, false });
                 }
+            }
+            if (cursor != n) {
+                wpt_scene_free(s);
+                return fail(WPT_ERR_INVALID_ARGUMENT, "BVH conversion: the links do not reach every node");
             }
         }
         UP(uploadArray(s, dev.data(), dev.size(), &nodes));
