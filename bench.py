@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--verify", action="store_true",
                     help="after the timed steps rank 0 renders the frame once more in a single launch and compares (bit for bit)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant / scheduler tuning word for wpt_set_launch_config (experiments)")
+    ap.add_argument("--top-nodes", type=int, default=-1, help="BVH nodes stored level by level in front of the array (wpt_set_top_nodes; experiments)")
     args = ap.parse_args()
 
     import numpy as np
@@ -172,6 +173,8 @@ def main():
     scene = build_scene(w)
     if args.variant:
         device.lib().wpt_set_launch_config(0, args.variant)
+    if args.top_nodes >= 0:
+        device.lib().wpt_set_top_nodes(args.top_nodes)
     dscene = device.DeviceScene(scene)
     params = host.default_params()
     frame = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")

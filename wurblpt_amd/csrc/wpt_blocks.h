@@ -8,8 +8,18 @@
  *   blockNeeEnd  the next-event ray came back: add its contribution (wurblpt.hpp:203-218,236-250)
  *
  * each followed by `advancePath` (wurblpt.hpp:254-273) where the path continues.  They return
- * what the lane needs next: a ray to be traced (ps.ray / ps.rayKind are set), a new sample, or
+ * what the lane needs next: a ray to be traced (ps.o / ps.d / ps.rayKind are set), a new sample, or
  * nothing more (all samples done).  The traversal of the ray is the kernel's business.
+ *
+ * Where a path's state lives.  A lane walks one pixel's paths; between two blocks it traverses, and all it
+ * needs for that is the ray.  Everything else a path carries (generator, accumulators, attenuations, the
+ * continuation while a next-event ray is in flight: 32 words) is COLD while the lane traverses, and in the
+ * blocks each word is needed at one or two places only.  The path tracing kernels therefore keep the cold
+ * words in LDS (PathLds: eight 16-byte slots per lane, lane-major, so that every access is a conflict-free
+ * ds_read_b128 / ds_write_b128) and the blocks below fetch a slot where they use it and store it where its
+ * value is final.  Registers then hold what the running block works on, not what other lanes of the wave
+ * will need later: that is what used to spill to scratch memory at four waves per SIMD.  The ground truth
+ * kernel, one ray per lane, uses the same blocks over plain registers (PathRegs).
  */
 #ifndef WPT_BLOCKS_H
 #define WPT_BLOCKS_H
@@ -35,36 +45,87 @@ struct LaneCounters {
     unsigned long long shadeClock[8];
 };
 
-/* everything a pixel's path carries between blocks (registers) */
-struct PathState {
-    Prng prng;
-    float acc0, acc1, acc2;
-    uint32_t px, py;
-    uint32_t sampleIndex, pathComponent;
+/* ---- the cold words of a path, by slot (x, y, z, w) ----
+ *   0 prng s0 s1 s2 s3        1 att                      2 ray.ri (refractiveIndex)    3 nextAtt
+ *   4 acc r g b, sample       5 opl x y z, pathComponent 6 neeFactor r g b, chosenPrim 7 srDir x y z, pixel
+ * sample = the next sample's stratum, column | row << 16 (row == samplesSqrt: all done); pixel = x | y << 16
+ * (launches check samples_sqrt, width and height against 65535): no division per sample.
+ * opticalPathLength and the next-event factor have three channels here: SensorRGB reads channels 0..2 only
+ * (sensor_rgb.hpp:63-80), and nothing else reads their fourth. */
+enum { SLOT_PRNG = 0, SLOT_ATT = 1, SLOT_RI = 2, SLOT_NEXTATT = 3, SLOT_ACC = 4, SLOT_OPL = 5, SLOT_NEE = 6, SLOT_SRDIR = 7, SLOT_COUNT = 8 };
+
+struct Slot {
+    float x, y, z;
+    uint32_t w;
+};
+
+/* what both kinds of path state share: the words that stay in registers */
+struct PathHot {
+    f3 o, d;      /* the ray being traced (Ray::origin, Ray::direction) */
     int rayKind;
-    Ray ray;
-    f4 att;
-    f3 opl; /* opticalPathLength; SensorRGB reads channels 0..2 only */
-    /* continuation of the path while a next-event ray is in flight */
-    f4 nextAtt;
-    f4 neeFactor; /* attenuation * directSR.attenuation / directPdf * weight (wurblpt.hpp:211,243) */
-    f3 srDir;
-    uint32_t chosenPrim;
-    float time; /* FEAT_ANIM: the path's time (Ray::time; the thread's AnimationCache is set to it, wurblpt.hpp:361) */
-    /* FEAT_ANIM: the lane's AnimationCache, one entry deep -- the matrix of the animation it used last at ps.time.
+    float time;   /* FEAT_ANIM: the path's time (Ray::time; the thread's AnimationCache is set to it, wurblpt.hpp:361) */
+    /* FEAT_ANIM: the lane's AnimationCache, one entry deep -- the matrix of the animation it used last at `time`.
      * Consecutive leaf tests of a walk mostly hit triangles of one instance, and the lights share few animations. */
     int animCached;
     float animM[16];
 };
 
+/* cold words in LDS: `base` is this lane's first slot, slot k lies k * STRIDE float4 further */
+template<int STRIDE> struct PathLds : PathHot {
+    float4* base;
+    WPT_D f4 get4(int k) const { const float4 v = base[k * STRIDE]; return mk4(v.x, v.y, v.z, v.w); }
+    WPT_D void set4(int k, f4 v) { base[k * STRIDE] = make_float4(v.x, v.y, v.z, v.w); }
+    WPT_D Slot get(int k) const
+    {
+        const float4 v = base[k * STRIDE];
+        Slot s;
+        s.x = v.x; s.y = v.y; s.z = v.z; s.w = __float_as_uint(v.w);
+        return s;
+    }
+    WPT_D void set(int k, Slot s) { base[k * STRIDE] = make_float4(s.x, s.y, s.z, __uint_as_float(s.w)); }
+    WPT_D void set3(int k, f3 v) /* x, y, z only: w keeps its value */
+    {
+        float* p = reinterpret_cast<float*>(base + k * STRIDE);
+        p[0] = v.x; p[1] = v.y; p[2] = v.z;
+    }
+    WPT_D uint32_t getW(int k) const { return reinterpret_cast<const uint32_t*>(base + k * STRIDE)[3]; }
+    WPT_D void setW(int k, uint32_t w) { reinterpret_cast<uint32_t*>(base + k * STRIDE)[3] = w; }
+};
+
+/* cold words in registers (one ray per lane: the ground truth kernel) */
+struct PathRegs : PathHot {
+    Slot slot[SLOT_COUNT];
+    WPT_D f4 get4(int k) const { return mk4(slot[k].x, slot[k].y, slot[k].z, __uint_as_float(slot[k].w)); }
+    WPT_D void set4(int k, f4 v) { slot[k].x = v.x; slot[k].y = v.y; slot[k].z = v.z; slot[k].w = __float_as_uint(v.w); }
+    WPT_D Slot get(int k) const { return slot[k]; }
+    WPT_D void set(int k, Slot s) { slot[k] = s; }
+    WPT_D void set3(int k, f3 v) { slot[k].x = v.x; slot[k].y = v.y; slot[k].z = v.z; }
+    WPT_D uint32_t getW(int k) const { return slot[k].w; }
+    WPT_D void setW(int k, uint32_t w) { slot[k].w = w; }
+};
+
+template<class PS> WPT_D Prng loadPrng(const PS& ps)
+{
+    const Slot s = ps.get(SLOT_PRNG);
+    Prng p;
+    p.s0 = __float_as_uint(s.x); p.s1 = __float_as_uint(s.y); p.s2 = __float_as_uint(s.z); p.s3 = s.w;
+    return p;
+}
+template<class PS> WPT_D void storePrng(PS& ps, const Prng& p)
+{
+    Slot s;
+    s.x = __uint_as_float(p.s0); s.y = __uint_as_float(p.s1); s.z = __uint_as_float(p.s2); s.w = p.s3;
+    ps.set(SLOT_PRNG, s);
+}
+
 /* AnimationCache::getM(ai) at the path's time.  Spheres do not go through it: measured on the test scene, sharing the
  * entry with them lets sphere and triangle leaves evict each other (162 -> 141 Msamples/s) and an entry of their own
  * is evicted by the next sphere (158), so their transformation is evaluated where it is needed. */
-WPT_D wptanim::Trs animationTrs(const SceneView& sv, PathState& ps, int ai)
+WPT_D wptanim::Trs animationTrs(const SceneView& sv, const PathHot& ps, int ai)
 {
     return animationAt(sv, ai, ps.time);
 }
-WPT_D const float* animationMatrix(const SceneView& sv, PathState& ps, int ai)
+WPT_D const float* animationMatrix(const SceneView& sv, PathHot& ps, int ai)
 {
     if (ps.animCached != ai) {
         wptanim::toMat4(animationAt(sv, ai, ps.time), ps.animM);
@@ -73,7 +134,7 @@ WPT_D const float* animationMatrix(const SceneView& sv, PathState& ps, int ai)
     return ps.animM;
 }
 /* an animated sphere at the path's time, through the lane's cache: as hit() / direction() place it */
-template<uint32_t F> WPT_D wpt_sphere sphereNow(const SceneView& sv, PathState& ps, const wpt_sphere& sp)
+template<uint32_t F> WPT_D wpt_sphere sphereNow(const SceneView& sv, const PathHot& ps, const wpt_sphere& sp)
 {
     if ((F & FEAT_ANIM) && sp.animation >= 0)
         return sphereMoved(sp, animationTrs(sv, ps, sp.animation));
@@ -84,26 +145,50 @@ struct FrameArgs {
     wpt_camera cam;
     wpt_params par;
     uint32_t width, height, samplesSqrt;
+    /* 1.0f / (float)width, / height, / samplesSqrt: divided once on the host (IEEE, the same bits) */
+    float invWidth, invHeight, invSamplesSqrt;
 };
 
-WPT_D void pathStateInit(PathState& ps, uint32_t pixel, uint32_t width)
+/* A uniform value as the compiler must take it where it stands (a scalar register, no instruction).  Values that
+ * depend only on the launch arguments are loop invariant, float arithmetic on them has no scalar form on gfx950,
+ * so the compiler computes e.g. a pinhole camera's origin once in front of the kernel's loop into VECTOR registers
+ * that then stay occupied (or spill) for the whole kernel.  Behind this fence the arithmetic stays where it is used. */
+WPT_D float here(float x)
 {
-    prngSeed(ps.prng, pixel);
-    ps.acc0 = ps.acc1 = ps.acc2 = 0.0f;
-    ps.px = pixel % width;
-    ps.py = pixel / width;
-    ps.sampleIndex = 0;
-    ps.pathComponent = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* (the value is the same in all lanes; should the compiler hold it in a vector register, this takes it from there) */
+    int bits = __builtin_amdgcn_readfirstlane(__float_as_int(x));
+    asm volatile("" : "+s"(bits));
+    x = __int_as_float(bits);
+#endif
+    return x;
+}
+
+template<class PS> WPT_D void pathStateInit(PS& ps, uint32_t pixel, uint32_t px, uint32_t py)
+{
+    Prng prng;
+    prngSeed(prng, pixel);
+    storePrng(ps, prng);
+    const f4 one = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+    ps.set4(SLOT_ATT, one);
+    ps.set4(SLOT_RI, one);
+    ps.set4(SLOT_NEXTATT, one);
+    Slot z;
+    z.x = z.y = z.z = 0.0f;
+    z.w = 0;
+    ps.set(SLOT_ACC, z); /* stratum (0, 0) */
+    ps.set(SLOT_OPL, z); /* pathComponent 0 */
+    Slot n;
+    n.x = n.y = n.z = 1.0f;
+    n.w = NO_HIT;
+    ps.set(SLOT_NEE, n);
+    Slot s;
+    s.x = 0.0f; s.y = 0.0f; s.z = 1.0f;
+    s.w = px | (py << 16);
+    ps.set(SLOT_SRDIR, s);
+    ps.o = mk3(0.0f, 0.0f, 0.0f);
+    ps.d = mk3(0.0f, 0.0f, 1.0f);
     ps.rayKind = RAY_PATH;
-    ps.ray.o = mk3(0.0f, 0.0f, 0.0f);
-    ps.ray.d = mk3(0.0f, 0.0f, 1.0f);
-    ps.ray.ri = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-    ps.att = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-    ps.opl = mk3(0.0f, 0.0f, 0.0f);
-    ps.nextAtt = ps.att;
-    ps.neeFactor = ps.att;
-    ps.srDir = ps.ray.d;
-    ps.chosenPrim = NO_HIT;
     ps.time = 0.0f;
     ps.animCached = -1;
 }
@@ -147,24 +232,33 @@ WPT_CALL float spherePdfValue(const wpt_sphere& sp, const wpt_sphere& spHit, f3 
     return value;
 }
 
-/* HitableSphere::direction (hitable_sphere.hpp:188-219) */
-WPT_CALL f3 sphereDirection(const wpt_sphere& sp, f3 org, Prng& prng)
+/* HitableSphere::direction (hitable_sphere.hpp:188-219).  The generator travels by value, in and out: a reference
+ * would pin the caller's copy to scratch memory, because this is a real call. */
+struct DirectionDraw {
+    f3 dir;
+    Prng prng;
+};
+WPT_CALL DirectionDraw sphereDirection(const wpt_sphere& sp, f3 org, Prng prng)
 {
+    DirectionDraw r;
     const f3 cmo = sub(ld3(sp.center), org);
     const float distanceSquared = dot(cmo, cmo);
     const float radiusSquared = sp.radius * sp.radius;
-    if (distanceSquared <= radiusSquared)
-        return onUnitSphere(in01x2(prng));
-    const float discriminant = 1.0f - radiusSquared / distanceSquared;
-    const float cosThetaMax = discriminant > 0.0f ? __builtin_sqrtf(discriminant) : 0.0f;
-    return toSphere(normalize(cmo), cosThetaMax, in01x2(prng));
+    if (distanceSquared <= radiusSquared) {
+        r.dir = onUnitSphere(in01x2(prng));
+    } else {
+        const float discriminant = 1.0f - radiusSquared / distanceSquared;
+        const float cosThetaMax = discriminant > 0.0f ? __builtin_sqrtf(discriminant) : 0.0f;
+        r.dir = toSphere(normalize(cmo), cosThetaMax, in01x2(prng));
+    }
+    r.prng = prng;
+    return r;
 }
 
-/* mean pdf over all hot spots of hitting them from org along dir (wurblpt.hpp:181-184) */
+/* mean pdf over all hot spots of hitting them from org along dir (wurblpt.hpp:181-184); `h` = rayAux(dir) */
 template<uint32_t F, bool COUNT, class Tri4>
-WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, PathState& ps, LaneCounters& lc)
+WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, const RayAux& h, PathHot& ps, LaneCounters& lc)
 {
-    const RayAux h = rayAux(dir);
     float sum = 0.0f;
     for (uint32_t i = 0; i < sv.hotspotCount; i++) {
         const uint32_t p = sv.hotspots[i].prim;
@@ -195,60 +289,68 @@ WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, Path
     return sum;
 }
 
-/* SensorRGB::accumulateRadiance (sensor_rgb.hpp:63-80) */
-WPT_D void accumulateRadiance(const wpt_params& par, f3 opl, float distanceToLight, f4 radiance, PathState& ps)
+/* SensorRGB::accumulateRadiance (sensor_rgb.hpp:63-80): read - add - write of the accumulator slot; a closed
+ * distance gate adds nothing, so the slot is not touched then */
+template<class PS> WPT_D void accumulateRadiance(const wpt_params& par, f3 opl, float distanceToLight, f4 radiance, PS& ps)
 {
     const bool dOk = distanceToLight >= par.min_dist_to_light && distanceToLight <= par.max_dist_to_light;
-    if (dOk && opl.x >= par.min_path_len && opl.x <= par.max_path_len)
-        ps.acc0 += radiance.x;
-    if (dOk && opl.y >= par.min_path_len && opl.y <= par.max_path_len)
-        ps.acc1 += radiance.y;
-    if (dOk && opl.z >= par.min_path_len && opl.z <= par.max_path_len)
-        ps.acc2 += radiance.z;
+    if (!dOk)
+        return;
+    Slot acc = ps.get(SLOT_ACC);
+    if (opl.x >= par.min_path_len && opl.x <= par.max_path_len)
+        acc.x += radiance.x;
+    if (opl.y >= par.min_path_len && opl.y <= par.max_path_len)
+        acc.y += radiance.y;
+    if (opl.z >= par.min_path_len && opl.z <= par.max_path_len)
+        acc.z += radiance.z;
+    ps.set3(SLOT_ACC, mk3(acc.x, acc.y, acc.z));
 }
 
-/* wurblpt.hpp:254-273: continue along the scattered direction (ps.ray.o already is the hit
- * position, ps.ray.ri the index to continue with), Russian roulette */
-WPT_D int advancePath(const wpt_params& par, PathState& ps)
+/* wurblpt.hpp:254-273: continue along the scattered direction (ps.o already is the hit position, the ray's
+ * refractive index the one to continue with), Russian roulette.  nextAtt / srDir / pathComponent are the
+ * path's values, handed over by the caller who has them at hand; prng is the caller's copy of the generator
+ * (the caller stores it afterwards). */
+template<class PS> WPT_D int advancePath(const wpt_params& par, PS& ps, f4 nextAtt, f3 srDir, uint32_t pathComponent, Prng& prng)
 {
-    ps.att = ps.nextAtt;
-    ps.ray.d = ps.srDir;
-    const float mx = max4(ps.att);
-    if (mx < par.rr_threshold && ps.pathComponent >= 5) {
+    f4 att = nextAtt;
+    ps.d = srDir;
+    const float mx = max4(att);
+    if (mx < par.rr_threshold && pathComponent >= 5) {
         const float q = clampr(1.0f - mx, 0.0f, 0.95f);
-        if (in01(ps.prng) < q)
+        if (in01(prng) < q)
             return NEXT_NEW;
         const float rrWeight = 1.0f / (1.0f - q);
-        ps.att = sclr(ps.att, rrWeight);
+        att = sclr(att, rrWeight);
     }
-    ps.pathComponent++;
+    ps.set4(SLOT_ATT, att);
+    ps.setW(SLOT_OPL, pathComponent + 1);
     ps.rayKind = RAY_PATH;
     return NEXT_TRACE;
 }
 
 /* wurblpt.hpp:348-360 + Camera::getRay (camera.hpp:123-185), pinhole or thin lens */
-template<uint32_t F>
-WPT_D int blockNew(const FrameArgs& fa, PathState& ps, const SceneView* sv = nullptr)
+template<uint32_t F, class PS>
+WPT_D int blockNew(const FrameArgs& fa, PS& ps, const SceneView* sv = nullptr)
 {
-    const uint32_t samples = fa.samplesSqrt * fa.samplesSqrt;
-    if (ps.sampleIndex >= samples)
+    const uint32_t stratum = ps.getW(SLOT_ACC);
+    const uint32_t i = stratum & 0xffffu, j = stratum >> 16; /* sampleIndex % samplesSqrt, sampleIndex / samplesSqrt */
+    if (j >= fa.samplesSqrt)
         return NEXT_DONE;
-    float u = (float)ps.px, v = (float)ps.py;
+    const uint32_t pxy = ps.getW(SLOT_SRDIR);
+    Prng prng = loadPrng(ps);
+    float u = (float)(pxy & 0xffffu), v = (float)(pxy >> 16);
     if (fa.par.randomize_ray_over_pixel) {
         /* stratified jitter; the reference compiler draws the vertical stratum first */
-        const uint32_t j = ps.sampleIndex / fa.samplesSqrt;
-        const uint32_t i = ps.sampleIndex % fa.samplesSqrt;
-        const float fj = (float)j + in01(ps.prng);
-        const float fi = (float)i + in01(ps.prng);
-        const float invSamplesSqrt = 1.0f / (float)fa.samplesSqrt;
-        u += fi * invSamplesSqrt;
-        v += fj * invSamplesSqrt;
+        const float fj = (float)j + in01(prng);
+        const float fi = (float)i + in01(prng);
+        u += fi * fa.invSamplesSqrt;
+        v += fj * fa.invSamplesSqrt;
     } else {
         u += 0.5f;
         v += 0.5f;
     }
-    u *= 1.0f / (float)fa.width;
-    v *= 1.0f / (float)fa.height;
+    u *= fa.invWidth;
+    v *= fa.invHeight;
     /* Camera::getRay (camera.hpp:123-185) */
     float stereoscopicShift = 0.0f;
     if ((F & FEAT_LENS) && fa.cam.stereoscopic_distance > 0.0f) {
@@ -273,12 +375,12 @@ WPT_D int blockNew(const FrameArgs& fa, PathState& ps, const SceneView* sv = nul
     } else {
         /* the samples lie in the distorted output image: rays are made from the undistorted coordinates */
         if ((F & FEAT_LENS) && fa.cam.distortion_type != WPT_DISTORTION_NONE)
-            wptlens::undistort(fa.cam, u, v, fa.width, fa.height);
-        f3 P = mk3(mixr(fa.cam.l, fa.cam.r, u), mixr(fa.cam.b, fa.cam.t, v), -1.0f);
+            wptlens::undistort(fa.cam, u, v, fa.width, fa.height); /* a real call; the coefficients travel by value */
+        f3 P = mk3(mixr(here(fa.cam.l), here(fa.cam.r), u), mixr(here(fa.cam.b), here(fa.cam.t), v), -1.0f);
         O = mk3(0.0f, 0.0f, 0.0f);
         if ((F & FEAT_LENS) && fa.cam.lens_radius > 0.0f) {
             P = sclr(P, fa.cam.focus_dist);
-            f2 d = inUnitDisk(in01x2(ps.prng));
+            f2 d = inUnitDisk(in01x2(prng));
             O = mk3(fa.cam.lens_radius * d.x, fa.cam.lens_radius * d.y, 0.0f);
         }
         D = sub(P, O);
@@ -286,47 +388,61 @@ WPT_D int blockNew(const FrameArgs& fa, PathState& ps, const SceneView* sv = nul
     }
     if ((F & FEAT_ANIM) && fa.par.t0 != fa.par.t1) {
         /* camera.hpp:175-184: the ray draws its time in the exposure interval; a moving camera is taken at that time */
-        const float t = fa.par.t0 + in01(ps.prng) * (fa.par.t1 - fa.par.t0);
+        const float t = fa.par.t0 + in01(prng) * (fa.par.t1 - fa.par.t0);
         ps.time = t;
         ps.animCached = -1; /* AnimationCache::init(r.time) */
         if (fa.cam.animation >= 0 && sv) {
             const wptanim::Trs T = animationAt(*sv, fa.cam.animation, t);
-            ps.ray.o = add(ld3(T.t), quatRotate(T.q, mul(O, ld3(T.s))));
-            ps.ray.d = normalize(quatRotate(T.q, D));
+            ps.o = add(ld3(T.t), quatRotate(T.q, mul(O, ld3(T.s))));
+            ps.d = normalize(quatRotate(T.q, D));
         } else {
-            ps.ray.o = add(ld3(fa.cam.translation), quatRotate(fa.cam.rotation, mul(O, ld3(fa.cam.scaling))));
-            ps.ray.d = normalize(quatRotate(fa.cam.rotation, D));
+            ps.o = add(ld3(fa.cam.translation), quatRotate(fa.cam.rotation, mul(O, ld3(fa.cam.scaling))));
+            ps.d = normalize(quatRotate(fa.cam.rotation, D));
         }
     } else {
         if (F & FEAT_ANIM)
             ps.time = fa.par.t0;
-        ps.ray.o = add(ld3(fa.cam.translation), quatRotate(fa.cam.rotation, mul(O, ld3(fa.cam.scaling))));
-        ps.ray.d = normalize(quatRotate(fa.cam.rotation, D));
+        const float rotation[4] = { here(fa.cam.rotation[0]), here(fa.cam.rotation[1]), here(fa.cam.rotation[2]), here(fa.cam.rotation[3]) };
+        const f3 translation = mk3(here(fa.cam.translation[0]), here(fa.cam.translation[1]), here(fa.cam.translation[2]));
+        const f3 scaling = mk3(here(fa.cam.scaling[0]), here(fa.cam.scaling[1]), here(fa.cam.scaling[2]));
+        ps.o = add(translation, quatRotate(rotation, mul(O, scaling)));
+        ps.d = normalize(quatRotate(rotation, D));
     }
-    ps.ray.ri = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-    ps.att = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-    ps.opl = mk3(0.0f, 0.0f, 0.0f);
-    ps.pathComponent = 0;
-    ps.sampleIndex++;
+    storePrng(ps, prng);
+    const f4 one = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+    ps.set4(SLOT_RI, one);
+    ps.set4(SLOT_ATT, one);
+    Slot opl;
+    opl.x = opl.y = opl.z = 0.0f;
+    opl.w = 0; /* pathComponent */
+    ps.set(SLOT_OPL, opl);
+    ps.setW(SLOT_ACC, i + 1 < fa.samplesSqrt ? stratum + 1 : (j + 1) << 16);
     ps.rayKind = RAY_PATH;
     return NEXT_TRACE;
 }
 
 /* tracePath, one path component (wurblpt.hpp:131-252); `best` is the path ray's result */
-template<uint32_t F, bool COUNT, class Tri4>
-WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PathState& ps, const Candidate& best, LaneCounters& lc)
+template<uint32_t F, bool COUNT, class Tri4, class PS>
+WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& ps, const Candidate& best, LaneCounters& lc)
 {
     const bool haveEnv = (F & FEAT_ENVMAP) && sv.envType != WPT_ENV_NONE;
     if (best.prim == NO_HIT) {
         if (haveEnv) {
-            f4 rad = mul(ps.att, envL(sv, ps.ray.d));
+            f4 rad = mul(ps.get4(SLOT_ATT), envL(sv, ps.d));
             accumulateRadiance(par, mk3(k_maxval, k_maxval, k_maxval), k_maxval, rad, ps);
         }
         return NEXT_NEW;
     }
-    ps.opl = add(ps.opl, scl(best.a, mk3(ps.ray.ri.x, ps.ray.ri.y, ps.ray.ri.z)));
-    if (!(ps.pathComponent + 1 < par.max_path_components))
+    Ray ray;
+    ray.o = ps.o;
+    ray.d = ps.d;
+    ray.ri = ps.get4(SLOT_RI);
+    const Slot oplSlot = ps.get(SLOT_OPL);
+    const uint32_t pathComponent = oplSlot.w;
+    const f3 opl = add(mk3(oplSlot.x, oplSlot.y, oplSlot.z), scl(best.a, mk3(ray.ri.x, ray.ri.y, ray.ri.z)));
+    if (!(pathComponent + 1 < par.max_path_components))
         return NEXT_NEW;
+    ps.set3(SLOT_OPL, opl);
     long long tSection = 0;
     auto section = [&](int k) { /* COUNT builds: close section k */
         if (COUNT) {
@@ -337,44 +453,49 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
     };
     if (COUNT)
         tSection = clock64();
-    Hit h = finishHit<F>(sv, best, ps.ray.o, ps.ray.d, ps.time);
+    Hit h = finishHit<F>(sv, best, ray.o, ray.d, ps.time);
     const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
     if (COUNT)
         lc.scatters++;
     section(0);
-    const Scatter sr = materialScatter<F>(sv, m, ps.ray, h, ps.prng);
+    Prng prng = loadPrng(ps);
+    const Scatter sr = materialScatter<F>(sv, m, ray, h, prng);
     section(1);
+    const f4 att = ps.get4(SLOT_ATT);
     {
-        f4 rad = mul(ps.att, materialEmitted<F>(sv, m, h));
-        accumulateRadiance(par, ps.opl, (ps.pathComponent == 0 ? 0.0f : h.a), rad, ps);
+        f4 rad = mul(att, materialEmitted<F>(sv, m, h));
+        accumulateRadiance(par, opl, (pathComponent == 0 ? 0.0f : h.a), rad, ps);
     }
     section(2);
-    if (sr.type == SCATTER_NONE)
+    if (sr.type == SCATTER_NONE) {
+        storePrng(ps, prng);
         return NEXT_NEW;
-    ps.nextAtt = mul(ps.att, sr.att);
+    }
+    f4 nextAtt = mul(att, sr.att);
     if (sr.type == SCATTER_RANDOM) {
         if (sr.pdf > 0.0f)
-            ps.nextAtt = divs(ps.nextAtt, sr.pdf);
+            nextAtt = divs(nextAtt, sr.pdf);
         else
-            ps.nextAtt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+            nextAtt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    ps.srDir = sr.dir;
     if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
         /* light sampling with MIS (wurblpt.hpp:179-220) */
-        const float hotSpotsPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, sr.dir, ps, lc);
-        ps.nextAtt = sclr(ps.nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
+        const float hotSpotsPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, sr.dir, rayAux(sr.dir), ps, lc);
+        nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
         section(3);
-        uint32_t idx = (uint32_t)(in01(ps.prng) * (float)sv.hotspotCount);
+        uint32_t idx = (uint32_t)(in01(prng) * (float)sv.hotspotCount);
         idx = idx < sv.hotspotCount - 1 ? idx : sv.hotspotCount - 1;
         const wpt_hotspot& hs = sv.hotspots[idx];
         f3 directDir;
         uint32_t hotSpotPrim = hs.prim;
         if ((F & FEAT_SPHERES) && hs.kind == WPT_HOTSPOT_SPHERE) {
-            directDir = sphereDirection(sphereNow<F>(sv, ps, sv.spheres[hs.prim]), h.p, ps.prng);
+            const DirectionDraw draw = sphereDirection(sphereNow<F>(sv, ps, sv.spheres[hs.prim]), h.p, prng);
+            directDir = draw.dir;
+            prng = draw.prng;
             hotSpotPrim = PRIM_SPHERE | hs.prim;
         } else {
             /* HitableTriangle::direction (hitable_triangle.hpp:425-443) */
-            const f3 bary = inTriangle(in01x2(ps.prng));
+            const f3 bary = inTriangle(in01x2(prng));
             f3 p = add(add(scl(bary.x, ld3(hs.p0)), scl(bary.y, ld3(hs.p1))), scl(bary.z, ld3(hs.p2)));
             if (hs.transform)
                 p = mat4mulPoint(hs.M, p);
@@ -383,17 +504,23 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
             directDir = normalize(sub(p, h.p));
         }
         section(4);
-        const float directPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, directDir, ps, lc);
+        const float directPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, directDir, rayAux(directDir), ps, lc);
         section(5);
         if (directPdf > 0.0f) {
             float dpdf;
             f4 directAtt;
-            materialEval<F>(sv, m, ps.ray, h, directDir, directAtt, dpdf);
+            materialEval<F>(sv, m, ray, h, directDir, directAtt, dpdf);
             if (dpdf > 0.0f) {
-                ps.neeFactor = sclr(divs(mul(ps.att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
-                ps.chosenPrim = hotSpotPrim;
-                ps.ray.o = h.p;
-                ps.ray.d = directDir;
+                const f4 neeFactor = sclr(divs(mul(att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
+                Slot nee;
+                nee.x = neeFactor.x; nee.y = neeFactor.y; nee.z = neeFactor.z;
+                nee.w = hotSpotPrim;
+                ps.set(SLOT_NEE, nee);
+                ps.set4(SLOT_NEXTATT, nextAtt);
+                ps.set3(SLOT_SRDIR, sr.dir);
+                storePrng(ps, prng);
+                ps.o = h.p;
+                ps.d = directDir;
                 ps.rayKind = RAY_NEE_LIGHT;
                 section(6);
                 return NEXT_TRACE;
@@ -402,16 +529,20 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
     } else if ((F & FEAT_ENVMAP) && sr.type == SCATTER_RANDOM && haveEnv && sv.envN > 0) {
         /* environment sampling with MIS (wurblpt.hpp:221-252) */
         const float lightsP = envP(sv, sr.dir);
-        ps.nextAtt = sclr(ps.nextAtt, powerHeuristicWeight(sr.pdf, lightsP));
-        const f3 lightDir = envD(sv, ps.prng);
+        nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, lightsP));
+        const f3 lightDir = envD(sv, prng);
         const float directPdf = envP(sv, lightDir);
         float dpdf;
         f4 directAtt;
-        materialEval<F>(sv, m, ps.ray, h, lightDir, directAtt, dpdf);
+        materialEval<F>(sv, m, ray, h, lightDir, directAtt, dpdf);
         if (dpdf > 0.0f) {
-            ps.neeFactor = sclr(divs(mul(ps.att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
-            ps.ray.o = h.p;
-            ps.ray.d = lightDir;
+            const f4 neeFactor = sclr(divs(mul(att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
+            ps.set3(SLOT_NEE, mk3(neeFactor.x, neeFactor.y, neeFactor.z));
+            ps.set4(SLOT_NEXTATT, nextAtt);
+            ps.set3(SLOT_SRDIR, sr.dir);
+            storePrng(ps, prng);
+            ps.o = h.p;
+            ps.d = lightDir;
             ps.rayKind = RAY_NEE_ENV;
             section(7);
             return NEXT_TRACE;
@@ -419,35 +550,52 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, Path
     }
     /* No next-event ray.  The scattered ray's refractive index: every ScatterRandom record
      * carries the incoming ray's index unchanged (material_lambertian.hpp:83, material_ggx.hpp:224,
-     * material_modphong.hpp:307), so while a next-event ray is in flight ray.ri already is the
-     * value to continue with; only explicit scattering (glass, transparent ModPhong) changes it. */
-    ps.ray.o = h.p;
-    ps.ray.ri = sr.ri;
-    const int next = advancePath(par, ps);
+     * material_modphong.hpp:307), so the slot already holds the value to continue with, also while a
+     * next-event ray is in flight; only explicit scattering (glass, mirror, transparent ModPhong) sets it. */
+    ps.o = h.p;
+    if (sr.type == SCATTER_EXPLICIT)
+        ps.set4(SLOT_RI, sr.ri);
+    const int next = advancePath(par, ps, nextAtt, sr.dir, pathComponent, prng);
+    storePrng(ps, prng);
     section(7);
     return next;
 }
 
 /* the next-event ray's result (wurblpt.hpp:208-218: only the CHOSEN hot spot as nearest hit
  * counts; :240-250: the environment counts if nothing was hit), then the path continues */
-template<uint32_t F>
-WPT_D int blockNeeEnd(const SceneView& sv, const wpt_params& par, PathState& ps, const Candidate& best)
+template<uint32_t F, class PS>
+WPT_D int blockNeeEnd(const SceneView& sv, const wpt_params& par, PS& ps, const Candidate& best)
 {
+    const Slot oplSlot = ps.get(SLOT_OPL);
     if (ps.rayKind == RAY_NEE_LIGHT) {
-        if (best.prim == ps.chosenPrim) {
-            Hit lh = finishHit<F>(sv, best, ps.ray.o, ps.ray.d, ps.time);
+        const Slot nee = ps.get(SLOT_NEE);
+        if (best.prim == nee.w) {
+            Hit lh = finishHit<F>(sv, best, ps.o, ps.d, ps.time);
             const wpt_material& lm = resolveMaterial<F>(sv, lh.material, lh);
-            f4 rad = mul(ps.neeFactor, materialEmitted<F>(sv, lm, lh));
-            f3 oplLight = add(ps.opl, scl(lh.a, mk3(ps.ray.ri.x, ps.ray.ri.y, ps.ray.ri.z)));
+            f4 rad = mul(mk4(nee.x, nee.y, nee.z, 0.0f), materialEmitted<F>(sv, lm, lh));
+            const f4 ri = ps.get4(SLOT_RI);
+            f3 oplLight = add(mk3(oplSlot.x, oplSlot.y, oplSlot.z), scl(lh.a, mk3(ri.x, ri.y, ri.z)));
             accumulateRadiance(par, oplLight, lh.a, rad, ps);
         }
     } else if (F & FEAT_ENVMAP) {
         if (best.prim == NO_HIT) {
-            f4 rad = mul(ps.neeFactor, envL(sv, ps.ray.d));
+            const Slot nee = ps.get(SLOT_NEE);
+            f4 rad = mul(mk4(nee.x, nee.y, nee.z, 0.0f), envL(sv, ps.d));
             accumulateRadiance(par, mk3(k_maxval, k_maxval, k_maxval), k_maxval, rad, ps);
         }
     }
-    return advancePath(par, ps);
+    const f4 nextAtt = ps.get4(SLOT_NEXTATT);
+    const Slot sd = ps.get(SLOT_SRDIR);
+    /* the generator is fetched (and stored again) only when the roulette will draw: advancePath's own test */
+    const bool roulette = max4(nextAtt) < par.rr_threshold && oplSlot.w >= 5;
+    Prng prng;
+    prng.s0 = prng.s1 = prng.s2 = prng.s3 = 0;
+    if (roulette)
+        prng = loadPrng(ps);
+    const int next = advancePath(par, ps, nextAtt, mk3(sd.x, sd.y, sd.z), oplSlot.w, prng);
+    if (roulette)
+        storePrng(ps, prng);
+    return next;
 }
 
 } /* namespace wptk */

@@ -11,8 +11,7 @@
 #include <vector>
 
 #include "../../include/wurblpt_hip.h"
-#include "wpt_pathtrace_pc.inc.h"
-#include "wpt_pathtrace_wf.inc.h"
+#include "wpt_pathtrace.inc.h"
 #include "wpt_postproc.h"
 
 using namespace wptd;
@@ -138,11 +137,7 @@ struct wpt_scene {
     uint32_t animationCount;
     std::vector<void*> allocations;
     uint32_t* status; /* device word: set by a launch that aborted */
-    uint32_t* pixelCounters; /* LDS-state kernel: one "next pixel" word per launch in flight (64 of them) */
-    uint32_t launchSeq;
     int cuCount;
-    float4* wfState;       /* state-in-memory kernel: records of 4 launches in flight, allocated on first use */
-    size_t wfStateRecords; /* records per launch region */
     std::vector<float> envM, envMcs;
     std::vector<int32_t> envMs;
 };
@@ -154,6 +149,7 @@ uint32_t g_variant = 0;
 uint32_t g_leaveEighths = 0; /* 0 = default: chosen per scene size (single-role kernel) / patience 8 rounds (ray-pool kernel) */
 uint32_t g_heavyMin = 0; /* 0 = chosen per scene size at launch */
 uint32_t g_leafBias = 0;
+uint32_t g_topNodes = 65536; /* nodes of a large tree that are stored level by level in front (wpt_set_top_nodes) */
 unsigned long long* g_schedStats = nullptr;
 
 template<typename T> wpt_status uploadArray(wpt_scene* s, const T* src, size_t count, const T** dst)
@@ -226,7 +222,7 @@ wpt_status validate(const wpt_scene_desc* d)
             if (n.link >= d->tri_count || n.link >= PRIM_SPHERE)
                 return fail(WPT_ERR_INVALID_ARGUMENT, "BVH leaf references a triangle outside the array");
         } else if (n.kind == WPT_NODE_SPHERE) {
-            if (n.link >= d->sphere_count || (PRIM_SPHERE | n.link) >= NODE_EMPTY)
+            if (n.link >= d->sphere_count || n.link >= (NODE_CHILD & ~PRIM_SPHERE))
                 return fail(WPT_ERR_INVALID_ARGUMENT, "BVH leaf references a sphere outside the array");
         } else if (n.kind != WPT_NODE_EMPTY) {
             return fail(WPT_ERR_UNSUPPORTED, "BVH node kind is not known to the kernel");
@@ -416,65 +412,70 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     } while (0)
     {
         /* Device node form.  The reference pops a stack to find the next node after a subtree
-         * (bvh.hpp:296,305); in a depth-first array that node is the first one behind the
-         * subtree, so it is stored per node ("skip") and the kernel needs no stack.
-         * With ORDERED_KERNELS (off by default) eight copies of the tree are stored, one per sign
-         * octant of the ray direction: copy k
-         * lists at every inner node first the child that is nearer for such rays along the
-         * node's split axis (the builder sorts by centre along the longest axis of the node's
-         * box, bvh.hpp:110-113, and the left child takes the low side).  Copy 0 (all signs
-         * positive) is the reference's own order: left child first everywhere. */
+         * (bvh.hpp:296,305); in depth-first order that node is the first one behind the subtree, so
+         * its index is stored per node ("skip"), an inner node also carries the index of its first
+         * child, and the kernel needs neither a stack nor any particular storage order.
+         *
+         * Storage order.  Every ray starts at the root, so the top of the tree is what all waves
+         * of an XCD keep fetching; in depth-first order those nodes lie scattered over the whole
+         * array (the right child of the root is half the array away), each dragging a 128-byte
+         * line of rarely visited neighbours into the XCD's 4 MiB L2.  For trees larger than an L2
+         * the nodes of the top levels are therefore stored first, level by level (WPT_TOP_NODES
+         * nodes, 2 MiB by default, contiguous and dense), and the subtrees below them after that,
+         * each depth-first as before (a walk that descends to a first child then reads the next
+         * 32 bytes).  The visiting order is the tree's, not the array's: results do not change. */
         const uint32_t n = desc->node_count;
-        const uint32_t copies = ORDERED_KERNELS ? 8u : 1u;
-        std::vector<float4> dev(size_t(n) * 2 * copies);
-        struct Item { uint32_t src; uint32_t pos; bool done; };
-        for (uint32_t oct = 0; oct < copies; oct++) {
-            float4* out = dev.data() + size_t(oct) * n * 2;
+        if (n > NODE_INDEX_MASK)
+            return fail(WPT_ERR_UNSUPPORTED, "more than 2^30 - 1 BVH nodes");
+        /* end[i] = first depth-first index behind the subtree of node i (validated above) */
+        std::vector<uint32_t> end(n);
+        for (uint32_t i = n; i-- > 0;)
+            end[i] = desc->nodes[i].kind == WPT_NODE_INNER ? end[desc->nodes[i].link] : i + 1;
+        std::vector<uint32_t> place(size_t(n) + 1); /* depth-first index -> storage index; place[n] = n ends the walk */
+        place[n] = n;
+        uint32_t topNodes = g_topNodes;
+        if (n <= topNodes) /* the whole tree is no larger than the part that would go in front: nothing to gain */
+            topNodes = 0;
+        {
             uint32_t cursor = 0;
-            std::vector<Item> stack;
-            stack.push_back(Item { 0, 0, false });
-            while (!stack.empty()) {
-                Item it = stack.back();
-                stack.pop_back();
-                const wpt_bvh_node& nd = desc->nodes[it.src];
-                if (it.done) {
-                    /* subtree emitted: its skip link is the next free position */
-                    float sk;
-                    memcpy(&sk, &cursor, 4);
-                    out[2 * size_t(it.pos) + 1].z = sk;
-                    continue;
+            std::vector<uint32_t> level, next;
+            if (topNodes > 0) {
+                level.push_back(0);
+                while (!level.empty() && cursor + level.size() <= topNodes) {
+                    next.clear();
+                    for (uint32_t i : level) {
+                        place[i] = cursor++;
+                        if (desc->nodes[i].kind == WPT_NODE_INNER) {
+                            next.push_back(i + 1);
+                            next.push_back(desc->nodes[i].link);
+                        }
+                    }
+                    level.swap(next);
                 }
-                if (cursor >= n) { /* cannot happen after validate(); keeps the conversion inside `dev` whatever comes in */
-                    wpt_scene_free(s);
-                    return fail(WPT_ERR_INVALID_ARGUMENT, "BVH conversion: the links describe more nodes than the array holds");
-                }
-                const uint32_t pos = cursor++;
-                const uint32_t prim = nd.kind == WPT_NODE_INNER ? NODE_INNER : nd.kind == WPT_NODE_TRIANGLE ? nd.link
-                    : nd.kind == WPT_NODE_SPHERE ? (PRIM_SPHERE | nd.link) : NODE_EMPTY;
-                float pr;
-                memcpy(&pr, &prim, 4);
-                out[2 * size_t(pos)] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0]);
-                out[2 * size_t(pos) + 1] = make_float4(nd.hi[1], nd.hi[2], 0.0f, pr);
-                stack.push_back(Item { it.src, pos, true });
-                if (nd.kind == WPT_NODE_INNER) {
-                    /* AABB::longestAxis (aabb.hpp:52-62) */
-                    const float l0 = nd.hi[0] - nd.lo[0], l1 = nd.hi[1] - nd.lo[1], l2 = nd.hi[2] - nd.lo[2];
-                    int axis = 2;
-                    if (l0 > l1 && l0 > l2)
-                        axis = 0;
-                    else if (l1 > l2)
-                        axis = 1;
-                    const bool leftFirst = ((oct >> axis) & 1u) == 0;
-                    const uint32_t first = leftFirst ? it.src + 1 : nd.link;
-                    const uint32_t second = leftFirst ? nd.link : it.src + 1;
-                    stack.push_back(Item { second, 0, false }); /* popped after the first subtree */
-                    stack.push_back(Item { first, 0, false });
-                }
+            } else {
+                level.push_back(0);
             }
+            /* the subtrees that did not make it into the top part, depth-first each, in depth-first order of their roots */
+            std::sort(level.begin(), level.end());
+            for (uint32_t root : level)
+                for (uint32_t i = root; i < end[root]; i++)
+                    place[i] = cursor++;
             if (cursor != n) {
                 wpt_scene_free(s);
-                return fail(WPT_ERR_INVALID_ARGUMENT, "BVH conversion: the links do not reach every node");
+                return fail(WPT_ERR_INVALID_ARGUMENT, "BVH conversion: the links do not reach every node exactly once");
             }
+        }
+        std::vector<float4> dev(size_t(n) * 2);
+        for (uint32_t i = 0; i < n; i++) {
+            const wpt_bvh_node& nd = desc->nodes[i];
+            const uint32_t skip = place[end[i]];
+            const uint32_t word = nd.kind == WPT_NODE_INNER ? (NODE_CHILD | place[i + 1]) : nd.kind == WPT_NODE_TRIANGLE ? nd.link
+                : nd.kind == WPT_NODE_SPHERE ? (PRIM_SPHERE | nd.link) : (NODE_CHILD | skip);
+            float sk, wd;
+            memcpy(&sk, &skip, 4);
+            memcpy(&wd, &word, 4);
+            dev[2 * size_t(place[i])] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0]);
+            dev[2 * size_t(place[i]) + 1] = make_float4(nd.hi[1], nd.hi[2], sk, wd);
         }
         UP(uploadArray(s, dev.data(), dev.size(), &nodes));
     }
@@ -540,14 +541,10 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     for (int k = 0; k < 6; k++)
         s->view.envCube[k] = desc->envmap.cube_tex[k];
     {
-        const uint32_t zeros[1 + 64] = { 0 };
+        const uint32_t zeros[1] = { 0 };
         const uint32_t* statusWord = nullptr;
-        UP(uploadArray(s, zeros, 1 + 64, &statusWord));
+        UP(uploadArray(s, zeros, 1, &statusWord));
         s->status = const_cast<uint32_t*>(statusWord);
-        s->pixelCounters = s->status + 1;
-        s->launchSeq = 0;
-        s->wfState = nullptr;
-        s->wfStateRecords = 0;
         hipDeviceProp_t prop;
         s->cuCount = hipGetDeviceProperties(&prop, s->device) == hipSuccess ? prop.multiProcessorCount : 256;
     }
@@ -661,14 +658,12 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
 {
     if (!scene || !camera || !params || !frame_device)
         return fail(WPT_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (width == 0 || height == 0 || samples_sqrt == 0 || samples_sqrt > 65535)
-        return fail(WPT_ERR_INVALID_ARGUMENT, "width, height and samples_sqrt must be positive");
+    if (width == 0 || height == 0 || samples_sqrt == 0 || samples_sqrt > 65535 || width > 65535 || height > 65535)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "width, height and samples_sqrt must lie in 1 .. 65535");
     if (uint64_t(width) * height > 0xffffffffull || uint64_t(block_start) + (band_stride ? 0u : block_size) > uint64_t(width) * height)
         return fail(WPT_ERR_INVALID_ARGUMENT, "pixel block lies outside the frame");
     if (block_size == 0)
         return WPT_OK;
-    if (band_stride && (g_variant & 0x50u))
-        return fail(WPT_ERR_UNSUPPORTED, "interleaved bands are rendered by the product kernel only");
     KernelArgs args;
     args.bandPixels = band_pixels;
     args.bandFirst = band_first;
@@ -679,13 +674,16 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     args.width = width;
     args.height = height;
     args.samplesSqrt = samples_sqrt;
+    args.invWidth = 1.0f / float(width);
+    args.invHeight = 1.0f / float(height);
+    args.invSamplesSqrt = 1.0f / float(samples_sqrt);
+    args.invSamples = 1.0f / float(samples_sqrt * samples_sqrt);
     args.blockStart = block_start;
     args.blockSize = block_size;
     args.frame = frame_device;
     args.counters = counters_device;
     args.status = scene->status;
     args.schedStats = g_schedStats;
-    args.patience = 8;
     args.fuse = (g_variant & 0x20u) ? 0u : 1u; /* variant bit 0x20: separate SHADE / NEE-END / NEW rounds (the older scheduler) */
 
     /* a wave covers an 8x8 pixel tile when the block consists of whole groups of 8 rows */
@@ -706,7 +704,7 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     dim3 grid((block_size + WG - 1) / WG);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const bool count = counters_device != nullptr;
-    const size_t ldsBytes = size_t(scene->nodeCount) * 32 * (ORDERED_KERNELS ? 8 : 1) + size_t(scene->triCount) * 48;
+    const size_t ldsBytes = size_t(scene->nodeCount) * 32 + size_t(scene->triCount) * 48;
     /* scheduler defaults from sweeps on the Cornell box (scene in LDS, short walks) and on the
      * Sponza-class scene (deep tree in HBM: traversal dominates, so long blocks may run with fewer
      * lanes and leaf tests earlier) */
@@ -715,25 +713,13 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     args.leaveEighths = g_leaveEighths ? (g_leaveEighths > 8u ? 8u : g_leaveEighths) : (smallScene ? 1u : 3u);
     args.heavyMin = g_heavyMin ? g_heavyMin : (smallScene ? 16u : 8u);
     args.leafBias = g_leafBias ? g_leafBias : (smallScene ? 16u : 32u);
-    /* kernel choice: the single-role kernel (wpt_pathtrace.inc.h) is the product path and the only
-     * one with work counters.  Variant bit 0x10 selects the workgroup ray-pool kernel
-     * (wpt_pathtrace_pc.inc.h), kept as a measured experiment: same results, slower.
-     * Low nibble: 1 = keep the scene in HBM, 2 = all features. */
+    /* kernel choice.  Low nibble of the variant word: 1 = keep the scene in HBM, 2 = all features. */
     const uint32_t force = g_variant & 0x7u;
-    const bool singleRole = (g_variant & 0x10u) == 0 || (scene->features & FEAT_SPHERES) != 0;
     const bool basic = (need & ~FEAT_BASIC) == 0 && force != 2;
     const bool lds = smallScene && force != 1;
-    /* the two experimental kernel families have no sphere leaf test: scenes with spheres run the product kernel */
-    const bool spheres = (scene->features & FEAT_SPHERES) != 0;
-    const bool ldsState = (g_variant & 0x40u) != 0 && !spheres;
-    args.travWaves = 8;
-    args.heavyWaves = 4;
-    args.pixelCounter = nullptr;
-    args.wfState = nullptr;
-    args.wfSlots = 0;
-    const bool rgl = (need & FEAT_RGL) != 0; /* measured BRDFs have their own instantiation of the product kernel */
+    const bool rgl = (need & FEAT_RGL) != 0; /* measured BRDFs have their own instantiation */
     if (anim) {
-        /* its own instantiation of the product kernel, like the measured BRDFs */
+        /* its own instantiation, like the measured BRDFs */
         if (need & FEAT_RGL) {
             if (count)
                 launchFullRglAnimCount(args, grid, stream);
@@ -753,83 +739,12 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
             launchFullCount(args, grid, stream);
     } else if (rgl) {
         launchFullRgl(args, grid, stream);
-    } else if (ldsState && (g_variant & 0x08u)) {
-        /* variant bits 0x48: the same persistent kernel with the pixel states in global memory
-         * (byte 1 = traversal waves, byte 2 = heavy waves, byte 3 = slots per workgroup / 64) */
-        args.travWaves = g_leaveEighths ? g_leaveEighths : 6u;
-        args.heavyWaves = g_heavyMin ? g_heavyMin : 10u;
-        if (args.travWaves + args.heavyWaves > uint32_t(WF_WAVES))
-            return fail(WPT_ERR_INVALID_ARGUMENT, "more traversal + heavy waves than the workgroup has");
-        args.wfSlots = g_leafBias ? g_leafBias * 64u : 2048u;
-        if (args.wfSlots > uint32_t(WF_GRING))
-            args.wfSlots = WF_GRING;
-        args.leafBias = smallScene ? 16u : 32u;
-        args.heavyMin = 16;
-        args.patience = 8;
-        const uint32_t groups = (block_size + args.wfSlots - 1) / args.wfSlots;
-        dim3 wfGrid(groups < uint32_t(scene->cuCount) ? groups : uint32_t(scene->cuCount));
-        const size_t records = size_t(scene->cuCount) * WF_GRING;
-        if (!scene->wfState) {
-            void* p = nullptr;
-            hipError_t e = hipMalloc(&p, records * 4 * WF_GRECORD4 * sizeof(float4));
-            if (e != hipSuccess)
-                return fail(e == hipErrorOutOfMemory ? WPT_ERR_OUT_OF_MEMORY : WPT_ERR_HIP, std::string("hipMalloc for the pixel states: ") + hipGetErrorString(e));
-            scene->allocations.push_back(p);
-            scene->wfState = static_cast<float4*>(p);
-            scene->wfStateRecords = records;
-        }
-        args.pixelCounter = scene->pixelCounters + (scene->launchSeq & 63u);
-        args.wfState = scene->wfState + size_t(scene->launchSeq & 3u) * scene->wfStateRecords * WF_GRECORD4;
-        scene->launchSeq++;
-        HIP_TRY(hipMemsetAsync(args.pixelCounter, 0, sizeof(uint32_t), stream));
-        const bool wfLds = basic && force != 1 && ldsBytes <= WF_LDS_SCENE_MAX_BYTES;
-        const size_t bytes = wfgLdsBytes(wfLds ? uint32_t(ldsBytes) : 0u);
-        if (wfLds)
-            launchWfgBasicLds(args, wfGrid, bytes, stream);
-        else
-            launchWfgFull(args, wfGrid, bytes, stream);
-    } else if (ldsState) {
-        /* variant bit 0x40: pixel states in LDS, persistent workgroups (wpt_pathtrace_wf.inc.h);
-         * byte 1 of the variant word, if set, is the number of traversal waves per workgroup */
-        args.travWaves = g_leaveEighths ? g_leaveEighths : 8u;
-        args.heavyWaves = g_heavyMin ? g_heavyMin : 4u;
-        if (args.travWaves + args.heavyWaves > uint32_t(WF_WAVES))
-            return fail(WPT_ERR_INVALID_ARGUMENT, "more traversal + heavy waves than the workgroup has");
-        args.heavyMin = 16; /* not used by this kernel */
-        args.patience = 8;
-        args.pixelCounter = scene->pixelCounters + (scene->launchSeq++ & 63u);
-        HIP_TRY(hipMemsetAsync(args.pixelCounter, 0, sizeof(uint32_t), stream));
-        const bool wfLds = basic && force != 1 && ldsBytes <= WF_LDS_SCENE_MAX_BYTES;
-        const uint32_t groups = (block_size + WF_SLOTS - 1) / WF_SLOTS;
-        dim3 wfGrid(groups < uint32_t(scene->cuCount) ? groups : uint32_t(scene->cuCount));
-        const size_t wfBytes = wfLdsBytes(wfLds ? uint32_t(ldsBytes) : 0u);
-        if (wfLds)
-            launchWfBasicLds(args, wfGrid, wfBytes, stream);
-        else if (basic)
-            launchWfBasic(args, wfGrid, wfBytes, stream);
-        else
-            launchWfFull(args, wfGrid, wfBytes, stream);
-    } else if (singleRole) {
-        /* a launch that cannot put more than two waves on a SIMD takes the paired-step build (variant bit 0x80: never) */
-        const bool starved = uint64_t(block_size) <= uint64_t(scene->cuCount) * 4u * 2u * 64u && (g_variant & 0x80u) == 0;
-        if (basic && lds && starved)
-            launchBasicLdsPairs(args, grid, ldsBytes, stream);
-        else if (basic && lds)
-            launchBasicLds(args, grid, ldsBytes, stream);
-        else if (basic)
-            launchBasic(args, grid, stream);
-        else
-            launchFull(args, grid, stream);
+    } else if (basic && lds) {
+        launchBasicLds(args, grid, ldsBytes, stream);
+    } else if (basic) {
+        launchBasic(args, grid, stream);
     } else {
-        args.heavyMin = g_heavyMin ? g_heavyMin : 32u; /* waiting is free (the wave traverses meanwhile): shade well filled */
-        args.patience = g_leaveEighths ? g_leaveEighths : 8u;
-        dim3 pcGrid((block_size + PC_SLOTS - 1) / PC_SLOTS);
-        if (basic && lds)
-            launchPcBasicLds(args, pcGrid, ldsBytes, stream);
-        else if (basic)
-            launchPcBasic(args, pcGrid, stream);
-        else
-            launchPcFull(args, pcGrid, stream);
+        launchFull(args, grid, stream);
     }
     HIP_TRY(hipGetLastError());
     return WPT_OK;
@@ -998,6 +913,12 @@ wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant)
         g_heavyMin = ((variant >> 16) & 0xffu) - 1;     /* byte 2: lanes a long block needs, plus one */
     if ((variant >> 24) & 0xffu)
         g_leafBias = (variant >> 24) & 0xffu;           /* byte 3: leaf bias */
+    return WPT_OK;
+}
+
+wpt_status wpt_set_top_nodes(uint32_t nodes)
+{
+    g_topNodes = nodes;
     return WPT_OK;
 }
 

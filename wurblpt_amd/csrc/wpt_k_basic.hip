@@ -5,7 +5,7 @@ namespace wptk {
 
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false, false, 4, ORDERED_KERNELS>), grid, dim3(WG), 0, stream, args);
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false, false, 4>), grid, dim3(WG), COLD_BYTES, stream, args);
 }
 
 }

@@ -3,9 +3,9 @@
 
 namespace wptk {
 
-void launchBasicLds(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream)
+void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false, true, 4, ORDERED_KERNELS>), grid, dim3(WG), ldsBytes, stream, args);
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false, true, 4>), grid, dim3(WG), COLD_BYTES + sceneLdsBytes, stream, args);
 }
 
 }

@@ -5,7 +5,7 @@ namespace wptk {
 
 void launchFullCount(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL, true, false, 2, false>), grid, dim3(WG), 0, stream, args);
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL, true, false, 2>), grid, dim3(WG), COLD_BYTES, stream, args);
 }
 
 }

@@ -6,12 +6,12 @@ namespace wptk {
 
 void launchFullRglAnim(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL | FEAT_RGL | FEAT_ANIM, false, false, 2, false>), grid, dim3(WG), 0, stream, args);
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL | FEAT_RGL | FEAT_ANIM, false, false, 2>), grid, dim3(WG), COLD_BYTES, stream, args);
 }
 
 void launchFullRglAnimCount(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL | FEAT_RGL | FEAT_ANIM, true, false, 2, false>), grid, dim3(WG), 0, stream, args);
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL | FEAT_RGL | FEAT_ANIM, true, false, 2>), grid, dim3(WG), COLD_BYTES, stream, args);
 }
 
 }

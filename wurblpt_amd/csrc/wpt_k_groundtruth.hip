@@ -89,12 +89,15 @@ __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs a
     fa.width = args.width;
     fa.height = args.height;
     fa.samplesSqrt = 1;
-    PathState ps;
-    pathStateInit(ps, pixel, args.width);
+    fa.invWidth = 1.0f / (float)args.width;
+    fa.invHeight = 1.0f / (float)args.height;
+    fa.invSamplesSqrt = 1.0f;
+    PathRegs ps;
+    pathStateInit(ps, pixel, pixel % args.width, pixel / args.width);
     blockNew<GT_FEATURES>(fa, ps, &sv); /* par.t0 == par.t1: no time draw, ps.time = t0 */
 
     /* BVH::hit (bvh.hpp:270-329): closest candidate, later candidates win ties */
-    const RayAux aux = rayAux(ps.ray.d);
+    const RayAux aux = rayAux(ps.d);
     Candidate best;
     best.prim = NO_HIT;
     best.a = best.invDet = best.U = best.V = best.W = 0.0f;
@@ -104,13 +107,13 @@ __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs a
         const float4 n0 = sv.nodes[2 * node], n1 = sv.nodes[2 * node + 1];
         const uint32_t skip = __float_as_uint(n1.z);
         const uint32_t prim = __float_as_uint(n1.w);
-        const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.ray.o, aux.inv, args.par.min_hit_distance, amax);
-        if (hit && prim < NODE_EMPTY) {
+        const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.o, aux.inv, args.par.min_hit_distance, amax);
+        if (hit && prim < NODE_CHILD) {
             Candidate c;
             bool accepted;
             if (prim & PRIM_SPHERE) {
                 c.invDet = c.U = c.V = c.W = 0.0f;
-                accepted = sphereTest(sphereAt<GT_FEATURES>(sv, sv.spheres[prim & ~PRIM_SPHERE], ps.time), ps.ray.o, ps.ray.d, args.par.min_hit_distance, amax, c.a);
+                accepted = sphereTest(sphereAt<GT_FEATURES>(sv, sv.spheres[prim & ~PRIM_SPHERE], ps.time), ps.o, ps.d, args.par.min_hit_distance, amax, c.a);
             } else {
                 const float4 g0 = sv.triGeom[3 * (size_t)prim], g1 = sv.triGeom[3 * (size_t)prim + 1], g2 = sv.triGeom[3 * (size_t)prim + 2];
                 f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
@@ -121,16 +124,16 @@ __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs a
                     v1 = animatePoint(animationM, v1);
                     v2 = animatePoint(animationM, v2);
                 }
-                accepted = triangleTest(v0, v1, v2, ps.ray.o, aux, args.par.min_hit_distance, amax, c);
+                accepted = triangleTest(v0, v1, v2, ps.o, aux, args.par.min_hit_distance, amax, c);
             }
             if (accepted) {
                 c.prim = prim;
                 best = c;
                 amax = c.a;
             }
-            node = node + 1;
+            node = skip; /* a leaf's subtree is the leaf itself */
         } else {
-            node = (hit && prim == NODE_INNER) ? node + 1 : skip;
+            node = hit ? (prim & NODE_INDEX_MASK) : skip;
         }
     }
 
@@ -144,7 +147,7 @@ __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs a
     f2 psOP = txCor, psON = txCor;
     int matInd = -1;
     if (best.prim != NO_HIT) {
-        const Hit h = finishHit<GT_FEATURES>(sv, best, ps.ray.o, ps.ray.d, ps.time);
+        const Hit h = finishHit<GT_FEATURES>(sv, best, ps.o, ps.d, ps.time);
         wsPos = h.p;
         wsGNrm = h.n;
         wsGTan = h.t;
@@ -202,8 +205,8 @@ __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs a
         if (args.array[17] || args.array[18]) {
             const float fw = (float)args.width, fh = (float)args.height;
             f2 psPos;
-            psPos.x = (((float)ps.px + 0.5f) * (1.0f / fw)) * fw;
-            psPos.y = (((float)ps.py + 0.5f) * (1.0f / fh)) * fh;
+            psPos.x = (((float)(pixel % args.width) + 0.5f) * (1.0f / fw)) * fw;
+            psPos.y = (((float)(pixel / args.width) + 0.5f) * (1.0f / fh)) * fh;
             const f2 icPrev = cameraSpaceToImageSpace(args.cam, csPosPrev), icNext = cameraSpaceToImageSpace(args.cam, csPosNext);
             psOP.x = icPrev.x * fw - psPos.x;
             psOP.y = icPrev.y * fh - psPos.y;

@@ -16,13 +16,20 @@
  *    Each lane still executes its own operations in the reference's order, so results do not
  *    change; only SIMD utilisation does (v0 without the scheduler: 18 % active lanes).
  *
- *  - BVH traversal is stackless.  The reference walks its depth-first node array with a stack,
- *    left child first (bvh.hpp:277-311); in that layout the node a pop returns to is always
- *    the first node after the current subtree, so each device node carries that index
- *    ("skip") and the walk is: box hit & inner -> next node; otherwise -> skip.  Same visiting
- *    order, no stack, no LDS or scratch traffic for it.
+ *  - Registers hold the ray and the walk (origin, direction, reciprocals, shear, node, bound, best
+ *    candidate: 24 words).  The rest of the path's state (32 words: generator, accumulators,
+ *    attenuations, the continuation behind a next-event ray) lives in LDS, eight 16-byte slots per
+ *    lane (wpt_blocks.h): 32 KiB per 256-thread workgroup, so four workgroups per CU still fit, and
+ *    the long round no longer spills the waiting lanes' words to scratch memory.
  *
- *  - Small scenes (nodes + triangle positions up to 48 KiB, e.g. the Cornell box: 4 KiB) are
+ *  - BVH traversal is stackless.  The reference walks its depth-first node array with a stack,
+ *    left child first (bvh.hpp:277-311); the node a pop returns to is always the first node behind
+ *    the current subtree in depth-first order, so each device node carries that node's index
+ *    ("skip") and an inner node the index of its first child: box hit & inner -> first child;
+ *    leaf -> test it, then skip; otherwise -> skip.  Same visiting order, no stack, and the nodes
+ *    may be STORED in any order (wpt_capi.hip lays the top of a large tree out level by level).
+ *
+ *  - Small scenes (nodes + triangle positions up to 21 KiB, e.g. the Cornell box: 4 KiB) are
  *    copied into LDS once per workgroup and traversed from there; larger scenes are fetched
  *    from HBM/L2 as two dwordx4 per node and three per triangle.
  *
@@ -42,36 +49,30 @@ namespace wptk {
 using namespace wptd;
 
 constexpr int WG = 256; /* threads per workgroup: 4 waves, one per SIMD */
-constexpr uint32_t NODE_INNER = 0xffffffffu; /* device node: marker in the primitive slot */
-constexpr uint32_t NODE_EMPTY = 0xfffffffeu;
-constexpr uint32_t LDS_SCENE_MAX_BYTES = 48 * 1024;
-/* Near-first walk over the octant copies of the BVH (template parameter ORDERED).  Measured on
- * the Sponza-class scene: only 10 % fewer node visits (1112 vs 1243 per sample; the reference's
- * tree is 50 levels deep, so most visits are the two boxes per level on the way down) for 4 more
- * registers per lane, which costs more than it saves.  Kept as an option, switched off. */
-constexpr bool ORDERED_KERNELS = false;
+/* device node, word 7: a triangle index (< 2^31), PRIM_SPHERE | sphere index (< 2^30), or NODE_CHILD | index of the
+ * first child (an empty node: NODE_CHILD | its own skip link, so that entering it is the same as skipping it) */
+constexpr uint32_t NODE_CHILD = 0xc0000000u;
+constexpr uint32_t NODE_INDEX_MASK = 0x3fffffffu;
+constexpr uint32_t COLD_BYTES = SLOT_COUNT * WG * 16; /* the paths' cold words: 32 KiB of LDS per workgroup */
+/* with the scene behind them three workgroups still fit into a CU's 160 KiB */
+constexpr uint32_t LDS_SCENE_MAX_BYTES = 21 * 1024;
 
 struct KernelArgs {
     SceneView sv;
     wpt_camera cam;
     wpt_params par;
     uint32_t width, height, samplesSqrt;
+    float invWidth, invHeight, invSamplesSqrt, invSamples; /* 1.0f / (float)..., divided on the host */
     uint32_t blockStart, blockSize;
     uint32_t tiled; /* 1: a wave covers an 8x8 pixel tile (block is whole rows, multiple of 8) */
-    /* bands (product kernel only): with bandStride > 0 the launch covers the bands of bandPixels consecutive pixels
+    /* bands: with bandStride > 0 the launch covers the bands of bandPixels consecutive pixels
      * whose index is bandFirst, bandFirst + bandStride, ... -- one rank's interleaved share of the frame in one launch;
      * blockStart is 0 and blockSize the number of lanes (pixels behind the end of the frame stay idle) */
     uint32_t bandPixels, bandFirst, bandStride;
     uint32_t leaveEighths; /* scheduler: leave the NODE loop when fewer than this many eighths of the entering lanes remain */
     uint32_t heavyMin;     /* scheduler: lanes a long block needs before it runs */
     uint32_t leafBias;     /* scheduler: leaf tests run when waiting lanes * leafBias >= walking lanes * 8 */
-    uint32_t patience;     /* ray-pool kernel: traversal rounds a wave may spend before it shades what it has */
     uint32_t fuse;         /* scheduler: 1 = one long round serves SHADE, NEE-END and NEW lanes together */
-    uint32_t travWaves;    /* LDS-state kernel: waves of a workgroup that hold traversal contexts */
-    uint32_t heavyWaves;   /* LDS-state kernel: waves of a workgroup that run heavy batches */
-    uint32_t* pixelCounter; /* LDS-state kernel: next unassigned pixel of the block (zero at launch) */
-    float4* wfState;        /* state-in-memory kernel: 12 float4 per slot, wfSlots slots per workgroup */
-    uint32_t wfSlots;
     float* frame;
     wpt_counters* counters;
     unsigned long long* schedStats; /* COUNT builds: 16 scheduler statistics, or NULL */
@@ -81,10 +82,12 @@ struct KernelArgs {
 /* lane states, in scheduling priority order for ties */
 enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5 };
 
-template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, bool ORDERED, bool PAIRS = false>
+template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC>
 __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 {
-    extern __shared__ float4 ldsScene[];
+    /* [ cold path words: SLOT_COUNT x WG float4 ][ LDSSCENE: nodes, triangle positions ] */
+    extern __shared__ float4 lds[];
+    float4* const ldsScene = lds + SLOT_COUNT * WG;
 
     const SceneView& sv = args.sv;
     const wpt_params& par = args.par;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 
     if (LDSSCENE) {
         /* nodes (2 x float4 each) followed by the triangle positions (3 x float4 each) */
-        const uint32_t n4 = 2 * nodeCount * (ORDERED ? 8u : 1u), t4 = 3 * sv.triCount;
+        const uint32_t n4 = 2 * nodeCount, t4 = 3 * sv.triCount;
         for (uint32_t i = threadIdx.x; i < n4; i += WG)
             ldsScene[i] = sv.nodes[i];
         for (uint32_t i = threadIdx.x; i < t4; i += WG)
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     };
     auto tri4 = [&](uint32_t i) -> float4 {
         if constexpr (LDSSCENE)
-            return ldsScene[2 * nodeCount * (ORDERED ? 8u : 1u) + i];
+            return ldsScene[2 * nodeCount + i];
         else
             return sv.triGeom[i];
     };
@@ -136,66 +139,43 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         inBlock = false; /* the last band may be shorter */
     if (!inBlock)
         pixel = args.blockStart;
-    const uint32_t samples = args.samplesSqrt * args.samplesSqrt;
     FrameArgs fa;
     fa.cam = args.cam;
     fa.par = args.par;
     fa.width = args.width;
     fa.height = args.height;
     fa.samplesSqrt = args.samplesSqrt;
+    fa.invWidth = args.invWidth;
+    fa.invHeight = args.invHeight;
+    fa.invSamplesSqrt = args.invSamplesSqrt;
 
-    /* ---- per-lane state: the pixel's path (wpt_blocks.h) and the traversal registers ---- */
-    PathState ps;
-    pathStateInit(ps, pixel, args.width);
+    /* ---- per-lane state: the pixel's path (wpt_blocks.h; its cold words in LDS) and the traversal registers ---- */
+    PathLds<WG> ps;
+    ps.base = lds + threadIdx.x;
+    pathStateInit(ps, pixel, pixel % args.width, pixel / args.width);
     LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
     /* wave-level scheduler statistics (COUNT builds): rounds and lane counts per state */
     unsigned long long sched[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int state = inBlock ? S_NEW : S_DONE;
-    RayAux aux = rayAux(ps.ray.d);
+    RayAux aux = rayAux(ps.d);
     uint32_t node = 0, leafPrim = 0;
-    uint32_t nodeBase = 0; /* ORDERED: first node of the ray's octant copy of the BVH */
-    bool exact = !ORDERED; /* true: the reference's own walk (copy 0, exact bounds) */
     float amax = k_maxval;
-    float amaxCull = k_maxval, second = k_maxval; /* ORDERED: widened bound, 2nd closest candidate */
     Candidate best;
     best.prim = NO_HIT;
     best.a = best.invDet = best.U = best.V = best.W = 0.0f;
 
-    /* start the traversal of ps.ray */
+    /* start the traversal of the ray ps.o, ps.d */
     auto beginRay = [&]() {
-        aux = rayAux(ps.ray.d);
+        aux = rayAux(ps.d);
         node = 0;
         amax = k_maxval;
         best.prim = NO_HIT;
-        if (ORDERED) {
-            const uint32_t octant = (ps.ray.d.x < 0.0f ? 1u : 0u) | (ps.ray.d.y < 0.0f ? 2u : 0u) | (ps.ray.d.z < 0.0f ? 4u : 0u);
-            nodeBase = octant * nodeCount;
-            exact = false;
-            amaxCull = k_maxval;
-            second = k_maxval;
-        }
         state = S_NODE;
         if (COUNT)
             lc.rays++;
     };
-    /* State after the walk has left the tree.  ORDERED: the near-first walk found the closest
-     * candidate `best` and the runner-up distance `second`; if no other candidate lies within
-     * (1 + 2^-13) of it, the reference's unordered walk must end with the same candidate (it
-     * accepts it whenever it reaches it, and nothing can replace it).  Otherwise candidates
-     * tie and the winner depends on the reference's visiting order, so the ray walks again in
-     * exactly that order (copy 0, exact bounds) starting from amax = best.a * (1 + 2^-13),
-     * which gives the reference's result: everything farther is superseded in its walk anyway. */
-    auto endOfRayState = [&]() {
-        if (ORDERED && !exact && best.prim != NO_HIT && !(second > best.a * 1.0001220703125f)) {
-            exact = true;
-            nodeBase = 0;
-            node = 0;
-            amax = best.a * 1.0001220703125f;
-            best.prim = NO_HIT;
-            return (int)S_NODE;
-        }
-        return ps.rayKind == RAY_PATH ? (int)S_SHADE : (int)S_NEEEND;
-    };
+    /* state after the walk has left the tree */
+    auto endOfRayState = [&]() { return ps.rayKind == RAY_PATH ? (int)S_SHADE : (int)S_NEEEND; };
     /* what a block of wpt_blocks.h asks for next */
     auto afterBlock = [&](int next) {
         if (next == NEXT_TRACE)
@@ -263,16 +243,16 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         sched[4] += nLeaf;
                     }
                     if (state == S_LEAF) {
-                        /* HitableTriangle::hit, candidate part (hitable_triangle.hpp:189-271) */
+                        /* HitableTriangle::hit, candidate part (hitable_triangle.hpp:189-271); `node` already is the
+                         * node to go on with (a leaf's subtree is the leaf itself) */
                         if (COUNT)
                             lc.leaves++;
                         Candidate c;
-                        const float bound = (ORDERED && !exact) ? amaxCull : amax;
                         bool accepted;
                         if ((F & FEAT_SPHERES) && (leafPrim & PRIM_SPHERE)) {
                             /* HitableSphere::hit (hitable_sphere.hpp:104-147) */
                             c.invDet = c.U = c.V = c.W = 0.0f;
-                            accepted = sphereTest(sphereNow<F>(sv, ps, sv.spheres[leafPrim & ~PRIM_SPHERE]), ps.ray.o, ps.ray.d, par.min_hit_distance, bound, c.a);
+                            accepted = sphereTest(sphereNow<F>(sv, ps, sv.spheres[leafPrim & ~PRIM_SPHERE]), ps.o, ps.d, par.min_hit_distance, amax, c.a);
                         } else {
                             const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
                             f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
@@ -283,27 +263,14 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                                 v1 = animatePoint(animationM, v1);
                                 v2 = animatePoint(animationM, v2);
                             }
-                            accepted = triangleTest(v0, v1, v2, ps.ray.o, aux, par.min_hit_distance, bound, c);
+                            accepted = triangleTest(v0, v1, v2, ps.o, aux, par.min_hit_distance, amax, c);
                         }
                         if (accepted) {
                             c.prim = leafPrim;
-                            if (ORDERED && !exact) {
-                                /* keep the closest; remember how close the runner-up came */
-                                if (best.prim == NO_HIT || c.a < best.a) {
-                                    second = best.prim != NO_HIT && best.a < second ? best.a : second;
-                                    best = c;
-                                    amax = c.a;
-                                    amaxCull = amax * 1.000244140625f; /* 1 + 2^-12 */
-                                } else {
-                                    second = c.a < second ? c.a : second;
-                                }
-                            } else {
-                                best = c;
-                                amax = c.a;
-                            }
+                            best = c;
+                            amax = c.a;
                         }
-                        node = node + 1; /* a leaf's subtree is the leaf itself */
-                        state = node >= nodeCount ? endOfRayState() : S_NODE;
+                        state = node >= nodeCount ? endOfRayState() : (int)S_NODE;
                     }
                 } else {
                     if (COUNT) {
@@ -311,40 +278,22 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         sched[2] += nNode;
                     }
                     if (state == S_NODE) {
-                        /* AABB::mayHit + the stackless form of BVH::hit's walk; true when the walk
-                         * descends into the node's first child, which is the next node in memory */
-                        auto nodeStep = [&](const float4& n0, const float4& n1) {
-                            if (COUNT)
-                                lc.nodes++;
-                            const uint32_t skip = __float_as_uint(n1.z);
-                            const uint32_t prim = __float_as_uint(n1.w);
-                            const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.ray.o, aux.inv, par.min_hit_distance,
-                                    (ORDERED && !exact) ? amaxCull : amax);
-                            /* select form of: hit & inner -> next node; hit & leaf -> test it; else -> skip */
-                            const bool toLeaf = hit && prim < NODE_EMPTY;
-                            const bool down = hit && prim == NODE_INNER;
-                            const uint32_t next = down ? node + 1 : skip;
-                            leafPrim = toLeaf ? prim : leafPrim;
-                            node = toLeaf ? node : next;
-                            state = toLeaf ? (int)S_LEAF : (int)S_NODE;
-                            if (!toLeaf && node >= nodeCount)
-                                state = endOfRayState();
-                            return down;
-                        };
-                        const uint32_t at = 2 * (nodeBase + node);
+                        /* AABB::mayHit + the stackless form of BVH::hit's walk */
+                        if (COUNT)
+                            lc.nodes++;
+                        const uint32_t at = 2 * node;
                         const float4 n0 = node4(at), n1 = node4(at + 1);
-                        if (PAIRS) {
-                            /* Option for scenes in HBM, measured slower and off (Sponza-class 0.95x,
-                             * 10 M triangles 0.93x): a node step is a dependent memory round trip, so
-                             * the neighbouring node (the first child, usually in the same 128-byte
-                             * line) is fetched with it and a lane that descends takes two steps per trip */
-                            const uint32_t at1 = node + 1 < nodeCount ? at + 2 : at;
-                            const float4 m0 = node4(at1), m1 = node4(at1 + 1);
-                            if (nodeStep(n0, n1))
-                                nodeStep(m0, m1);
-                        } else {
-                            nodeStep(n0, n1);
-                        }
+                        const uint32_t skip = __float_as_uint(n1.z);
+                        const uint32_t word = __float_as_uint(n1.w);
+                        const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.o, aux.inv, par.min_hit_distance, amax);
+                        /* select form of: hit & inner -> first child; hit & leaf -> test it, then skip; else -> skip */
+                        const bool inner = word >= NODE_CHILD;
+                        const bool toLeaf = hit && !inner;
+                        leafPrim = toLeaf ? word : leafPrim;
+                        node = (hit && inner) ? (word & NODE_INDEX_MASK) : skip;
+                        state = toLeaf ? (int)S_LEAF : (int)S_NODE;
+                        if (!toLeaf && node >= nodeCount)
+                            state = endOfRayState();
                     }
                 }
             }
@@ -389,14 +338,15 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 
     if (inBlock) {
         /* SensorRGB::finishPixel (sensor_rgb.hpp:82-87) */
-        const float invSamples = 1.0f / (float)samples;
-        float* out = args.frame + 3 * (size_t)pixel;
-        out[0] = invSamples * ps.acc0;
-        out[1] = invSamples * ps.acc1;
-        out[2] = invSamples * ps.acc2;
+        const Slot acc = ps.get(SLOT_ACC);
+        const uint32_t pxy = ps.getW(SLOT_SRDIR);
+        float* out = args.frame + 3 * ((size_t)(pxy >> 16) * args.width + (pxy & 0xffffu));
+        out[0] = args.invSamples * acc.x;
+        out[1] = args.invSamples * acc.y;
+        out[2] = args.invSamples * acc.z;
     }
     if (COUNT && args.counters && inBlock) {
-        atomicAdd((unsigned long long*)&args.counters->samples, (unsigned long long)samples);
+        atomicAdd((unsigned long long*)&args.counters->samples, (unsigned long long)args.samplesSqrt * args.samplesSqrt);
         atomicAdd((unsigned long long*)&args.counters->rays, (unsigned long long)lc.rays);
         atomicAdd((unsigned long long*)&args.counters->node_visits, (unsigned long long)lc.nodes);
         atomicAdd((unsigned long long*)&args.counters->leaf_tests, (unsigned long long)lc.leaves);
@@ -416,8 +366,6 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 constexpr uint32_t FEAT_BASIC = FEAT_GGX | FEAT_GLASS;
 constexpr uint32_t FEAT_ALL = FEAT_TEXTURES | FEAT_MODPHONG | FEAT_ENVMAP | FEAT_LENS | FEAT_TWOSIDED | FEAT_GGX | FEAT_GLASS | FEAT_SPHERES;
 
-/* one launcher per instantiation, each defined in its own translation unit;
- * ldsBytes is the dynamic LDS size (0 for the HBM variants) */
 /* getGroundTruth (wpt_k_groundtruth.hip): array[k] is the device array of GroundTruth bit k or NULL */
 struct GroundTruthArgs {
     SceneView scene;
@@ -429,8 +377,9 @@ struct GroundTruthArgs {
 };
 void launchGroundTruth(const GroundTruthArgs& args, hipStream_t stream);
 
-void launchBasicLds(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream);
-void launchBasicLdsPairs(const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream);
+/* one launcher per instantiation, each defined in its own translation unit; sceneLdsBytes is the size of the scene
+ * copy behind the cold path words in LDS (0 for the kernels that fetch the scene from HBM) */
+void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream);

@@ -12,13 +12,14 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libwurblpt_hip.so")
+    # WPT_LIB_DIR: a second build of the pair of libraries (wurblpt_amd/csrc/Makefile, LIB=...), for experiments
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("WPT_LIB_DIR", "lib"), "libwurblpt_hip.so")
 
 
 EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_scene_upload", "wpt_scene_free", "wpt_scene_check",
            "wpt_postproc_to_srgb", "wpt_postproc_max_luminance", "wpt_postproc_uniform_rational_quantization",
            "wpt_postproc_scale_luminance", "wpt_postproc_host", "wpt_ground_truth_device", "wpt_ground_truth", "wpt_render_bands_device", "wpt_render_bands",
-           "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_kernel_name",
+           "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_set_top_nodes", "wpt_kernel_name",
            "wpt_last_error"]
 
 

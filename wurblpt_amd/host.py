@@ -13,7 +13,8 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libwurblpt_host.so")
+    # WPT_LIB_DIR: a second build of the pair of libraries (wurblpt_amd/csrc/Makefile, LIB=...), for experiments
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("WPT_LIB_DIR", "lib"), "libwurblpt_host.so")
 
 
 def lib():
