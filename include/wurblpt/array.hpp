@@ -1,100 +1,34 @@
 /*
- * array.hpp -- minimal in-memory 2D image container for textures and sensor frames.
+ * array.hpp -- the image container of textures, sensor frames and ground truth arrays.
  *
- * The reference uses libtgd's TGD::ArrayContainer / TGD::Array<T> for this
- * (texture_image.hpp:45, sensor_rgb.hpp:37); libtgd is an external library, so this
- * framework carries its own small container with the same element order:
- * x fastest, then y, components interleaved; copies share the pixel storage.
+ * The reference uses libtgd's TGD::ArrayContainer / TGD::Array<T> for this (texture_image.hpp:45,
+ * sensor_rgb.hpp:37) and its applications spell the type TGD::Array<float> (wurblpt-cornellbox.cpp:271).
+ * libtgd is an external library; where it is not installed, include/tgd/array.hpp of this repository provides the
+ * container under the same names, and WurblPT:: sees it through the aliases below either way.
  */
 #pragma once
 
-#include <cstddef>
-#include <cstdint>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <string>
-#include <vector>
+#if defined(__has_include)
+#if __has_include(<tgd/array.hpp>)
+#include <tgd/array.hpp>
+#else
+#include "../tgd/array.hpp"
+#endif
+#else
+#include "../tgd/array.hpp"
+#endif
 
 namespace WurblPT {
 
-enum ComponentType { uint8 = 0, uint16 = 1, float32 = 2, int32 = 3 };
-
-inline size_t componentTypeSize(ComponentType t) { return t == uint8 ? 1 : t == uint16 ? 2 : 4; }
-
-class TagList
-{
-private:
-    std::map<std::string, std::string> _tags;
-
-public:
-    void set(const std::string& key, const std::string& value) { _tags[key] = value; }
-    std::string value(const std::string& key, const std::string& def = std::string()) const
-    {
-        auto it = _tags.find(key);
-        return it == _tags.end() ? def : it->second;
-    }
-    bool contains(const std::string& key) const { return _tags.find(key) != _tags.end(); }
-};
-
-class ArrayContainer
-{
-private:
-    size_t _dims[2];
-    size_t _comps;
-    ComponentType _type;
-    std::shared_ptr<std::vector<unsigned char>> _data;
-    std::shared_ptr<TagList> _globalTags;
-
-public:
-    ArrayContainer() : _dims { 0, 0 }, _comps(0), _type(uint8), _globalTags(new TagList) {}
-    ArrayContainer(size_t width, size_t height, size_t comps, ComponentType type) :
-        _dims { width, height }, _comps(comps), _type(type),
-        _data(new std::vector<unsigned char>(width * height * comps * componentTypeSize(type), 0)),
-        _globalTags(new TagList)
-    {
-    }
-
-    size_t dimensionCount() const { return 2; }
-    size_t dimension(size_t i) const { return _dims[i]; }
-    size_t componentCount() const { return _comps; }
-    ComponentType componentType() const { return _type; }
-    size_t componentSize() const { return componentTypeSize(_type); }
-    size_t elementCount() const { return _dims[0] * _dims[1]; }
-    size_t elementSize() const { return _comps * componentSize(); }
-    size_t dataSize() const { return elementCount() * elementSize(); }
-    void* data() { return _data ? _data->data() : nullptr; }
-    const void* data() const { return _data ? _data->data() : nullptr; }
-    TagList& globalTagList() { return *_globalTags; }
-    const TagList& globalTagList() const { return *_globalTags; }
-
-    template<typename T> T* get(size_t elementIndex)
-    {
-        return reinterpret_cast<T*>(_data->data() + elementIndex * elementSize());
-    }
-    template<typename T> const T* get(size_t elementIndex) const
-    {
-        return reinterpret_cast<const T*>(_data->data() + elementIndex * elementSize());
-    }
-    template<typename T> T* get(size_t x, size_t y) { return get<T>(y * _dims[0] + x); }
-    template<typename T> const T* get(size_t x, size_t y) const { return get<T>(y * _dims[0] + x); }
-};
-
-template<typename T> struct ComponentTypeOf;
-template<> struct ComponentTypeOf<uint8_t> { static constexpr ComponentType value = uint8; };
-template<> struct ComponentTypeOf<uint16_t> { static constexpr ComponentType value = uint16; };
-template<> struct ComponentTypeOf<float> { static constexpr ComponentType value = float32; };
-template<> struct ComponentTypeOf<int32_t> { static constexpr ComponentType value = int32; };
-
-template<typename T> class Array : public ArrayContainer
-{
-public:
-    Array() {}
-    Array(size_t width, size_t height, size_t comps) : ArrayContainer(width, height, comps, ComponentTypeOf<T>::value) {}
-    T* operator[](size_t elementIndex) { return this->template get<T>(elementIndex); }
-    const T* operator[](size_t elementIndex) const { return this->template get<T>(elementIndex); }
-    T* at(size_t x, size_t y) { return this->template get<T>(x, y); }
-    const T* at(size_t x, size_t y) const { return this->template get<T>(x, y); }
-};
+using TGD::Array;
+using TGD::ArrayContainer;
+using TGD::ComponentType;
+using TGD::ComponentTypeOf;
+using TGD::TagList;
+using TGD::componentTypeSize;
+using TGD::float32;
+using TGD::int32;
+using TGD::uint16;
+using TGD::uint8;
 
 }

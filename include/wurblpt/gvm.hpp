@@ -105,6 +105,8 @@ template<typename T, int N> struct vector {
     vector<T, 3> xyz() const requires(N >= 3) { return vector<T, 3>(values[0], values[1], values[2]); }
     vector<T, 3> rgb() const requires(N >= 3) { return vector<T, 3>(values[0], values[1], values[2]); }
 
+    friend vector radians(const vector& p) { vector o; for (int i = 0; i < N; i++) o[i] = radians(p[i]); return o; }
+    friend vector degrees(const vector& p) { vector o; for (int i = 0; i < N; i++) o[i] = degrees(p[i]); return o; }
     friend vector operator+(const vector& p, const vector& q) { vector o; for (int i = 0; i < N; i++) o[i] = p[i] + q[i]; return o; }
     friend vector operator-(const vector& p, const vector& q) { vector o; for (int i = 0; i < N; i++) o[i] = p[i] - q[i]; return o; }
     friend vector operator*(const vector& p, const vector& q) { vector o; for (int i = 0; i < N; i++) o[i] = p[i] * q[i]; return o; }

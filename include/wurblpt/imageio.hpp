@@ -7,7 +7,7 @@
  * (P5, P6; 8 and 16 bit), PFM (Pf, PF), Radiance HDR (RLE and flat), JPEG (jpeg.hpp) and OpenEXR
  * scanline files (exr.hpp).  A file that cannot be decoded is reported and the importer substitutes
  * its dummy texture, as the reference does for any file libtgd cannot load (import.hpp:131-134).
- * saveImage() writes PNG, PGM/PPM, PFM and OpenEXR.
+ * saveImage() writes PNG, PGM/PPM, PFM, PFS, OpenEXR and this framework's raw array file (*.tgd).
  *
  * Convention: the returned array has row 0 at the BOTTOM of the picture (texture coordinate
  * v = 0, texture_image.hpp:85-212), i.e. formats that store the top row first are flipped.
@@ -715,9 +715,70 @@ inline bool savePnm(const ArrayContainer& img, std::vector<unsigned char>& out, 
     return true;
 }
 
+/* Portable Floating-point Streams (pfstools), one frame: text header, then every channel as width x height floats,
+ * top row first; channels are named X Y Z (three components), Y (one) or C0, C1, ... */
+inline bool savePfs(const ArrayContainer& img, std::vector<unsigned char>& out, std::string& error)
+{
+    if (img.componentType() != float32 || img.componentCount() < 1) {
+        error = "PFS takes float data";
+        return false;
+    }
+    const size_t w = img.dimension(0), h = img.dimension(1), comps = img.componentCount();
+    std::string header = "PFS1\n" + std::to_string(w) + " " + std::to_string(h) + "\n" + std::to_string(comps) + "\n0\n";
+    static const char* xyz[3] = { "X", "Y", "Z" };
+    for (size_t c = 0; c < comps; c++)
+        header += (comps == 3 ? std::string(xyz[c]) : comps == 1 ? std::string("Y") : "C" + std::to_string(c)) + "\n0\n";
+    header += "ENDH";
+    out.assign(header.begin(), header.end());
+    const float* data = static_cast<const float*>(img.data());
+    for (size_t c = 0; c < comps; c++)
+        for (size_t y = 0; y < h; y++)
+            for (size_t x = 0; x < w; x++) {
+                const float v = data[((h - 1 - y) * w + x) * comps + c];
+                const unsigned char* p = reinterpret_cast<const unsigned char*>(&v);
+                out.insert(out.end(), p, p + 4);
+            }
+    return true;
 }
 
-/* Saves an image by file name extension: .png (uint8/uint16), .ppm/.pgm/.pnm (uint8/uint16), .pfm (float), .exr (float).
+/* This framework's raw array file: the line "WPTARRAY1 <width> <height> <components> <type>\n" (type 0 uint8, 1 uint16,
+ * 2 float32, 3 int32), then the data as it lies in memory (row 0 first, little endian) */
+inline bool saveRaw(const ArrayContainer& img, std::vector<unsigned char>& out, std::string&)
+{
+    const std::string header = "WPTARRAY1 " + std::to_string(img.dimension(0)) + " " + std::to_string(img.dimension(1)) + " "
+        + std::to_string(img.componentCount()) + " " + std::to_string(int(img.componentType())) + "\n";
+    out.assign(header.begin(), header.end());
+    const unsigned char* data = static_cast<const unsigned char*>(img.data());
+    out.insert(out.end(), data, data + img.dataSize());
+    return true;
+}
+inline bool loadRaw(const std::vector<unsigned char>& b, ArrayContainer& img, std::string& error)
+{
+    size_t eol = 0;
+    while (eol < b.size() && eol < 128 && b[eol] != '\n')
+        eol++;
+    unsigned long long w = 0, h = 0, comps = 0;
+    int type = -1;
+    const std::string line(b.begin(), b.begin() + eol);
+    if (eol >= b.size() || sscanf(line.c_str(), "WPTARRAY1 %llu %llu %llu %d", &w, &h, &comps, &type) != 4 || type < 0 || type > 3 || comps < 1
+            || comps > 64 || w == 0 || h == 0 || w > (1ull << 24) || h > (1ull << 24)) {
+        error = "damaged array file header";
+        return false;
+    }
+    const size_t bytes = size_t(w) * size_t(h) * size_t(comps) * componentTypeSize(ComponentType(type));
+    if (b.size() - (eol + 1) < bytes) {
+        error = "array file is shorter than its header says";
+        return false;
+    }
+    img = ArrayContainer(w, h, comps, ComponentType(type));
+    memcpy(img.data(), b.data() + eol + 1, bytes);
+    return true;
+}
+
+}
+
+/* Saves an image by file name extension: .png (uint8/uint16), .ppm/.pgm/.pnm (uint8/uint16), .pfm / .pfs / .exr (float),
+ * .tgd (any type, this framework's raw layout).
  * The counterpart of the reference's TGD::save() calls for the formats this build writes. */
 inline bool saveImage(const ArrayContainer& img, const std::string& filename, std::string* error = nullptr)
 {
@@ -733,6 +794,10 @@ inline bool saveImage(const ArrayContainer& img, const std::string& filename, st
         ok = savePng(img, bytes, err);
     else if (ext == "exr")
         ok = saveExr(img, bytes, err);
+    else if (ext == "pfs")
+        ok = savePfs(img, bytes, err);
+    else if (ext == "tgd")
+        ok = saveRaw(img, bytes, err);
     else if (ext == "pfm" && img.componentType() != float32)
         err = "PFM takes float data";
     else if ((ext == "ppm" || ext == "pgm" || ext == "pnm") && img.componentType() == float32)
@@ -775,6 +840,8 @@ inline ArrayContainer loadImage(const std::string& filename, std::string* error 
         ok = loadExr(b, img, err);
     } else if (b.size() >= 3 && b[0] == 0xff && b[1] == 0xd8) {
         ok = loadJpeg(b, img, err);
+    } else if (b.size() >= 10 && !memcmp(b.data(), "WPTARRAY1 ", 10)) {
+        ok = loadRaw(b, img, err);
     } else {
         const size_t dot = filename.find_last_of('.');
         std::string ext = dot == std::string::npos ? "" : filename.substr(dot + 1);

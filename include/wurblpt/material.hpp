@@ -234,6 +234,31 @@ public:
     const vec4 refractiveIndexOfSurroundingMedium;
     const bool chromaticDispersion;
 
+    /* material_glass.hpp:154-188: absorption coefficient that leaves the given colour after targetDistance (1 cm), and back */
+    static float transparentColorToAbsorption(float transparentColor, float targetDistance = 0.01f)
+    {
+        return max(-log(transparentColor) / targetDistance, 0.0f);
+    }
+    static vec3 transparentColorToAbsorption(const vec3& c, float targetDistance = 0.01f)
+    {
+        return vec3(transparentColorToAbsorption(c.r(), targetDistance), transparentColorToAbsorption(c.g(), targetDistance),
+                transparentColorToAbsorption(c.b(), targetDistance));
+    }
+    static vec4 transparentColorToAbsorption(const vec4& c, float targetDistance = 0.01f)
+    {
+        return vec4(transparentColorToAbsorption(c.r(), targetDistance), transparentColorToAbsorption(c.g(), targetDistance),
+                transparentColorToAbsorption(c.b(), targetDistance), transparentColorToAbsorption(c.a(), targetDistance));
+    }
+    static float absorptionToTransparentColor(float absorption, float targetDistance = 0.01f)
+    {
+        return exp(-absorption / targetDistance);
+    }
+    static vec3 absorptionToTransparentColor(const vec3& a, float targetDistance = 0.01f)
+    {
+        return vec3(absorptionToTransparentColor(a.r(), targetDistance), absorptionToTransparentColor(a.g(), targetDistance),
+                absorptionToTransparentColor(a.b(), targetDistance));
+    }
+
     MaterialGlass(const vec4& absorption, const vec4& refractiveIndexOfMaterial,
             const vec4& refractiveIndexOfSurroundingMedium = vec4(refractiveIndexOfVacuum)) :
         Material(nullptr), absorption(absorption), refractiveIndexOfMaterial(refractiveIndexOfMaterial),

@@ -290,6 +290,21 @@ public:
         return handles;
     }
 
+    /* scene.hpp:113-125: a component handed over through its base class (wurblpt-furnace-test.cpp:52-67 keeps its
+     * spheres as SceneComponent*).  The kernels know the components that create triangles and spheres; any other
+     * kind is owned as usual and reported by updateBVH() / mcpt(), which refuse the scene: there is no CPU fallback
+     * that could ask a user-defined component for its hitables. */
+    std::vector<const Hitable*> take(SceneComponent* component, HotSpotType hotSpotType = ColdSpot)
+    {
+        if (MeshInstance* instance = dynamic_cast<MeshInstance*>(component))
+            return take(instance, hotSpotType);
+        if (Sphere* sphere = dynamic_cast<Sphere*>(component))
+            return take(sphere, hotSpotType);
+        _error = "a scene component of a kind the HIP kernels do not know was taken as hitable";
+        _components.push_back(std::unique_ptr<SceneComponent>(component));
+        return std::vector<const Hitable*>();
+    }
+
     EnvironmentMap* take(EnvironmentMap* envmap)
     {
         _envmap = std::unique_ptr<EnvironmentMap>(envmap);

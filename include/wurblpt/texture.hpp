@@ -16,6 +16,7 @@
 #include "../wurblpt_hip.h"
 #include "array.hpp"
 #include "gvm.hpp"
+#include "imageio.hpp"
 #include "scene_component.hpp"
 
 namespace WurblPT {
@@ -192,6 +193,25 @@ inline Texture* createTextureImage(const ArrayContainer& img, LinearizeSRGBType 
     bool lin = linearizeSRGBType == LinearizeSRGB_On
         || (linearizeSRGBType == LinearizeSRGB_Auto && (img.componentType() == uint8 || img.componentType() == uint16));
     return new TextureImage(img, lin, coordFactor, coordOffset, valFactor, valOffset);
+}
+
+/* texture_image.hpp:343-366: the same from an image file (wurblpt-sponza.cpp:56, wurblpt-envmap.cpp:73); decoded by
+ * imageio.hpp (PNG, JPEG, TGA, PNM / PFM, Radiance HDR, OpenEXR).  NULL and a line on stderr when the file cannot be used. */
+inline Texture* createTextureImage(const std::string& imgFileName, LinearizeSRGBType linearizeSRGBType = LinearizeSRGB_Auto,
+        const vec2& coordFactor = vec2(1.0f), const vec2& coordOffset = vec2(0.0f),
+        const vec4& valFactor = vec4(1.0f), const vec4& valOffset = vec4(0.0f))
+{
+    std::string error;
+    const ArrayContainer img = loadImage(imgFileName, &error);
+    if (img.elementCount() == 0) {
+        fprintf(stderr, "%s\n", error.c_str());
+        return nullptr;
+    }
+    if (img.componentType() != uint8 && img.componentType() != uint16 && img.componentType() != float32) {
+        fprintf(stderr, "%s: not a valid texture image\n", imgFileName.c_str());
+        return nullptr;
+    }
+    return createTextureImage(img, linearizeSRGBType, coordFactor, coordOffset, valFactor, valOffset);
 }
 
 inline int FlattenContext::indexOf(const Texture* tex)

@@ -29,6 +29,7 @@
 #include "mesh.hpp"
 #include "mpi.hpp"
 #include "postproc.hpp"
+#include "prng.hpp"
 #include "scene.hpp"
 #include "sensor.hpp"
 #include "texture.hpp"

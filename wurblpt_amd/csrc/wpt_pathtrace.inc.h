@@ -56,6 +56,13 @@ constexpr uint32_t NODE_INDEX_MASK = 0x3fffffffu;
 constexpr uint32_t COLD_BYTES = SLOT_COUNT * WG * 16; /* the paths' cold words: 32 KiB of LDS per workgroup */
 /* with the scene behind them three workgroups still fit into a CU's 160 KiB */
 constexpr uint32_t LDS_SCENE_MAX_BYTES = 21 * 1024;
+/* Five waves per SIMD.  The kernel is a chain of short dependent pieces (LDS fetch, box test, ballot, branch), so a
+ * wave is ready to issue a vector instruction about a third of the time and four waves leave half of a SIMD's issue
+ * slots empty (r02 PMC pass: 7.8e11 vector instructions in 1.35 s = 47 % of the slots).  A fifth wave needs at most 96
+ * registers per lane and 160 KiB / 20 waves = 8 KiB of LDS per wave: exactly the eight slots without a scene, or seven
+ * slots (launches whose path length gates are open) with a scene of up to 4 KiB behind every five waves. */
+constexpr int WG5 = 320;
+constexpr uint32_t LDS_SCENE_MAX_BYTES_5 = 160 * 1024 / 4 - 7 * WG5 * 16;
 
 struct KernelArgs {
     SceneView sv;
@@ -82,12 +89,13 @@ struct KernelArgs {
 /* lane states, in scheduling priority order for ties */
 enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5 };
 
-template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC>
-__global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
+template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, int WGSZ = WG, bool GATES = true>
+__global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args)
 {
-    /* [ cold path words: SLOT_COUNT x WG float4 ][ LDSSCENE: nodes, triangle positions ] */
+    /* [ cold path words: slots x WGSZ float4 ][ LDSSCENE: nodes, triangle positions ] */
     extern __shared__ float4 lds[];
-    float4* const ldsScene = lds + SLOT_COUNT * WG;
+    constexpr int WG = WGSZ; /* (shadows the default workgroup size) */
+    float4* const ldsScene = lds + (GATES ? SLOT_COUNT : SLOT_COUNT - 1) * WG;
 
     const SceneView& sv = args.sv;
     const wpt_params& par = args.par;
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     fa.invSamplesSqrt = args.invSamplesSqrt;
 
     /* ---- per-lane state: the pixel's path (wpt_blocks.h; its cold words in LDS) and the traversal registers ---- */
-    PathLds<WG> ps;
+    PathLds<WG, GATES> ps;
     ps.base = lds + threadIdx.x;
     pathStateInit(ps, pixel, pixel % args.width, pixel / args.width);
     LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
@@ -380,6 +388,10 @@ void launchGroundTruth(const GroundTruthArgs& args, hipStream_t stream);
 /* one launcher per instantiation, each defined in its own translation unit; sceneLdsBytes is the size of the scene
  * copy behind the cold path words in LDS (0 for the kernels that fetch the scene from HBM) */
 void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
+/* five waves per SIMD: 320-thread workgroups; the Gateless ones are for launches with open path length gates */
+void launchBasicLds5Gateless(const KernelArgs& args, uint32_t lanes, size_t sceneLdsBytes, hipStream_t stream);
+void launchBasic5(const KernelArgs& args, uint32_t lanes, hipStream_t stream);
+void launchFull5(const KernelArgs& args, uint32_t lanes, hipStream_t stream);
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream);
