@@ -329,6 +329,17 @@ template<typename T> quaternion<T> toQuat(const vector<T, 3>& dir1, const vector
     return toQuat(acos(cosAngle), cross(dir1, dir2));
 }
 
+/* rotation about x, then y, then z by the three angles of `euler` (reference gvm.hpp:1873-1890): the product
+ * qz * qy * qx of the three axis rotations written out, half angles, terms in the reference's order */
+template<typename T> quaternion<T> toQuat(const vector<T, 3>& euler)
+{
+    const T half = T(0.5l);
+    const T cx = cos(half * euler.x()), sx = sin(half * euler.x());
+    const T cy = cos(half * euler.y()), sy = sin(half * euler.y());
+    const T cz = cos(half * euler.z()), sz = sin(half * euler.z());
+    return quaternion<T>(sx * cy * cz - cx * sy * sz, cx * sy * cz + sx * cy * sz, cx * cy * sz - sx * sy * cz, cx * cy * cz + sx * sy * sz);
+}
+
 template<typename T> matrix<T, 3, 3> toMat3(const quaternion<T>& q)
 {
     matrix<T, 3, 3> m;

@@ -238,6 +238,15 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
             leaveBelow = leaveBelow < 1 ? 1 : leaveBelow;
             if (COUNT)
                 sched[0]++;
+#ifdef WPT_PREFETCH
+            /* the node a lane will test next is known one iteration ahead: its two quadwords are requested at the end
+             * of the iteration before, so that the fetch runs behind the loop's ballots and branches */
+            float4 pn0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pn1 = pn0;
+            if (state == S_NODE) {
+                pn0 = node4(2 * node);
+                pn1 = node4(2 * node + 1);
+            }
+#endif
             for (;;) {
                 const int nNode = __popcll(__ballot(state == S_NODE));
                 const int nLeaf = __popcll(__ballot(state == S_LEAF));
@@ -279,6 +288,12 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
                             amax = c.a;
                         }
                         state = node >= nodeCount ? endOfRayState() : (int)S_NODE;
+#ifdef WPT_PREFETCH
+                        if (state == S_NODE) {
+                            pn0 = node4(2 * node);
+                            pn1 = node4(2 * node + 1);
+                        }
+#endif
                     }
                 } else {
                     if (COUNT) {
@@ -289,8 +304,12 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
                         /* AABB::mayHit + the stackless form of BVH::hit's walk */
                         if (COUNT)
                             lc.nodes++;
+#ifdef WPT_PREFETCH
+                        const float4 n0 = pn0, n1 = pn1;
+#else
                         const uint32_t at = 2 * node;
                         const float4 n0 = node4(at), n1 = node4(at + 1);
+#endif
                         const uint32_t skip = __float_as_uint(n1.z);
                         const uint32_t word = __float_as_uint(n1.w);
                         const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.o, aux.inv, par.min_hit_distance, amax);
@@ -302,6 +321,12 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
                         state = toLeaf ? (int)S_LEAF : (int)S_NODE;
                         if (!toLeaf && node >= nodeCount)
                             state = endOfRayState();
+#ifdef WPT_PREFETCH
+                        if (state == S_NODE) {
+                            pn0 = node4(2 * node);
+                            pn1 = node4(2 * node + 1);
+                        }
+#endif
                     }
                 }
             }
