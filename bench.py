@@ -11,7 +11,11 @@ full frame on their GPU and the frames are summed onto rank 0 with one RCCL redu
 (blocks are disjoint, so the sum is exact).  The frame is fixed, so scaling is "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline      HBM roofline of the path-tracing kernel from ALGORITHMIC bytes
+  roofline      the bound that binds the path-tracing kernel: scenes that fit LDS never touch HBM while they traverse,
+                so their line is priced against the vector pipes (bound "valu": executed lane-operations per second
+                from the committed PMC pass x the live sample rate, against 1024 SIMD-32 at 2.4 GHz); scenes in HBM
+                against the HBM roofline from ALGORITHMIC bytes.  The algorithmic GB/s is reported for
+                both as `algorithmic_gbps`.
   cpu_baseline  the CPU restatement (oracle/, "port") timed on this box's host cores
 """
 import argparse
@@ -26,6 +30,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# vector pipes: 256 CUs x 4 SIMD-32 at up to 2.4 GHz, one lane-operation per lane and cycle (MI355X_MICROARCH.md:
+# "a wave issues each VALU instruction over 2 cycles"; 157.3 TFLOP/s f32 = 2 flops per lane-operation)
+VALU_PEAK_GLANEOPS = 256 * 4 * 32 * 2.4
+LDS_SCENE_MAX_BYTES = 21 * 1024  # wpt_pathtrace.inc.h: scenes up to this size are traversed from LDS
 
 WORKLOADS = {
     # name: (builder kwargs, width, height, samples_sqrt)
@@ -137,17 +145,24 @@ def main():
     ap.add_argument("--top-nodes", type=int, default=-1, help="BVH nodes stored level by level in front of the array (wpt_set_top_nodes; experiments)")
     args = ap.parse_args()
 
+    # before anything initialises the HIP / HSA runtime: the host driver only supports dmabuf IPC
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d runs in %d process(es): launch it as python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ... (or plain python bench.py for --gpus 1)"
+                         % (args.gpus, world, args.gpus, args.gpus))
+    if world > 1 and not os.environ.get("WPT_HOST_THREADS"):
+        # torch.distributed.run exports OMP_NUM_THREADS=1; the host-side BVH build (rank 0 only, see below) may use its share
+        os.environ["OMP_NUM_THREADS"] = str(max(1, host_cores()))
+
     import numpy as np
     import torch
     import torch.distributed as dist
     from wurblpt_amd import device, host
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the path tracer has no CPU fallback"
     # rehearsal on a one-GPU box: WPT_BENCH_DEVICE=0 WPT_BENCH_BACKEND=gloo puts every rank on cuda:0
     # (RCCL refuses two ranks on one device); the driver's runs use neither
@@ -156,7 +171,6 @@ def main():
     backend = os.environ.get("WPT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -170,7 +184,16 @@ def main():
     width, height, ssqrt = w["width"], w["height"], w["samples_sqrt"]
     spp = ssqrt * ssqrt
     pixels = width * height
-    scene = build_scene(w)
+    if world > 1:
+        # one builder per node: rank 0 builds and flattens the scene (with all host cores: the BVH build of the
+        # 10 M triangle scene takes most of a minute), the other ranks map its file from /dev/shm
+        from wurblpt_amd import scenefile
+        shared = "/dev/shm/wpt_bench_scene_%s.bin" % os.environ.get("MASTER_PORT", "0")
+        t_build = time.perf_counter()
+        scene = scenefile.build_once(lambda: build_scene(w), shared, rank, dist.barrier)
+        t_build = time.perf_counter() - t_build
+    else:
+        scene = build_scene(w)
     if args.variant:
         device.lib().wpt_set_launch_config(0, args.variant)
     if args.top_nodes >= 0:
@@ -181,7 +204,7 @@ def main():
     main_stream = torch.cuda.current_stream()
 
     # ---- counted pass (untimed): work per sample for the roofline's algorithmic bytes ----
-    count_sqrt = min(ssqrt, 4)
+    count_sqrt = ssqrt  # the counting build renders the timed frame, sample for sample
     counters = torch.zeros(6, dtype=torch.int64, device="cuda")
     dscene.render_block_into(frame, count_sqrt, None, params, counters, main_stream)
     torch.cuda.synchronize()
@@ -279,14 +302,37 @@ def main():
             achieved = bps * sum(s for _, s in launches) / elapsed / 1e9
             basis = "algorithmic bytes of rank 0's %d overlapping launches / the timed region" % len(launches)
         traffic = None
+        pmc = {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and world == 1:
-            # HBM bytes per launch of this workload, from the committed rocprofv3 PMC passes
-            # (FETCH_SIZE / WRITE_SIZE, separate runs; tools/profile_round.sh + tools/collect_profiles.py)
+            # per launch of this workload, from the committed rocprofv3 PMC passes (separate runs;
+            # tools/profile_round.sh + tools/collect_profiles.py): HBM bytes (FETCH_SIZE / WRITE_SIZE), vector
+            # instructions (SQ_INSTS_VALU) and the fraction of lanes active in them (VALUUtilization)
             try:
-                traffic = json.load(open(tpath)).get("workloads", {}).get(name, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(tpath)).get("workloads", {}).get(name, {})
+                traffic = pmc.get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                pmc, traffic = {}, None
+        in_lds = int(scene.d.node_count) * 32 + int(scene.d.tri_count) * 48 <= LDS_SCENE_MAX_BYTES
+        counted = "%dx%d x %d spp" % (width, height, count_sqrt ** 2)
+        per_sample = {k: cnt[k] / float(cnt["samples"]) for k in ("rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")}
+        common = {"traffic": traffic, "basis": basis, "kernel": device.lib().wpt_kernel_name().decode(), "avg_launch_ms": avg_ms,
+                  "launches": len(launches), "bytes_per_sample": bps, "algorithmic_gbps": achieved, "per_sample": per_sample, "counted_on": counted}
+        if in_lds and pmc.get("valu_insts_per_sample") and launches:
+            # the scene is LDS resident: what binds is vector issue.  Executed lane-operations = wave instructions x 64 lanes x
+            # the fraction of lanes active in them (both from the committed PMC pass of this workload), at the live sample rate
+            lane_ops = pmc["valu_insts_per_sample"] * 64.0 * pmc["valu_active_lane_fraction"] * avg_samples / (avg_ms * 1e-3) / 1e9
+            roofline = dict(common, bound="valu", achieved=lane_ops, peak=VALU_PEAK_GLANEOPS, unit="Glane-op/s", frac=lane_ops / VALU_PEAK_GLANEOPS,
+                            issue_slot_frac=pmc["valu_insts_per_sample"] * 2.0 * avg_samples / (avg_ms * 1e-3) / (1024 * 2.4e9),
+                            active_lane_fraction=pmc["valu_active_lane_fraction"], valu_insts_per_sample=pmc["valu_insts_per_sample"],
+                            note="scene in LDS: HBM sees the frame only (traffic); frac = issue_slot_frac x active_lane_fraction; "
+                                 "counters from " + pmc.get("pmc_file", "profiles/"))
+        else:
+            roofline = dict(common, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s", frac=min(1.0, achieved / HBM_PEAK_GBPS))
+            if in_lds:
+                roofline["note"] = "scene in LDS and no committed PMC pass for this workload: algorithmic bytes never reach HBM, frac is capped at 1"
+            if traffic and launches:
+                roofline["hbm_gbps_from_traffic"] = traffic / (avg_ms * 1e-3) / 1e9
         out = {
             "metric": "Msamples/s", "value": total_samples / elapsed / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -298,12 +344,7 @@ def main():
                            "pixel blocks of %d from a shared counter over %d GPUs (%d streams each) + RCCL reduce" % (block_size, world, args.streams)
                            if args.dynamic_blocks else
                            "bands of %d rows, band i to rank i mod %d, one launch per GPU + RCCL reduce" % (max(1, block_size // width), world))},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis,
-                         "kernel": device.lib().wpt_kernel_name().decode(), "avg_launch_ms": avg_ms,
-                         "launches": len(launches), "bytes_per_sample": bps,
-                         "per_sample": {k: cnt[k] / float(cnt["samples"]) for k in ("rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")},
-                         "counted_on": "%dx%d x %d spp" % (width, height, count_sqrt ** 2)},
+            "roofline": roofline,
             "frame_finite": ok,
         }
         if verified is not None:
@@ -315,6 +356,11 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if rank == 0:
+            try:
+                os.remove(shared)  # /dev/shm is memory
+            except OSError:
+                pass
         dist.destroy_process_group()
 
 

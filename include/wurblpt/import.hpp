@@ -13,6 +13,10 @@
  *    MTL order, shapes in file order inside each), so an import is reproducible;
  *  - images come from imageio.hpp (row 0 = bottom) instead of libtgd; files it cannot decode become
  *    the dummy textures the reference uses for load failures.
+ *
+ * Interface (function names, flags, argument order) and the material rules follow marlam/wurblpt (import.hpp), which is
+ * distributed under the MIT licence: Copyright (c) 2023 Martin Lambers <marlam@marlam.de>; the permission notice is
+ * reproduced in the LICENSE file of this repository.  The implementation is this repository's own.
  */
 #pragma once
 
@@ -160,76 +164,74 @@ inline bool importIntoScene(Scene& scene, const std::string& filename, const Tra
         textureFileMap.insert(std::pair<std::string, ArrayContainer>(name, img));
     }
 
-    /* the materials */
+    /* the materials.  An MTL record becomes the simplest material that can show it (the reference's rules,
+     * import.hpp:288-387): Lambertian when nothing but a diffuse colour / texture without alpha is set; glass, on
+     * request, for an untextured transparent record; modified Phong for everything else. */
     std::vector<Material*> materials;
     std::vector<std::string> materialNames;
     std::vector<bool> materialIsLight, materialWantsTangents;
     std::map<std::string, Texture*> textureMap;
+    const bool lightsOff = (importBits & ImportBitDisableLightSources) != 0;
+    auto textureOf = [&](const std::string& file, const ObjTexOpt& opt, int* components = nullptr,
+            LinearizeSRGBType linearize = LinearizeSRGB_Auto, float bumpMultiplier = -1.0f /* not a bump map */) -> Texture* {
+        if (file.empty())
+            return nullptr;
+        return importTexture(textureMap, textureFileMap, file, opt.scale, opt.originOffset, components, linearize, bumpMultiplier);
+    };
     for (const ObjMaterial& M : objMaterials) {
-        vec3 dif = vec3(M.diffuse), spc = vec3(M.specular), emi = vec3(M.emission), tra = vec3(M.transmittance);
-        const float shi = M.shininess, ior = M.ior;
-        float opa = M.dissolve;
-        if (importBits & ImportBitInvertedTf)
-            tra = vec3(1.0f) - tra;
-        if (opa >= 1.0f && max(tra) < 1.0f) {
-            opa = average(tra);
-            tra = vec3(1.0f) - tra;
+        /* opacity and transmission filter, reconciled: `d` and `Tf` are two spellings of one thing in the wild */
+        vec3 transmission = (importBits & ImportBitInvertedTf) ? vec3(1.0f) - vec3(M.transmittance) : vec3(M.transmittance);
+        float opacity = M.dissolve;
+        const vec3 diffuse(M.diffuse), specular(M.specular), emission(M.emission);
+        if (opacity >= 1.0f && max(transmission) < 1.0f) {
+            opacity = average(transmission);
+            transmission = vec3(1.0f) - transmission;
         }
-        if (opa < 1.0f && max(tra) <= 0.0f)
-            tra = (1.0f - opa) * dif;
-        Texture* nrmTex = nullptr;
-        if (M.normalTex.size() > 0)
-            nrmTex = importTexture(textureMap, textureFileMap, M.normalTex, M.normalOpt.scale, M.normalOpt.originOffset, nullptr, LinearizeSRGB_Off);
-        else if (M.bumpTex.size() > 0)
-            nrmTex = importTexture(textureMap, textureFileMap, M.bumpTex, M.bumpOpt.scale, M.bumpOpt.originOffset, nullptr, LinearizeSRGB_Off, M.bumpOpt.bumpMultiplier);
-        int imgComp = 0;
-        Texture* difTex = nullptr;
-        if (M.diffuseTex.size() > 0)
-            difTex = importTexture(textureMap, textureFileMap, M.diffuseTex, M.diffuseOpt.scale, M.diffuseOpt.originOffset, &imgComp);
-        const bool difTexHasAlpha = (difTex && (imgComp == 2 || imgComp == 4));
-        const bool lightsOff = (importBits & ImportBitDisableLightSources) != 0;
-        if (!difTexHasAlpha && max(spc) <= 0.0f && M.specularTex.size() == 0
-                && (lightsOff || (max(emi) <= 0.0f && M.emissiveTex.size() == 0)) && opa >= 1.0f && M.alphaTex.size() == 0) {
-            MaterialLambertian* mat = new MaterialLambertian(dif, difTex);
-            mat->normalTex = nrmTex;
-            materials.push_back(mat);
-            materialIsLight.push_back(false);
-            materialWantsTangents.push_back(mat->normalTex != nullptr);
-        } else if ((importBits & ImportBitWithGlass) && !difTex && M.specularTex.size() == 0 && max(emi) <= 0.0f
-                && M.emissiveTex.size() == 0 && opa < 1.0f && M.alphaTex.size() == 0) {
-            MaterialGlass* mat = new MaterialGlass(transparentColorToAbsorption(dif), ior);
-            mat->normalTex = nrmTex;
-            materials.push_back(mat);
-            materialIsLight.push_back(false);
-            materialWantsTangents.push_back(mat->normalTex != nullptr);
+        if (opacity < 1.0f && max(transmission) <= 0.0f)
+            transmission = (1.0f - opacity) * diffuse;
+        Texture* normalMap = M.normalTex.empty()
+            ? textureOf(M.bumpTex, M.bumpOpt, nullptr, LinearizeSRGB_Off, M.bumpOpt.bumpMultiplier)
+            : textureOf(M.normalTex, M.normalOpt, nullptr, LinearizeSRGB_Off);
+        int diffuseComponents = 0;
+        Texture* diffuseMap = textureOf(M.diffuseTex, M.diffuseOpt, &diffuseComponents);
+        const bool diffuseMapHasAlpha = diffuseMap && (diffuseComponents == 2 || diffuseComponents == 4);
+        const bool emits = !lightsOff && (max(emission) > 0.0f || !M.emissiveTex.empty());
+        const bool hasSpecular = max(specular) > 0.0f || !M.specularTex.empty();
+        const bool opaque = opacity >= 1.0f && M.alphaTex.empty();
+        Material* made = nullptr;
+        bool isLight = false;
+        if (opaque && !diffuseMapHasAlpha && !hasSpecular && !emits) {
+            made = new MaterialLambertian(diffuse, diffuseMap);
+        } else if ((importBits & ImportBitWithGlass) && opacity < 1.0f && M.alphaTex.empty() && !diffuseMap && M.specularTex.empty()
+                && max(emission) <= 0.0f && M.emissiveTex.empty()) {
+            made = new MaterialGlass(transparentColorToAbsorption(diffuse), M.ior);
         } else {
-            MaterialModPhong* mat = new MaterialModPhong;
-            mat->normalTex = nrmTex;
-            mat->haveNIR = false;
-            int specComp = 0;
-            mat->diffuse = vec4(dif, 0.0f);
-            mat->diffuseTex = difTex;
-            mat->diffuseTexHasAlpha = difTexHasAlpha;
-            mat->specular = vec4(spc, 0.0f);
-            if (M.specularTex.size() > 0)
-                mat->specularTex = importTexture(textureMap, textureFileMap, M.specularTex, M.specularOpt.scale, M.specularOpt.originOffset, &specComp);
-            mat->specularTexHasAlpha = (mat->specularTex && (specComp == 2 || specComp == 4));
-            mat->shininess = shi;
-            if (M.shininessTex.size() > 0)
-                mat->shininessTex = importTexture(textureMap, textureFileMap, M.shininessTex, M.shininessOpt.scale, M.shininessOpt.originOffset, nullptr, LinearizeSRGB_Off);
-            mat->opacity = opa;
-            if (M.alphaTex.size() > 0)
-                mat->opacityTex = importTexture(textureMap, textureFileMap, M.alphaTex, M.alphaOpt.scale, M.alphaOpt.originOffset, nullptr, LinearizeSRGB_Off);
-            mat->indexOfRefraction = ior;
-            mat->transmissive = vec4(tra, 0.0f);
-            if (!lightsOff)
-                mat->emissive = vec4(emi, 0.0f);
-            if (!lightsOff && M.emissiveTex.size() > 0)
-                mat->emissiveTex = importTexture(textureMap, textureFileMap, M.emissiveTex, M.emissiveOpt.scale, M.emissiveOpt.originOffset);
-            materials.push_back(mat);
-            materialIsLight.push_back(dot(mat->emissive, mat->emissive) > 0.0f || mat->emissiveTex);
-            materialWantsTangents.push_back(mat->normalTex != nullptr);
+            MaterialModPhong* phong = new MaterialModPhong;
+            int specularComponents = 0;
+            phong->haveNIR = false;
+            phong->diffuse = vec4(diffuse, 0.0f);
+            phong->diffuseTex = diffuseMap;
+            phong->diffuseTexHasAlpha = diffuseMapHasAlpha;
+            phong->specular = vec4(specular, 0.0f);
+            phong->specularTex = textureOf(M.specularTex, M.specularOpt, &specularComponents);
+            phong->specularTexHasAlpha = phong->specularTex && (specularComponents == 2 || specularComponents == 4);
+            phong->shininess = M.shininess;
+            phong->shininessTex = textureOf(M.shininessTex, M.shininessOpt, nullptr, LinearizeSRGB_Off);
+            phong->opacity = opacity;
+            phong->opacityTex = textureOf(M.alphaTex, M.alphaOpt, nullptr, LinearizeSRGB_Off);
+            phong->indexOfRefraction = M.ior;
+            phong->transmissive = vec4(transmission, 0.0f);
+            if (!lightsOff) {
+                phong->emissive = vec4(emission, 0.0f);
+                phong->emissiveTex = textureOf(M.emissiveTex, M.emissiveOpt);
+            }
+            isLight = dot(phong->emissive, phong->emissive) > 0.0f || phong->emissiveTex;
+            made = phong;
         }
+        made->normalTex = normalMap;
+        materials.push_back(made);
+        materialIsLight.push_back(isLight);
+        materialWantsTangents.push_back(normalMap != nullptr);
         materialNames.push_back(M.name);
     }
     for (auto it = textureMap.cbegin(); it != textureMap.cend(); it++)

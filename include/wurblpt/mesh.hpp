@@ -2,6 +2,11 @@
  * mesh.hpp -- triangle mesh storage with the reference's layout (mesh.hpp:39-189):
  * interleaved float vertices pos3, nrm3, [tc2], [tan3] (6 / 8 / 11 floats) and uint indices;
  * MeshInstance = mesh + material + transformation.
+ *
+ * Interface (class, member and function names, argument order) and the arithmetic that the bit-parity contract fixes
+ * follow marlam/wurblpt, which is distributed under the MIT licence: Copyright (c) 2023 Martin Lambers
+ * <marlam@marlam.de>; the permission notice is reproduced in the LICENSE file of this repository.  The implementation
+ * below is this repository's own.
  */
 #pragma once
 
@@ -39,57 +44,47 @@ public:
     vec2 texcoord(unsigned int i) const { return vec2(vertices.data() + i * vertexSize() + texcoordOffset); }
     vec3 tangent(unsigned int i) const { return vec3(vertices.data() + i * vertexSize() + tangentOffset); }
 
-    /* Positions, normals and indices are required; texture coordinates may be empty (or all
-     * zero), in which case there are no tangents either.  T is baked into the vertices. */
+private:
+    static bool anyNonZero(const std::vector<vec2>& coordinates)
+    {
+        for (const vec2& c : coordinates)
+            if (c.x() != 0.0f || c.y() != 0.0f)
+                return true;
+        return false;
+    }
+    static void put3(float* destination, const vec3& v)
+    {
+        destination[0] = v.x();
+        destination[1] = v.y();
+        destination[2] = v.z();
+    }
+
+public:
+    /* Positions, normals and indices are required.  Texture coordinates may be missing or all zero: the mesh then
+     * stores none, and no tangents either (there is nothing to derive them from).  T is applied to the vertices here,
+     * once: positions through its 4x4 matrix, normals and tangents through its normal matrix. */
     Mesh(const std::vector<vec3>& pos, const std::vector<vec3>& nrm, const std::vector<vec2>& tc,
             const std::vector<unsigned int>& ind, const Transformation& T = Transformation(), bool wantTangents = true) :
-        indices(ind)
+        haveTexCoords(anyNonZero(tc)), haveTangents(wantTangents && haveTexCoords), indices(ind)
     {
-        assert(pos.size() > 0 && pos.size() == nrm.size());
-        assert(pos.size() == tc.size() || tc.size() == 0);
-        assert(ind.size() > 0 && ind.size() % 3 == 0);
-        bool allTexCoordsAreZero = true;
-        for (size_t i = 0; i < tc.size(); i++) {
-            if (tc[i] != vec2(0.0f, 0.0f)) {
-                allTexCoordsAreZero = false;
-                break;
-            }
-        }
-        if (allTexCoordsAreZero)
-            wantTangents = false;
-        std::vector<vec3> tng;
-        if (wantTangents)
-            tng = computeTangents(pos, nrm, tc, ind);
-        haveTexCoords = !allTexCoordsAreZero;
-        haveTangents = wantTangents;
-        vertices.resize(pos.size() * vertexSize());
-        const bool transform = !T.isIdentity();
-        mat4 M(1.0f);
-        mat3 N(1.0f);
-        if (transform) {
-            M = T.toMat4();
-            N = T.toNormalMatrix();
-        }
+        assert(!pos.empty() && nrm.size() == pos.size() && (tc.empty() || tc.size() == pos.size()));
+        assert(!ind.empty() && ind.size() % 3 == 0);
+        const std::vector<vec3> tangents = haveTangents ? computeTangents(pos, nrm, tc, ind) : std::vector<vec3>();
+        const bool baked = !T.isIdentity();
+        const mat4 toWorld = baked ? T.toMat4() : mat4(1.0f);
+        const mat3 normalToWorld = baked ? T.toNormalMatrix() : mat3(1.0f);
+        const size_t stride = vertexSize();
+        vertices.resize(pos.size() * stride);
         for (size_t i = 0; i < pos.size(); i++) {
-            float* d = vertices.data() + i * vertexSize();
-            vec3 p = pos[i];
-            vec3 n = nrm[i];
-            if (transform) {
-                p = (M * vec4(p, 1.0f)).xyz();
-                n = N * n;
-            }
-            d[0] = p.x(); d[1] = p.y(); d[2] = p.z();
-            d[3] = n.x(); d[4] = n.y(); d[5] = n.z();
+            float* vertex = vertices.data() + i * stride;
+            put3(vertex + positionOffset, baked ? (toWorld * vec4(pos[i], 1.0f)).xyz() : pos[i]);
+            put3(vertex + normalOffset, baked ? normalToWorld * nrm[i] : nrm[i]);
             if (haveTexCoords) {
-                d[6] = tc[i][0];
-                d[7] = tc[i][1];
+                vertex[texcoordOffset] = tc[i].x();
+                vertex[texcoordOffset + 1] = tc[i].y();
             }
-            if (haveTangents) {
-                vec3 t = tng[i];
-                if (transform)
-                    t = N * t;
-                d[8] = t.x(); d[9] = t.y(); d[10] = t.z();
-            }
+            if (haveTangents)
+                put3(vertex + tangentOffset, baked ? normalToWorld * tangents[i] : tangents[i]);
         }
     }
 };

@@ -13,6 +13,10 @@
  * its shape rules (a shape ends at `g` and `o`; `usemtl` changes the material inside a shape,
  * :2877-2996).  tests/test_import.py compares it with the vendored parser itself
  * (oracle/ref_probe.cpp) on the fixture files of tests/golden/obj.
+ *
+ * The behaviour reproduced here (number parsing, triangulation, shape and material rules) is tinyobjloader's, which
+ * is distributed under the MIT licence: Copyright (c) 2012-Present, Syoyo Fujita and many contributors; the permission
+ * notice is reproduced in the LICENSE file of this repository.  The code is this repository's own.
  */
 #pragma once
 

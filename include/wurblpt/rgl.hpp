@@ -4,6 +4,12 @@
  * powitacq_rgb.inl:728-803), builds the five interpolants / sample warps the model uses exactly
  * as its constructor does (powitacq_rgb.inl:213-310,893-1003) and appends them to the flat
  * float pool that the device reads.
+ *
+ * The model and the order of its operations are those of powitacq_rgb (Jonathan Dupuy and Wenzel Jakob, "An Adaptive
+ * Parameterization for Efficient Material Acquisition and Rendering"), which is distributed under the 3-clause BSD
+ * licence: Copyright 2018 Jonathan Dupuy and Wenzel Jakob.  Redistribution and use in source and binary forms, with or
+ * without modification, are permitted provided that the conditions of that licence are met; its full text, with the
+ * disclaimer, is reproduced in the LICENSE file of this repository.
  */
 #pragma once
 

@@ -3,6 +3,11 @@
  * reference's Transformation (transformation.hpp:45-207).  toMat4()/toNormalMatrix() feed
  * vertex baking (mesh.hpp) and fromLookAt() feeds the camera, so their arithmetic follows
  * the reference (:105-137).
+ *
+ * Interface (class, member and function names, argument order) and the arithmetic that the bit-parity contract fixes
+ * follow marlam/wurblpt, which is distributed under the MIT licence: Copyright (c) 2023 Martin Lambers
+ * <marlam@marlam.de>; the permission notice is reproduced in the LICENSE file of this repository.  The implementation
+ * below is this repository's own.
  */
 #pragma once
 
@@ -10,6 +15,8 @@
 
 namespace WurblPT {
 
+/* A pose: scale, then rotate, then translate.  Composition appends on the right, so that T.translate(v) moves
+ * along T's own (rotated and scaled) axes. */
 class Transformation
 {
 public:
@@ -22,43 +29,48 @@ public:
     {
     }
 
-    bool isIdentity() const
-    {
-        return all(equal(translation, vec3(0.0f))) && rotation.w >= 1.0f && all(equal(scaling, vec3(1.0f)));
-    }
-
-    bool operator==(const Transformation& o) const
-    {
-        return all(equal(translation, o.translation)) && rotation == o.rotation && all(equal(scaling, o.scaling));
-    }
-
-    vec3 operator*(const vec3& v) const { return translation + (rotation * (v * scaling)); }
+    /* applied to a point (40 % dearer than a 4x4 product on the reference author's machine, transformation.hpp:40-42;
+     * meshes therefore bake toMat4() instead) */
+    vec3 operator*(const vec3& point) const { return translation + (rotation * (point * scaling)); }
 
     void translate(const vec3& v) { translation += rotation * (v * scaling); }
     void rotate(const quat& q) { rotation *= q; }
     void scale(const vec3& s) { scaling *= s; }
 
+    bool isIdentity() const
+    {
+        const bool unmoved = all(equal(translation, vec3(0.0f)));
+        const bool unturned = rotation.w >= 1.0f; /* a unit quaternion with w = 1 has no vector part */
+        const bool unscaled = all(equal(scaling, vec3(1.0f)));
+        return unmoved && unturned && unscaled;
+    }
+    bool operator==(const Transformation& other) const
+    {
+        return all(equal(translation, other.translation)) && rotation == other.rotation && all(equal(scaling, other.scaling));
+    }
+
+    /* translation matrix times rotation matrix, columns then scaled: the order of the products is part of the bits */
     mat4 toMat4() const
     {
-        mat4 M(vec4(1.0f, 0.0f, 0.0f, 0.0f), vec4(0.0f, 1.0f, 0.0f, 0.0f), vec4(0.0f, 0.0f, 1.0f, 0.0f),
-                vec4(translation, 1.0f));
+        mat4 M(vec4(1.0f, 0.0f, 0.0f, 0.0f), vec4(0.0f, 1.0f, 0.0f, 0.0f), vec4(0.0f, 0.0f, 1.0f, 0.0f), vec4(translation, 1.0f));
         M *= WurblPT::toMat4(rotation);
         M.scale(scaling);
         return M;
     }
-
+    /* for directions that must stay perpendicular to surfaces: the rotation alone (normals are renormalised later) */
     mat3 toNormalMatrix() const { return toMat3(rotation); }
 
+    /* the pose of a viewer at `eye` looking at `center`: first the rotation that takes -z to the view direction, then
+     * the one about that direction that takes the turned y axis to the viewer's up vector */
     static Transformation fromLookAt(const vec3& eye, const vec3& center, const vec3& up = vec3(0.0f, 1.0f, 0.0f))
     {
-        vec3 f = normalize(center - eye);
-        vec3 s = normalize(cross(f, up));
-        vec3 u = cross(s, f);
-        quat rot0 = toQuat(vec3(0.0f, 0.0f, -1.0f), f);
-        quat rot1 = toQuat(rot0 * vec3(0.0f, 1.0f, 0.0f), u);
-        return Transformation(eye, rot1 * rot0);
+        const vec3 forward = normalize(center - eye);
+        const vec3 side = normalize(cross(forward, up));
+        const vec3 viewerUp = cross(side, forward);
+        const quat aim = toQuat(vec3(0.0f, 0.0f, -1.0f), forward);
+        const quat roll = toQuat(aim * vec3(0.0f, 1.0f, 0.0f), viewerUp);
+        return Transformation(eye, roll * aim);
     }
-
     vec3 lookFrom() const { return translation; }
     vec3 lookAt() const { return translation + rotation * vec3(0.0f, 0.0f, -1.0f); }
     vec3 up() const { return rotation * vec3(0.0f, 1.0f, 0.0f); }

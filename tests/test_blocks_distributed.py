@@ -19,12 +19,19 @@ WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np, torch, torch.distributed as dist
-from wurblpt_amd import blocks, host
+from wurblpt_amd import blocks, host, scenefile
 from tests import oracle_loader
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 W, H, S = 48, 40, 3
-sc = host.cornell(W, H, 1, 2)
+# one builder: rank 0 builds and flattens the scene, the others map its file (their host library never builds anything)
+built = []
+def build():
+    built.append(rank)
+    return host.cornell(W, H, 1, 2)
+sc = scenefile.build_once(build, sys.argv[1] + ".scene", rank, dist.barrier)
+assert built == ([0] if rank == 0 else []), built
+assert isinstance(sc, scenefile.FileScene) == (rank != 0)
 orc = oracle_loader.load("portable")
 frame = torch.zeros((H, W, 3), dtype=torch.float32)
 store = dist.distributed_c10d._get_default_store()

@@ -12,6 +12,12 @@
  * compiled for the device (math policy: wpt_math.h) and by the test oracle (math policy: its
  * portable or libm back end), which is pinned against golden vectors produced by the reference's
  * own implementation (oracle/ref_probe.cpp).
+ *
+ * The model and the order of its operations are those of powitacq_rgb (Jonathan Dupuy and Wenzel Jakob, "An Adaptive
+ * Parameterization for Efficient Material Acquisition and Rendering"), which is distributed under the 3-clause BSD
+ * licence: Copyright 2018 Jonathan Dupuy and Wenzel Jakob.  Redistribution and use in source and binary forms, with or
+ * without modification, are permitted provided that the conditions of that licence are met; its full text, with the
+ * disclaimer, is reproduced in the LICENSE file of this repository.
  */
 #ifndef WPT_RGL_H
 #define WPT_RGL_H

@@ -169,6 +169,15 @@ def furnace(width, height, material=0, slices=64):
     return HostScene(h, width, height, "furnace(material=%d)" % material)
 
 
+def mis_test(width, height, with_hot_spots=True):
+    """The scene of wurblpt-mis-test.cpp: four GGX plates under four sphere lights in a white room; the lights are hot
+    spots (next-event estimation with MIS) or not (material sampling alone)."""
+    L = lib()
+    L.wpt_host_mis_test.restype = C.c_void_p
+    h = L.wpt_host_mis_test(1 if with_hot_spots else 0, width, height)
+    return HostScene(h, width, height, "mis_test(hot_spots=%d)" % with_hot_spots)
+
+
 def spheres(width, height, variant=0):
     """Scenes with analytic spheres (HitableSphere): 0 = textured / GGX / glass / mirror spheres lit by
     a sphere light and a quad light (both hot spots), 1 = the same under a cube environment map,

@@ -577,6 +577,56 @@ extern "C" wpt_host_scene* wpt_host_spheres(int variant, unsigned int width, uns
     return wptHostFinish(scenePtr, width, height, radians(45.0f), vec3(0.0f, 2.0f, 6.0f), vec3(0.0f, 0.7f, 0.0f), 0.0f, 1.0f);
 }
 
+/* The scene of the reference's statistical test for multiple importance sampling (wurblpt-mis-test.cpp:32-97, after
+ * Veach's four plates under four lights): a white room, four GGX plates of growing roughness tilted towards the
+ * camera, four sphere lights of growing size and equal radiance.  withHotSpots = 0 leaves the lights to material
+ * sampling alone; the two renderings must converge to the same image (:118-133). */
+extern "C" wpt_host_scene* wpt_host_mis_test(int withHotSpots, unsigned int width, unsigned int height)
+{
+    Scene* scenePtr = new Scene;
+    Scene& scene = *scenePtr;
+    Material* white = scene.take(new MaterialLambertian(vec4(0.8f)));
+    /* walls: unit quads scaled by five; where each stands, and how it is turned to face the room */
+    struct Wall { vec3 where; float degrees; vec3 axis; };
+    const vec3 yAxis(0.0f, 1.0f, 0.0f), xAxis(1.0f, 0.0f, 0.0f);
+    const Wall walls[6] = {
+        { vec3(-2.6f, 0.0f, 0.0f), +90.0f, yAxis }, { vec3(+2.6f, 0.0f, 0.0f), -90.0f, yAxis },
+        { vec3(0.0f, 0.0f, +5.0f), 180.0f, yAxis }, { vec3(0.0f, 0.0f, -4.6f), 0.0f, yAxis },
+        { vec3(0.0f, -2.499, 0.0f), +90.0f, xAxis }, { vec3(0.0f, -5.0f, 0.0f), -90.0f, xAxis } };
+    Mesh* wallMesh[6];
+    for (int i = 0; i < 6; i++) {
+        Transformation T;
+        T.translate(walls[i].where);
+        T.scale(vec3(5.0f));
+        T.rotate(toQuat(radians(walls[i].degrees), walls[i].axis));
+        wallMesh[i] = scene.take(generateQuad(T));
+    }
+    for (int i = 0; i < 6; i++)
+        scene.take(new MeshInstance(wallMesh[i], white));
+    /* plates: roughness, position, tilt about x */
+    const float roughness[4] = { 0.001f, 0.008, 0.03f, 0.1f };
+    const vec3 platePosition[4] = { vec3(0.0f, -4.2f, -4.2f), vec3(0.0f, -4.6f, -3.8f), vec3(0.0f, -4.8f, -3.4f), vec3(0.0f, -4.9f, -3.0f) };
+    const float plateTilt[4] = { -35.0f, -47.0f, -59.0f, -71.0f };
+    Material* plateMaterial[4];
+    for (int i = 0; i < 4; i++)
+        plateMaterial[i] = scene.take(new MaterialGGX(vec3(1.0f), vec2(roughness[i])));
+    for (int i = 0; i < 4; i++) {
+        const Transformation T(platePosition[i], toQuat(radians(plateTilt[i]), xAxis), vec3(2.0f, 0.3f, 1.0f));
+        scene.take(new MeshInstance(scene.take(generateQuad(T)), plateMaterial[i]));
+    }
+    /* lights: x position and radius */
+    const float lightX[4] = { -1.5f, -0.5f, +0.5f, +1.5f };
+    const float lightRadius[4] = { 0.032f, 0.08f, 0.2f, 0.5f };
+    Material* lightMaterial[4];
+    for (int i = 0; i < 4; i++)
+        lightMaterial[i] = scene.take(new LightDiffuse(vec3(4.0f)));
+    for (int i = 0; i < 4; i++)
+        scene.take(new Sphere(lightMaterial[i], Transformation(vec3(lightX[i], -3.5f, -4.0f), quat::null(), vec3(lightRadius[i]))),
+                withHotSpots ? HotSpot : ColdSpot);
+    /* camera at (0, -4.5, -1.2) looking down -z (Transformation without rotation), 50 degrees */
+    return wptHostFinish(scenePtr, width, height, radians(50.0f), vec3(0.0f, -4.5f, -1.2f), vec3(0.0f, -4.5f, -2.2f), 0.0f, 1.0f);
+}
+
 /* Builds the tables of a measured BRDF file as MaterialRGL does (include/wurblpt/rgl.hpp).
  * Returns the number of floats of the table pool (0 on error, message on stderr); copies at most
  * `capacity` of them. */
