@@ -739,7 +739,7 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     args.heavyMin = g_heavyMin ? g_heavyMin : (smallScene ? 16u : 8u);
     args.leafBias = g_leafBias ? g_leafBias : (smallScene ? 16u : 32u);
     /* kernel choice.  Low nibble of the variant word: 1 = keep the scene in HBM, 2 = all features. */
-    const uint32_t force = g_variant & 0x7u;
+    const uint32_t force = g_variant & 0x3u;
     const bool basic = (need & ~FEAT_BASIC) == 0 && force != 2;
     const bool lds = smallScene && force != 1;
     const bool rgl = (need & FEAT_RGL) != 0; /* measured BRDFs have their own instantiation */
@@ -781,6 +781,8 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
             launchBasic(args, grid, stream);
         else if (five)
             launchFull5(args, block_size, stream);
+        else if ((scene->nodeCount >= (1u << 21) && (g_variant & 0x40u) == 0) || (g_variant & 0x04u) != 0)
+            launchFullWalk(args, grid, stream); /* tree of 64 MiB and more (variant 0x40: never, 0x04: always) */
         else
             launchFull(args, grid, stream);
     }

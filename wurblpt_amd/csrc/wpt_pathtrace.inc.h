@@ -89,9 +89,11 @@ struct KernelArgs {
 /* lane states, in scheduling priority order for ties */
 enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5 };
 
-template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, int WGSZ = WG, bool GATES = true>
+/* TUNE only tells apart two builds of one instantiation that are compiled with different options (Makefile) */
+template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, int WGSZ = WG, bool GATES = true, int TUNE = 0>
 __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args)
 {
+    constexpr bool PREFETCH = !LDSSCENE;
     /* [ cold path words: slots x WGSZ float4 ][ LDSSCENE: nodes, triangle positions ] */
     extern __shared__ float4 lds[];
     constexpr int WG = WGSZ; /* (shadows the default workgroup size) */
@@ -238,15 +240,13 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
             leaveBelow = leaveBelow < 1 ? 1 : leaveBelow;
             if (COUNT)
                 sched[0]++;
-#ifdef WPT_PREFETCH
             /* the node a lane will test next is known one iteration ahead: its two quadwords are requested at the end
              * of the iteration before, so that the fetch runs behind the loop's ballots and branches */
             float4 pn0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pn1 = pn0;
-            if (state == S_NODE) {
+            if (PREFETCH && state == S_NODE) {
                 pn0 = node4(2 * node);
                 pn1 = node4(2 * node + 1);
             }
-#endif
             for (;;) {
                 const int nNode = __popcll(__ballot(state == S_NODE));
                 const int nLeaf = __popcll(__ballot(state == S_LEAF));
@@ -288,12 +288,10 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
                             amax = c.a;
                         }
                         state = node >= nodeCount ? endOfRayState() : (int)S_NODE;
-#ifdef WPT_PREFETCH
-                        if (state == S_NODE) {
+                        if (PREFETCH && state == S_NODE) {
                             pn0 = node4(2 * node);
                             pn1 = node4(2 * node + 1);
                         }
-#endif
                     }
                 } else {
                     if (COUNT) {
@@ -304,12 +302,7 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
                         /* AABB::mayHit + the stackless form of BVH::hit's walk */
                         if (COUNT)
                             lc.nodes++;
-#ifdef WPT_PREFETCH
-                        const float4 n0 = pn0, n1 = pn1;
-#else
-                        const uint32_t at = 2 * node;
-                        const float4 n0 = node4(at), n1 = node4(at + 1);
-#endif
+                        const float4 n0 = PREFETCH ? pn0 : node4(2 * node), n1 = PREFETCH ? pn1 : node4(2 * node + 1);
                         const uint32_t skip = __float_as_uint(n1.z);
                         const uint32_t word = __float_as_uint(n1.w);
                         const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.o, aux.inv, par.min_hit_distance, amax);
@@ -321,12 +314,10 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
                         state = toLeaf ? (int)S_LEAF : (int)S_NODE;
                         if (!toLeaf && node >= nodeCount)
                             state = endOfRayState();
-#ifdef WPT_PREFETCH
-                        if (state == S_NODE) {
+                        if (PREFETCH && state == S_NODE) {
                             pn0 = node4(2 * node);
                             pn1 = node4(2 * node + 1);
                         }
-#endif
                     }
                 }
             }
@@ -417,6 +408,8 @@ void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hip
 void launchBasicLds5Gateless(const KernelArgs& args, uint32_t lanes, size_t sceneLdsBytes, hipStream_t stream);
 void launchBasic5(const KernelArgs& args, uint32_t lanes, hipStream_t stream);
 void launchFull5(const KernelArgs& args, uint32_t lanes, hipStream_t stream);
+/* the all-features kernel built for scenes whose frame time is traversal (trees far larger than the caches) */
+void launchFullWalk(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream);
