@@ -74,6 +74,9 @@ int main(int argc, char* argv[])
     }
     fprintf(stderr, "centre pixel: depth %.4f, material \"%s\"\n", gt.cameraSpaceDepths.at(width / 2, height / 2)[0],
             scene.materialNames()[gt.materials.at(width / 2, height / 2)[0]].c_str());
+    /* the run's record in the frame's tags (wurblpt.hpp:425-435 for the CPU; here for the device) */
+    for (const char* tag : { "WURBLPT/SAMPLES_PER_PIXEL", "WURBLPT/COMPILER", "WURBLPT/DEVICE_MODEL", "WURBLPT/DEVICE_COUNT", "WURBLPT/DEVICE_SECONDS", "WURBLPT/DEVICE_KERNEL" })
+        fprintf(stderr, "%s = %s\n", tag, hdr.globalTagList().value(tag).c_str());
 
     /* the same view over the exposure interval [0, 1]: the panel blurs */
     scene.updateBVH(0.0f, 1.0f);

@@ -12,6 +12,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -106,6 +107,7 @@ inline void mcpt(MPICoordinator& mpiCoordinator, Sensor& sensor, const Camera& c
 
     mpiCoordinator.init(width, height, static_cast<float*>(pixelArray->data()), pixelArray->componentCount());
     std::vector<std::string> workerErrors(mpiCoordinator.devices().size());
+    const auto renderStart = std::chrono::steady_clock::now();
     auto worker = [&](size_t w) {
         int device = mpiCoordinator.devices()[w];
         if (device >= 0 && wpt_select_device(device) != WPT_OK) {
@@ -161,6 +163,20 @@ inline void mcpt(MPICoordinator& mpiCoordinator, Sensor& sensor, const Camera& c
     pixelArray->globalTagList().set("WURBLPT/MAX_PATH_COMPONENTS", std::to_string(params.maxPathComponents));
     pixelArray->globalTagList().set("WURBLPT/RUSSIAN_ROULETTE_THRESHOLD", std::to_string(params.rrThreshold));
     pixelArray->globalTagList().set("WURBLPT/DEVICE_KERNEL", wpt_kernel_name());
+    /* the run's record (wurblpt.hpp:393-400,425-435 notes compiler, CPU model, threads and CPU seconds): here the
+     * compiler of the kernels, the device(s) and the wall-clock seconds from scene upload to the finished frame */
+    std::string deviceModel;
+    for (int device : mpiCoordinator.devices()) {
+        int current = device;
+        if (current < 0 && wpt_current_device(&current) != WPT_OK)
+            current = 0;
+        deviceModel += (deviceModel.empty() ? "" : "; ") + std::string(wpt_device_name(current));
+    }
+    pixelArray->globalTagList().set("WURBLPT/COMPILER", wpt_build_info());
+    pixelArray->globalTagList().set("WURBLPT/DEVICE_MODEL", deviceModel);
+    pixelArray->globalTagList().set("WURBLPT/DEVICE_COUNT", std::to_string(mpiCoordinator.devices().size()));
+    pixelArray->globalTagList().set("WURBLPT/DEVICE_SECONDS",
+            std::to_string(std::chrono::duration<double>(std::chrono::steady_clock::now() - renderStart).count()));
 }
 
 inline void mcpt(Sensor& sensor, const Camera& camera, const Scene& scene, unsigned int samplesSqrt, float t0 = 0.0f,

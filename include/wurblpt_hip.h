@@ -321,6 +321,7 @@ typedef struct wpt_scene wpt_scene;
 /* Number of HIP devices (0 if none); selects the device for this thread. */
 int wpt_device_count(void);
 wpt_status wpt_select_device(int device);
+wpt_status wpt_current_device(int* device); /* the calling thread's HIP device */
 
 /* Copies the flattened scene to the current device. */
 wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene);
@@ -442,6 +443,11 @@ wpt_status wpt_set_scheduler_stats(unsigned long long* stats_device);
 
 /* Name of the GPU kernel that wpt_render_block_device launches (for profile matching). */
 const char* wpt_kernel_name(void);
+/* What the reference records about a run for the CPU (wurblpt.hpp:393-400,425-435: COMPILER, CPU_MODEL), for the device:
+ * marketing name and architecture of HIP device `device` ("AMD Instinct MI355X (gfx950:...)", or "" if there is none), and
+ * the compiler and options the kernels were built with.  The strings live until the next call from the same thread. */
+const char* wpt_device_name(int device);
+const char* wpt_build_info(void);
 
 const char* wpt_last_error(void);
 

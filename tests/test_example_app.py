@@ -49,6 +49,12 @@ def test_example_application_renders(tmp_path):
     depth = host.image_load(str(out[0] / "room-depth.pfm"))[:, :, 0]
     # the camera stands 3.4 in front of the room's centre and looks at the back wall (z = -1): depth 4.4 there
     assert abs(depth[50, 40] - 4.4) < 1e-3 and b'material "' in r.stderr
+    # the run's record: device model, count, seconds and the kernels' compiler are in the frame's tags
+    log = r.stderr.decode()
+    assert "WURBLPT/DEVICE_MODEL = " in log and "gfx950" in log and "WURBLPT/DEVICE_COUNT = 1" in log
+    assert "WURBLPT/COMPILER = hipcc / clang" in log and "WURBLPT/SAMPLES_PER_PIXEL = 16" in log
+    seconds = float(log.split("WURBLPT/DEVICE_SECONDS = ")[1].split()[0])
+    assert 0.0 < seconds < 120.0
     assert depth[depth > 0].min() > 1.5 and depth.max() < 4.41 and (depth > 0).mean() > 0.5      # 0 where the view passes the room
     blur = host.image_load(str(out[0] / "room-blur.png"))
     assert blur.shape == png.shape and not np.array_equal(blur, png)

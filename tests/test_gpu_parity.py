@@ -221,17 +221,70 @@ def test_full_size_properties_of_config_2(dev):
     assert bits_equal(frame.cpu().numpy(), a)
 
 
+MITSUBA_CHANNEL_RATIOS = (0.9881, 0.9895, 0.9917)
+
+
 def test_full_size_config_1_against_mitsuba(dev):
-    """Lambertian Cornell at the Mitsuba render's resolution (1024x1024, 64 spp) against the
-    reference tree's converged Mitsuba image, on 16x16 block averages (statistical pin)."""
+    """Lambertian Cornell box at the resolution of the reference tree's converged Mitsuba render (1024x1024) and 1024 spp.
+    What was measured (tools/r02_pins.py, gpurun_out/r02e/pins.txt): against cbox-2500spp.exr the frame differs by
+    0.996 % rel-L2 on 16x16-pixel block means and its channel means are 0.9881 / 0.9895 / 0.9917 of Mitsuba's -- the same
+    numbers at 64, 1024 and 4096 spp, so this is not noise but the systematic difference between WurblPT's Cornell box and
+    Mitsuba's, which the survey measured for the compiled reference itself (1.0 % on block means, channel means within
+    1.3 %).  The pin is therefore two-sided: the frame must keep exactly that distance."""
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ref = np.load(os.path.join(root, "tests", "golden", "cbox_mitsuba_64x64.npy"))
     sc = host.cornell(1024, 1024)
-    img, _ = dev.DeviceScene(sc).render(8)
+    img, _ = dev.DeviceScene(sc).render(32)
     blocks = img[::-1].reshape(64, 16, 64, 16, 3).mean(axis=(1, 3))
     rel = np.sqrt(((blocks - ref) ** 2).sum() / (ref ** 2).sum())
-    assert rel < 0.015, rel
+    assert abs(rel - 0.00996) < 0.0005, rel           # noise at 1024 spp moves it by 2e-5
+    ratios = blocks.mean(axis=(0, 1)) / ref.mean(axis=(0, 1))
+    assert np.allclose(ratios, MITSUBA_CHANNEL_RATIOS, atol=5e-4), ratios
+    coarse = blocks.reshape(16, 4, 16, 4, 3).mean(axis=(1, 3))
+    coarse_ref = ref.reshape(16, 4, 16, 4, 3).mean(axis=(1, 3))
+    assert abs(np.sqrt(((coarse - coarse_ref) ** 2).sum() / (coarse_ref ** 2).sum()) - 0.0099) < 0.0005
+
+
+def _block_means(img, size):
+    h, w, _ = img.shape
+    return img.reshape(h // size, size, w // size, size, 3).mean(axis=(1, 3))
+
+
+def test_reference_mis_test_converges_to_material_sampling(dev):
+    """wurblpt-mis-test.cpp:118-133, the reference's own statistical test: the scene rendered with material sampling
+    alone (lights are no hot spots) and with multiple importance sampling must converge to the same image.
+    Measured at 960x540 (gpurun_out/r02e/pins.txt): with ONE light the two agree to the noise; with the reference's four
+    lights in a row MIS is darker by 0.49 % at 100 and at 1600 spp alike.  That deficit is the reference's rule that a
+    next-event ray counts only if the CHOSEN hot spot is its nearest hit (wurblpt.hpp:208-218): seen from the side walls
+    the four spheres line up, and a ray aimed at one that meets another first is dropped although the pdf it was drawn
+    with covers both.  Both facts are pinned."""
+    W, H, S = 960, 540, 24
+    frames = {}
+    for mask in (8, 15):
+        for hot in (False, True):
+            frames[(mask, hot)], _ = dev.DeviceScene(host.mis_test(W, H, hot, mask)).render(S)
+            assert np.isfinite(frames[(mask, hot)]).all()
+    # one light (the largest): nothing can be in front of the chosen hot spot but the plates, which both estimators see alike
+    a, b = frames[(8, False)], frames[(8, True)]
+    assert abs(a.mean() / b.mean() - 1.0) < 1.5e-3, a.mean() / b.mean()
+    ba, bb = _block_means(a, 60), _block_means(b, 60)
+    assert np.sqrt(((ba - bb) ** 2).sum() / (bb ** 2).sum()) < 4e-3
+    # the reference's scene
+    a, b = frames[(15, False)], frames[(15, True)]
+    assert abs(a.mean() / b.mean() - 1.0049) < 1.5e-3, a.mean() / b.mean()
+    ba, bb = _block_means(a, 60), _block_means(b, 60)
+    assert np.sqrt(((ba - bb) ** 2).sum() / (bb ** 2).sum()) < 8e-3     # 5.5e-3 measured, 1.5e-3 of it noise
+    assert np.abs(ba - bb).max() / bb.mean() < 0.05                     # no block is off by more than 5 % of the mean
+
+
+def test_reference_mis_test_scene_bit_exact(dev, oracle):
+    """the same scene (four GGX plates from mirror-like to rough, sphere lights as hot spots) against the oracle"""
+    for hot in (False, True):
+        sc = host.mis_test(96, 54, hot)
+        ref, rc = oracle.render(sc, 3)
+        got, gc = dev.DeviceScene(sc).render(3, with_counters=True)
+        assert bits_equal(got, ref) and gc == rc
 
 
 def test_sponza_like_textures_modphong_envmap_bit_exact(dev, oracle):

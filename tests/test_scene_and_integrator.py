@@ -71,17 +71,20 @@ def test_work_per_sample_config_2(oracle):
 
 
 def test_against_the_mitsuba_render_shipped_with_the_reference(oracle):
-    """wurblpt-cornellbox/mitsuba/cbox-2500spp.exr, block-averaged to 64x64 by
-    tests/golden/make_cbox_fixture.py.  Statistical: the survey measured 1.0 % rel-L2 between the
-    reference's own render and this image on 16x16 block averages."""
+    """wurblpt-cornellbox/mitsuba/cbox-2500spp.exr, block-averaged to 64x64 by tests/golden/make_cbox_fixture.py.
+    Statistical, and two-sided: WurblPT's Cornell box is not Mitsuba's -- the survey measured 1.0 % rel-L2 on block means
+    between the compiled reference and this image -- and the restatement keeps that distance: 1.00 % at 256 spp (1.04 %
+    at 64 spp), channel means 0.9883 / 0.9897 / 0.9919 of Mitsuba's, the values the GPU reaches at 4096 spp
+    (tests/test_gpu_parity.py::test_full_size_config_1_against_mitsuba)."""
     ref = np.load(os.path.join(ROOT, "tests", "golden", "cbox_mitsuba_64x64.npy"))
     sc = host.cornell(256, 256)
-    frame, _ = oracle.render(sc, 8)
+    frame, _ = oracle.render(sc, 16)
     img = frame[::-1]  # WurblPT's row 0 is the bottom row; the EXR is stored top-down
     blocks = img.reshape(64, 4, 64, 4, 3).mean(axis=(1, 3))
     rel = np.sqrt(((blocks - ref) ** 2).sum() / (ref ** 2).sum())
-    assert rel < 0.03, rel
-    assert np.allclose(blocks.reshape(-1, 3).mean(0), ref.reshape(-1, 3).mean(0), rtol=0.02)
+    assert abs(rel - 0.0100) < 0.001, rel
+    ratios = blocks.reshape(-1, 3).mean(0) / ref.reshape(-1, 3).mean(0)
+    assert np.allclose(ratios, [0.9881, 0.9895, 0.9917], atol=1.5e-3), ratios
 
 
 def test_thread_count_and_block_invariance(oracle):

@@ -388,6 +388,14 @@ wpt_status wpt_select_device(int device)
     return WPT_OK;
 }
 
+wpt_status wpt_current_device(int* device)
+{
+    if (!device)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "device is NULL");
+    HIP_TRY(hipGetDevice(device));
+    return WPT_OK;
+}
+
 wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
 {
     if (!out_scene)
@@ -773,6 +781,8 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
         const bool five = (g_variant & 0x08u) != 0; /* five waves per SIMD */
         if (basic && lds && five && gatesOpen && ldsBytes <= LDS_SCENE_MAX_BYTES_5)
             launchBasicLds5Gateless(args, block_size, ldsBytes, stream);
+        else if (basic && lds && (g_variant & 0x10u))
+            launchBasicLdsPlain(args, grid, ldsBytes, stream);
         else if (basic && lds)
             launchBasicLds(args, grid, ldsBytes, stream);
         else if (basic && five)
@@ -1083,6 +1093,26 @@ wpt_status wpt_set_scheduler_stats(unsigned long long* stats_device)
 const char* wpt_kernel_name(void)
 {
     return "wpt_pathtrace";
+}
+
+const char* wpt_device_name(int device)
+{
+    thread_local std::string name;
+    name.clear();
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        name = std::string(prop.name) + " (" + prop.gcnArchName + ", " + std::to_string(prop.multiProcessorCount) + " CUs)";
+    return name.c_str();
+}
+
+const char* wpt_build_info(void)
+{
+#if defined(__clang_version__)
+    return "hipcc / clang " __clang_version__ ", --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt "
+           "-fno-gpu-flush-denormals-to-zero";
+#else
+    return "unknown compiler";
+#endif
 }
 
 const char* wpt_last_error(void)

@@ -93,7 +93,9 @@ enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5 
 template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, int WGSZ = WG, bool GATES = true, int TUNE = 0>
 __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args)
 {
-    constexpr bool PREFETCH = !LDSSCENE;
+    constexpr bool PREFETCH = !LDSSCENE && TUNE == 0;
+    /* leaf tests read the corners from LDS in the ray's component order (no animated instances: those move the corners first) */
+    constexpr bool PERMUTED = LDSSCENE && !(F & FEAT_ANIM) && TUNE != 2;
     /* [ cold path words: slots x WGSZ float4 ][ LDSSCENE: nodes, triangle positions ] */
     extern __shared__ float4 lds[];
     constexpr int WG = WGSZ; /* (shadows the default workgroup size) */
@@ -174,9 +176,21 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
     best.prim = NO_HIT;
     best.a = best.invDet = best.U = best.V = best.W = 0.0f;
 
+    /* PERMUTED (scene in LDS): the ray's component order as byte offsets into a corner, and its origin in that order */
+    uint32_t offKx = 0, offKy = 4, offKz = 8;
+    f3 orgP = ps.o;
+    float auxSz = 1.0f;
     /* start the traversal of the ray ps.o, ps.d */
     auto beginRay = [&]() {
         aux = rayAux(ps.d);
+        if (PERMUTED) {
+            const int kx = auxKx(aux), ky = auxKy(aux), kz = auxKz(aux);
+            offKx = 4u * (uint32_t)kx;
+            offKy = 4u * (uint32_t)ky;
+            offKz = 4u * (uint32_t)kz;
+            orgP = mk3(comp(ps.o, kx), comp(ps.o, ky), comp(ps.o, kz));
+            auxSz = comp(aux.inv, kz);
+        }
         node = 0;
         amax = k_maxval;
         best.prim = NO_HIT;
@@ -270,6 +284,14 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
                             /* HitableSphere::hit (hitable_sphere.hpp:104-147) */
                             c.invDet = c.U = c.V = c.W = 0.0f;
                             accepted = sphereTest(sphereNow<F>(sv, ps, sv.spheres[leafPrim & ~PRIM_SPHERE]), ps.o, ps.d, par.min_hit_distance, amax, c.a);
+                        } else if (PERMUTED) {
+                            /* the nine corner components, fetched in the ray's component order */
+                            const char* corner = reinterpret_cast<const char*>(ldsScene + 2 * nodeCount + 3 * leafPrim);
+                            auto at = [&](uint32_t bytes) { return *reinterpret_cast<const float*>(corner + bytes); };
+                            const f3 p0 = mk3(at(offKx), at(offKy), at(offKz));
+                            const f3 p1 = mk3(at(16 + offKx), at(16 + offKy), at(16 + offKz));
+                            const f3 p2 = mk3(at(32 + offKx), at(32 + offKy), at(32 + offKz));
+                            accepted = triangleTestPermuted(p0, p1, p2, orgP, aux.Sx, aux.Sy, auxSz, par.min_hit_distance, amax, c);
                         } else {
                             const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
                             f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
@@ -404,6 +426,7 @@ void launchGroundTruth(const GroundTruthArgs& args, hipStream_t stream);
 /* one launcher per instantiation, each defined in its own translation unit; sceneLdsBytes is the size of the scene
  * copy behind the cold path words in LDS (0 for the kernels that fetch the scene from HBM) */
 void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
+void launchBasicLdsPlain(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
 /* five waves per SIMD: 320-thread workgroups; the Gateless ones are for launches with open path length gates */
 void launchBasicLds5Gateless(const KernelArgs& args, uint32_t lanes, size_t sceneLdsBytes, hipStream_t stream);
 void launchBasic5(const KernelArgs& args, uint32_t lanes, hipStream_t stream);

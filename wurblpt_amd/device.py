@@ -16,10 +16,10 @@ def lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("WPT_LIB_DIR", "lib"), "libwurblpt_hip.so")
 
 
-EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_scene_upload", "wpt_scene_free", "wpt_scene_check",
+EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_current_device", "wpt_scene_upload", "wpt_scene_free", "wpt_scene_check",
            "wpt_postproc_to_srgb", "wpt_postproc_max_luminance", "wpt_postproc_uniform_rational_quantization",
            "wpt_postproc_scale_luminance", "wpt_postproc_host", "wpt_ground_truth_device", "wpt_ground_truth", "wpt_render_bands_device", "wpt_render_bands",
-           "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_set_top_nodes", "wpt_kernel_name",
+           "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_set_top_nodes", "wpt_kernel_name", "wpt_device_name", "wpt_build_info",
            "wpt_last_error"]
 
 
@@ -38,6 +38,9 @@ def lib():
             pass
         L = C.CDLL(path)
         L.wpt_device_count.restype = C.c_int
+        L.wpt_device_name.restype = C.c_char_p
+        L.wpt_device_name.argtypes = [C.c_int]
+        L.wpt_build_info.restype = C.c_char_p
         L.wpt_select_device.argtypes = [C.c_int]
         L.wpt_scene_upload.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(C.c_void_p)]
         L.wpt_scene_free.argtypes = [C.c_void_p]

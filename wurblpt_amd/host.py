@@ -169,13 +169,14 @@ def furnace(width, height, material=0, slices=64):
     return HostScene(h, width, height, "furnace(material=%d)" % material)
 
 
-def mis_test(width, height, with_hot_spots=True):
+def mis_test(width, height, with_hot_spots=True, light_mask=15):
     """The scene of wurblpt-mis-test.cpp: four GGX plates under four sphere lights in a white room; the lights are hot
-    spots (next-event estimation with MIS) or not (material sampling alone)."""
+    spots (next-event estimation with MIS) or not (material sampling alone).  light_mask: bit i = light i exists."""
     L = lib()
     L.wpt_host_mis_test.restype = C.c_void_p
-    h = L.wpt_host_mis_test(1 if with_hot_spots else 0, width, height)
-    return HostScene(h, width, height, "mis_test(hot_spots=%d)" % with_hot_spots)
+    L.wpt_host_mis_test.argtypes = [C.c_int, C.c_uint, C.c_uint, C.c_uint]
+    h = L.wpt_host_mis_test(1 if with_hot_spots else 0, light_mask, width, height)
+    return HostScene(h, width, height, "mis_test(hot_spots=%d,lights=%d)" % (with_hot_spots, light_mask))
 
 
 def spheres(width, height, variant=0):

@@ -580,8 +580,9 @@ extern "C" wpt_host_scene* wpt_host_spheres(int variant, unsigned int width, uns
 /* The scene of the reference's statistical test for multiple importance sampling (wurblpt-mis-test.cpp:32-97, after
  * Veach's four plates under four lights): a white room, four GGX plates of growing roughness tilted towards the
  * camera, four sphere lights of growing size and equal radiance.  withHotSpots = 0 leaves the lights to material
- * sampling alone; the two renderings must converge to the same image (:118-133). */
-extern "C" wpt_host_scene* wpt_host_mis_test(int withHotSpots, unsigned int width, unsigned int height)
+ * sampling alone; the two renderings must converge to the same image (:118-133).  lightMask: bit i = light i is there
+ * (15 = the reference's scene). */
+extern "C" wpt_host_scene* wpt_host_mis_test(int withHotSpots, unsigned int lightMask, unsigned int width, unsigned int height)
 {
     Scene* scenePtr = new Scene;
     Scene& scene = *scenePtr;
@@ -621,8 +622,9 @@ extern "C" wpt_host_scene* wpt_host_mis_test(int withHotSpots, unsigned int widt
     for (int i = 0; i < 4; i++)
         lightMaterial[i] = scene.take(new LightDiffuse(vec3(4.0f)));
     for (int i = 0; i < 4; i++)
-        scene.take(new Sphere(lightMaterial[i], Transformation(vec3(lightX[i], -3.5f, -4.0f), quat::null(), vec3(lightRadius[i]))),
-                withHotSpots ? HotSpot : ColdSpot);
+        if (lightMask & (1u << i))
+            scene.take(new Sphere(lightMaterial[i], Transformation(vec3(lightX[i], -3.5f, -4.0f), quat::null(), vec3(lightRadius[i]))),
+                    withHotSpots ? HotSpot : ColdSpot);
     /* camera at (0, -4.5, -1.2) looking down -z (Transformation without rotation), 50 degrees */
     return wptHostFinish(scenePtr, width, height, radians(50.0f), vec3(0.0f, -4.5f, -1.2f), vec3(0.0f, -4.5f, -2.2f), 0.0f, 1.0f);
 }
