@@ -193,7 +193,9 @@ def main():
         scene = scenefile.build_once(lambda: build_scene(w), shared, rank, dist.barrier)
         t_build = time.perf_counter() - t_build
     else:
+        t_build = time.perf_counter()
         scene = build_scene(w)
+        t_build = time.perf_counter() - t_build
     if args.variant:
         device.lib().wpt_set_launch_config(0, args.variant)
     if args.top_nodes >= 0:
@@ -346,6 +348,9 @@ def main():
                            "bands of %d rows, band i to rank i mod %d, one launch per GPU + RCCL reduce" % (max(1, block_size // width), world))},
             "roofline": roofline,
             "frame_finite": ok,
+            # host side, untimed: rank 0 builds and flattens the scene; with N > 1 this includes saving it to /dev/shm and
+            # the barrier the other ranks wait at before they map it
+            "scene_build_s": t_build,
         }
         if verified is not None:
             out["frame_equals_single_launch"] = verified

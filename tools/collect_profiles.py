@@ -16,6 +16,9 @@ WORK = {"c": ("cornell", "cornell_1024x1024_1024spp_ggx_glass"),
         "y": ("courtyard", "courtyard_like_10M_1920x1080_121spp")}
 
 
+SAMPLES = {"c": 1024 * 1024 * 1024, "s": 1920 * 1080 * 256, "y": 1920 * 1080 * 121}  # samples per launch of the product kernel
+
+
 def counters(suffix):
     agg = collections.defaultdict(list)
     for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_*" % suffix, ""))):
@@ -46,7 +49,7 @@ for letter, (short, workload) in WORK.items():
         f.write("# rocprofv3 --pmc passes (one counter group per run, tools/profile_round.sh) of\n# python3 bench.py --workload %s --no-cpu-baseline; mean over the launches of each kernel\n" % workload)
         for (k, c), v in sorted(agg.items()):
             f.write("%-58s %-30s launches=%d mean=%.6g\n" % (k, c, len(v), sum(v) / len(v)))
-    prod = [k for (k, c) in agg if c == "FETCH_SIZE" and ", true, false, 2" not in k]
+    prod = [k for (k, c) in agg if c == "FETCH_SIZE" and "u, true, " not in k]  # not the counting build
     if prod:
         k = prod[0]
         fetch = sum(agg[(k, "FETCH_SIZE")]) / len(agg[(k, "FETCH_SIZE")])
@@ -56,6 +59,13 @@ for letter, (short, workload) in WORK.items():
             "fetch_size_kib": fetch, "write_size_kib": write, "kernel": k,
             "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_%s.txt); "
                    "FETCH_SIZE x 2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KiB -> bytes" % (prefix, short)}
+        mean = lambda c: sum(agg[(k, c)]) / len(agg[(k, c)]) if (k, c) in agg else None
+        if mean("SQ_INSTS_VALU") and mean("VALUUtilization") and letter in SAMPLES:
+            traffic[workload].update({
+                "valu_insts_per_sample": mean("SQ_INSTS_VALU") / SAMPLES[letter],
+                "valu_active_lane_fraction": mean("VALUUtilization") / 100.0,
+                "valu_busy_percent": mean("VALUBusy"),
+                "pmc_file": "profiles/%s_pmc_%s.txt" % (prefix, short)})
 if traffic:
     json.dump({"workloads": traffic}, open(os.path.join(OUT, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))

@@ -70,61 +70,26 @@ struct PathHot {
     float animM[16];
 };
 
-/* cold words in LDS: `base` is this lane's first slot, slot k lies k * STRIDE float4 further.
- * GATES = false: a launch whose path length gates are wide open (the default, sensor_rgb.hpp:49-52) and whose scene is
- * small enough for no optical path length to overflow needs no opticalPathLength at all; its slot is left out (seven
- * slots per lane, which is what lets five waves per SIMD share a CU's LDS) and pathComponent lives in a register. */
-template<int STRIDE, bool GATES = true> struct PathLds : PathHot {
-    static constexpr bool gates = GATES;
+/* cold words in LDS: `base` is this lane's first slot, slot k lies k * STRIDE float4 further */
+template<int STRIDE> struct PathLds : PathHot {
     float4* base;
-    uint32_t pathComponentRegister;
-    static WPT_D int at(int k) { return (!GATES && k > SLOT_OPL) ? k - 1 : k; }
-    WPT_D f4 get4(int k) const { const float4 v = base[at(k) * STRIDE]; return mk4(v.x, v.y, v.z, v.w); }
-    WPT_D void set4(int k, f4 v) { base[at(k) * STRIDE] = make_float4(v.x, v.y, v.z, v.w); }
+    WPT_D f4 get4(int k) const { const float4 v = base[k * STRIDE]; return mk4(v.x, v.y, v.z, v.w); }
+    WPT_D void set4(int k, f4 v) { base[k * STRIDE] = make_float4(v.x, v.y, v.z, v.w); }
     WPT_D Slot get(int k) const
     {
-        const float4 v = base[at(k) * STRIDE];
+        const float4 v = base[k * STRIDE];
         Slot s;
         s.x = v.x; s.y = v.y; s.z = v.z; s.w = __float_as_uint(v.w);
         return s;
     }
-    WPT_D void set(int k, Slot s) { base[at(k) * STRIDE] = make_float4(s.x, s.y, s.z, __uint_as_float(s.w)); }
+    WPT_D void set(int k, Slot s) { base[k * STRIDE] = make_float4(s.x, s.y, s.z, __uint_as_float(s.w)); }
     WPT_D void set3(int k, f3 v) /* x, y, z only: w keeps its value */
     {
-        float* p = reinterpret_cast<float*>(base + at(k) * STRIDE);
+        float* p = reinterpret_cast<float*>(base + k * STRIDE);
         p[0] = v.x; p[1] = v.y; p[2] = v.z;
     }
-    WPT_D uint32_t getW(int k) const { return reinterpret_cast<const uint32_t*>(base + at(k) * STRIDE)[3]; }
-    WPT_D void setW(int k, uint32_t w) { reinterpret_cast<uint32_t*>(base + at(k) * STRIDE)[3] = w; }
-    /* opticalPathLength and pathComponent (slot 5, or nowhere and a register) */
-    WPT_D Slot getOpl() const
-    {
-        if constexpr (GATES)
-            return get(SLOT_OPL);
-        Slot s;
-        s.x = s.y = s.z = 0.0f;
-        s.w = pathComponentRegister;
-        return s;
-    }
-    WPT_D void setOpl(Slot s)
-    {
-        if constexpr (GATES)
-            set(SLOT_OPL, s);
-        else
-            pathComponentRegister = s.w;
-    }
-    WPT_D void setOpl3(f3 v)
-    {
-        if constexpr (GATES)
-            set3(SLOT_OPL, v);
-    }
-    WPT_D void setPathComponent(uint32_t c)
-    {
-        if constexpr (GATES)
-            setW(SLOT_OPL, c);
-        else
-            pathComponentRegister = c;
-    }
+    WPT_D uint32_t getW(int k) const { return reinterpret_cast<const uint32_t*>(base + k * STRIDE)[3]; }
+    WPT_D void setW(int k, uint32_t w) { reinterpret_cast<uint32_t*>(base + k * STRIDE)[3] = w; }
 };
 
 /* cold words in registers (one ray per lane: the ground truth kernel) */
@@ -137,11 +102,6 @@ struct PathRegs : PathHot {
     WPT_D void set3(int k, f3 v) { slot[k].x = v.x; slot[k].y = v.y; slot[k].z = v.z; }
     WPT_D uint32_t getW(int k) const { return slot[k].w; }
     WPT_D void setW(int k, uint32_t w) { slot[k].w = w; }
-    static constexpr bool gates = true;
-    WPT_D Slot getOpl() const { return slot[SLOT_OPL]; }
-    WPT_D void setOpl(Slot s) { slot[SLOT_OPL] = s; }
-    WPT_D void setOpl3(f3 v) { set3(SLOT_OPL, v); }
-    WPT_D void setPathComponent(uint32_t c) { slot[SLOT_OPL].w = c; }
 };
 
 template<class PS> WPT_D Prng loadPrng(const PS& ps)
@@ -217,7 +177,7 @@ template<class PS> WPT_D void pathStateInit(PS& ps, uint32_t pixel, uint32_t px,
     z.x = z.y = z.z = 0.0f;
     z.w = 0;
     ps.set(SLOT_ACC, z); /* stratum (0, 0) */
-    ps.setOpl(z); /* pathComponent 0 */
+    ps.set(SLOT_OPL, z); /* pathComponent 0 */
     Slot n;
     n.x = n.y = n.z = 1.0f;
     n.w = NO_HIT;
@@ -337,11 +297,11 @@ template<class PS> WPT_D void accumulateRadiance(const wpt_params& par, f3 opl, 
     if (!dOk)
         return;
     Slot acc = ps.get(SLOT_ACC);
-    if (!PS::gates || (opl.x >= par.min_path_len && opl.x <= par.max_path_len))
+    if (opl.x >= par.min_path_len && opl.x <= par.max_path_len)
         acc.x += radiance.x;
-    if (!PS::gates || (opl.y >= par.min_path_len && opl.y <= par.max_path_len))
+    if (opl.y >= par.min_path_len && opl.y <= par.max_path_len)
         acc.y += radiance.y;
-    if (!PS::gates || (opl.z >= par.min_path_len && opl.z <= par.max_path_len))
+    if (opl.z >= par.min_path_len && opl.z <= par.max_path_len)
         acc.z += radiance.z;
     ps.set3(SLOT_ACC, mk3(acc.x, acc.y, acc.z));
 }
@@ -363,7 +323,7 @@ template<class PS> WPT_D int advancePath(const wpt_params& par, PS& ps, f4 nextA
         att = sclr(att, rrWeight);
     }
     ps.set4(SLOT_ATT, att);
-    ps.setPathComponent(pathComponent + 1);
+    ps.setW(SLOT_OPL, pathComponent + 1);
     ps.rayKind = RAY_PATH;
     return NEXT_TRACE;
 }
@@ -455,7 +415,7 @@ WPT_D int blockNew(const FrameArgs& fa, PS& ps, const SceneView* sv = nullptr)
     Slot opl;
     opl.x = opl.y = opl.z = 0.0f;
     opl.w = 0; /* pathComponent */
-    ps.setOpl(opl);
+    ps.set(SLOT_OPL, opl);
     ps.setW(SLOT_ACC, i + 1 < fa.samplesSqrt ? stratum + 1 : (j + 1) << 16);
     ps.rayKind = RAY_PATH;
     return NEXT_TRACE;
@@ -477,12 +437,12 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
     ray.o = ps.o;
     ray.d = ps.d;
     ray.ri = ps.get4(SLOT_RI);
-    const Slot oplSlot = ps.getOpl();
+    const Slot oplSlot = ps.get(SLOT_OPL);
     const uint32_t pathComponent = oplSlot.w;
     const f3 opl = add(mk3(oplSlot.x, oplSlot.y, oplSlot.z), scl(best.a, mk3(ray.ri.x, ray.ri.y, ray.ri.z)));
     if (!(pathComponent + 1 < par.max_path_components))
         return NEXT_NEW;
-    ps.setOpl3(opl);
+    ps.set3(SLOT_OPL, opl);
     long long tSection = 0;
     auto section = [&](int k) { /* COUNT builds: close section k */
         if (COUNT) {
@@ -606,7 +566,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
 template<uint32_t F, class PS>
 WPT_D int blockNeeEnd(const SceneView& sv, const wpt_params& par, PS& ps, const Candidate& best)
 {
-    const Slot oplSlot = ps.getOpl();
+    const Slot oplSlot = ps.get(SLOT_OPL);
     if (ps.rayKind == RAY_NEE_LIGHT) {
         const Slot nee = ps.get(SLOT_NEE);
         if (best.prim == nee.w) {

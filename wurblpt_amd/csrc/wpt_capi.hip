@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -140,9 +141,6 @@ struct wpt_scene {
     std::vector<void*> allocations;
     uint32_t* status; /* device word: set by a launch that aborted */
     int cuCount;
-    /* every coordinate of the scene is finite and below 1e12 in magnitude: no hit distance and no optical path length
-     * of a launch with up to 65535 path components can then overflow or become NaN (see gatesOpen) */
-    bool tame;
     std::vector<float> envM, envMcs;
     std::vector<int32_t> envMs;
 };
@@ -409,26 +407,6 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     wpt_scene* s = new wpt_scene;
     HIP_TRY(hipGetDevice(&s->device));
     s->features = sceneFeatures(desc);
-    {
-        bool tame = true;
-        const float limit = 1e12f;
-        for (int k = 0; k < 3; k++)
-            tame = tame && desc->nodes[0].lo[k] >= -limit && desc->nodes[0].hi[k] <= limit; /* false for NaN */
-        for (uint32_t i = 0; tame && i < desc->tri_count; i++) {
-            const wpt_tri_geom& g = desc->tri_geom[i];
-            for (int k = 0; k < 3; k++)
-                tame = tame && std::fabs(g.v0[k]) <= limit && std::fabs(g.v1[k]) <= limit && std::fabs(g.v2[k]) <= limit;
-        }
-        for (uint32_t i = 0; tame && i < desc->sphere_count; i++)
-            for (int k = 0; k < 3; k++)
-                tame = tame && std::fabs(desc->spheres[i].center[k]) <= limit && std::fabs(desc->spheres[i].radius) <= limit;
-        for (uint32_t i = 0; tame && i < desc->material_count; i++)
-            if (desc->materials[i].type == WPT_MAT_GLASS || desc->materials[i].type == WPT_MAT_MODPHONG)
-                for (int k = 0; k < 4; k++) /* refractive indices a ray can carry */
-                    tame = tame && std::fabs(desc->materials[i].v[1][k]) <= 1e3f && std::fabs(desc->materials[i].v[2][k]) <= 1e3f
-                        && std::fabs(desc->materials[i].f[2]) <= 1e3f;
-        s->tame = tame;
-    }
     s->nodeCount = desc->node_count;
     s->triCount = desc->tri_count;
     memset(&s->view, 0, sizeof(s->view));
@@ -773,24 +751,10 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     } else if (rgl) {
         launchFullRgl(args, grid, stream);
     } else {
-        /* Launches whose path length gates are wide open need no optical path length: in a tame scene (see wpt_scene)
-         * it stays finite, and SensorRGB then lets every contribution through whatever its value (sensor_rgb.hpp:63-80) */
-        const bool gatesOpen = scene->tame && params->min_path_len <= 0.0f && params->max_path_len == FLT_MAX
-            && params->max_path_components <= 65535u && std::fabs(camera->translation[0]) <= 1e12f
-            && std::fabs(camera->translation[1]) <= 1e12f && std::fabs(camera->translation[2]) <= 1e12f;
-        const bool five = (g_variant & 0x08u) != 0; /* five waves per SIMD */
-        if (basic && lds && five && gatesOpen && ldsBytes <= LDS_SCENE_MAX_BYTES_5)
-            launchBasicLds5Gateless(args, block_size, ldsBytes, stream);
-        else if (basic && lds && (g_variant & 0x10u))
-            launchBasicLdsPlain(args, grid, ldsBytes, stream);
-        else if (basic && lds)
+        if (basic && lds)
             launchBasicLds(args, grid, ldsBytes, stream);
-        else if (basic && five)
-            launchBasic5(args, block_size, stream);
         else if (basic)
             launchBasic(args, grid, stream);
-        else if (five)
-            launchFull5(args, block_size, stream);
         else if ((scene->nodeCount >= (1u << 21) && (g_variant & 0x40u) == 0) || (g_variant & 0x04u) != 0)
             launchFullWalk(args, grid, stream); /* tree of 64 MiB and more (variant 0x40: never, 0x04: always) */
         else

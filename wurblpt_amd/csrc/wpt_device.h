@@ -371,55 +371,6 @@ WPT_D bool triangleTest(f3 v0, f3 v1, f3 v2, f3 org, const RayAux& h, float amin
     return true;
 }
 
-/* The same test on corners and origin whose components already stand in the ray's order (kx, ky, kz): A = corner - origin
- * is taken per component, so permuting before or after the subtraction gives the same values.  Kernels that keep the
- * scene in LDS read the nine corner components at permuted addresses and save the eighteen selects. */
-WPT_D bool triangleTestPermuted(f3 p0, f3 p1, f3 p2, f3 orgP, float Sx, float Sy, float Sz, float amin, float amax, Candidate& c)
-{
-    const float Akz = p0.z - orgP.z, Bkz = p1.z - orgP.z, Ckz = p2.z - orgP.z;
-    const float Ax = (p0.x - orgP.x) - Sx * Akz;
-    const float Ay = (p0.y - orgP.y) - Sy * Akz;
-    const float Bx = (p1.x - orgP.x) - Sx * Bkz;
-    const float By = (p1.y - orgP.y) - Sy * Bkz;
-    const float Cx = (p2.x - orgP.x) - Sx * Ckz;
-    const float Cy = (p2.y - orgP.y) - Sy * Ckz;
-    float U = Cx * By - Cy * Bx;
-    float V = Ax * Cy - Ay * Cx;
-    float W = Bx * Ay - By * Ax;
-    if (__builtin_fabsf(U) < k_ldeps || __builtin_fabsf(V) < k_ldeps || __builtin_fabsf(W) < k_ldeps) {
-        double CxBy = (double)Cx * (double)By;
-        double CyBx = (double)Cy * (double)Bx;
-        U = (float)(CxBy - CyBx);
-        double AxCy = (double)Ax * (double)Cy;
-        double AyCx = (double)Ay * (double)Cx;
-        V = (float)(AxCy - AyCx);
-        double BxAy = (double)Bx * (double)Ay;
-        double ByAx = (double)By * (double)Ax;
-        W = (float)(BxAy - ByAx);
-    }
-    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f))
-        return false;
-    float det = U + V + W;
-    if (det == 0.0f)
-        return false;
-    const float Az = Sz * Akz;
-    const float Bz = Sz * Bkz;
-    const float Cz = Sz * Ckz;
-    const float T = U * Az + V * Bz + W * Cz;
-    const uint32_t sgn = wptm::float_to_bits(det) & 0x80000000u;
-    const float Ts = wptm::bits_to_float(wptm::float_to_bits(T) ^ sgn);
-    const float ds = wptm::bits_to_float(wptm::float_to_bits(det) ^ sgn);
-    if (Ts < amin * ds || Ts > amax * ds)
-        return false;
-    const float invDet = 1.0f / det;
-    c.a = invDet * T;
-    c.invDet = invDet;
-    c.U = U;
-    c.V = V;
-    c.W = W;
-    return true;
-}
-
 /* AABB::mayHit (aabb.hpp:70-86) written out with the reference's comparison chains, whose
  * results for NaN slab distances (0 * inf: origin on a slab plane, direction parallel to it)
  * depend on the operand order */

@@ -8,10 +8,4 @@ void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hip
     hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false, true, 4>), grid, dim3(WG), COLD_BYTES + sceneLdsBytes, stream, args);
 }
 
-/* the same without the permuted corner fetch (variant bit 0x10; kept for the measurement in DESIGN.md section 4) */
-void launchBasicLdsPlain(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream)
-{
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false, true, 4, WG, true, 2>), grid, dim3(WG), COLD_BYTES + sceneLdsBytes, stream, args);
-}
-
 }

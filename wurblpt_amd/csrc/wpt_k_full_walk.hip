@@ -9,7 +9,7 @@ namespace wptk {
 
 void launchFullWalk(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL, false, false, 4, WG, true, 1>), grid, dim3(WG), COLD_BYTES, stream, args);
+    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL, false, false, 4, 1>), grid, dim3(WG), COLD_BYTES, stream, args);
 }
 
 }

@@ -56,14 +56,6 @@ constexpr uint32_t NODE_INDEX_MASK = 0x3fffffffu;
 constexpr uint32_t COLD_BYTES = SLOT_COUNT * WG * 16; /* the paths' cold words: 32 KiB of LDS per workgroup */
 /* with the scene behind them three workgroups still fit into a CU's 160 KiB */
 constexpr uint32_t LDS_SCENE_MAX_BYTES = 21 * 1024;
-/* Five waves per SIMD.  The kernel is a chain of short dependent pieces (LDS fetch, box test, ballot, branch), so a
- * wave is ready to issue a vector instruction about a third of the time and four waves leave half of a SIMD's issue
- * slots empty (r02 PMC pass: 7.8e11 vector instructions in 1.35 s = 47 % of the slots).  A fifth wave needs at most 96
- * registers per lane and 160 KiB / 20 waves = 8 KiB of LDS per wave: exactly the eight slots without a scene, or seven
- * slots (launches whose path length gates are open) with a scene of up to 4 KiB behind every five waves. */
-constexpr int WG5 = 320;
-constexpr uint32_t LDS_SCENE_MAX_BYTES_5 = 160 * 1024 / 4 - 7 * WG5 * 16;
-
 struct KernelArgs {
     SceneView sv;
     wpt_camera cam;
@@ -90,16 +82,20 @@ struct KernelArgs {
 enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5 };
 
 /* TUNE only tells apart two builds of one instantiation that are compiled with different options (Makefile) */
-template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, int WGSZ = WG, bool GATES = true, int TUNE = 0>
-__global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args)
+template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, int TUNE = 0>
+__global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 {
     constexpr bool PREFETCH = !LDSSCENE && TUNE == 0;
-    /* leaf tests read the corners from LDS in the ray's component order (no animated instances: those move the corners first) */
-    constexpr bool PERMUTED = LDSSCENE && !(F & FEAT_ANIM) && TUNE != 2;
-    /* [ cold path words: slots x WGSZ float4 ][ LDSSCENE: nodes, triangle positions ] */
+    /* Node steps per look at the lane counts.  The look itself (two ballots, their counts, the leave and leaf decisions:
+     * some twenty scalar instructions and two branches in every lane's way) costs a wave as much issue time as half a
+     * node step.  From LDS a step is short, and taking up to three in a row before looking again gave 852 against 799
+     * Msamples/s on the Cornell frame (2: 839, 4: 841, 6: 836, 8: 791: lanes that reach a leaf wait out the rest); from
+     * HBM the steps are memory round trips and nothing is gained (Sponza-class 118.7 - 121.0 against 120.4, 10 M
+     * triangles 53 - 55 against 56.5 for 2 - 4 steps). */
+    constexpr int STEPS = LDSSCENE ? 3 : 1;
+    /* [ cold path words: SLOT_COUNT x WG float4 ][ LDSSCENE: nodes, triangle positions ] */
     extern __shared__ float4 lds[];
-    constexpr int WG = WGSZ; /* (shadows the default workgroup size) */
-    float4* const ldsScene = lds + (GATES ? SLOT_COUNT : SLOT_COUNT - 1) * WG;
+    float4* const ldsScene = lds + SLOT_COUNT * WG;
 
     const SceneView& sv = args.sv;
     const wpt_params& par = args.par;
@@ -162,7 +158,7 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
     fa.invSamplesSqrt = args.invSamplesSqrt;
 
     /* ---- per-lane state: the pixel's path (wpt_blocks.h; its cold words in LDS) and the traversal registers ---- */
-    PathLds<WG, GATES> ps;
+    PathLds<WG> ps;
     ps.base = lds + threadIdx.x;
     pathStateInit(ps, pixel, pixel % args.width, pixel / args.width);
     LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
@@ -176,21 +172,9 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
     best.prim = NO_HIT;
     best.a = best.invDet = best.U = best.V = best.W = 0.0f;
 
-    /* PERMUTED (scene in LDS): the ray's component order as byte offsets into a corner, and its origin in that order */
-    uint32_t offKx = 0, offKy = 4, offKz = 8;
-    f3 orgP = ps.o;
-    float auxSz = 1.0f;
     /* start the traversal of the ray ps.o, ps.d */
     auto beginRay = [&]() {
         aux = rayAux(ps.d);
-        if (PERMUTED) {
-            const int kx = auxKx(aux), ky = auxKy(aux), kz = auxKz(aux);
-            offKx = 4u * (uint32_t)kx;
-            offKy = 4u * (uint32_t)ky;
-            offKz = 4u * (uint32_t)kz;
-            orgP = mk3(comp(ps.o, kx), comp(ps.o, ky), comp(ps.o, kz));
-            auxSz = comp(aux.inv, kz);
-        }
         node = 0;
         amax = k_maxval;
         best.prim = NO_HIT;
@@ -284,14 +268,6 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
                             /* HitableSphere::hit (hitable_sphere.hpp:104-147) */
                             c.invDet = c.U = c.V = c.W = 0.0f;
                             accepted = sphereTest(sphereNow<F>(sv, ps, sv.spheres[leafPrim & ~PRIM_SPHERE]), ps.o, ps.d, par.min_hit_distance, amax, c.a);
-                        } else if (PERMUTED) {
-                            /* the nine corner components, fetched in the ray's component order */
-                            const char* corner = reinterpret_cast<const char*>(ldsScene + 2 * nodeCount + 3 * leafPrim);
-                            auto at = [&](uint32_t bytes) { return *reinterpret_cast<const float*>(corner + bytes); };
-                            const f3 p0 = mk3(at(offKx), at(offKy), at(offKz));
-                            const f3 p1 = mk3(at(16 + offKx), at(16 + offKy), at(16 + offKz));
-                            const f3 p2 = mk3(at(32 + offKx), at(32 + offKy), at(32 + offKz));
-                            accepted = triangleTestPermuted(p0, p1, p2, orgP, aux.Sx, aux.Sy, auxSz, par.min_hit_distance, amax, c);
                         } else {
                             const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
                             f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
@@ -320,6 +296,8 @@ __global__ __launch_bounds__(WGSZ, OCC) void wpt_pathtrace(const KernelArgs args
                         sched[1]++;
                         sched[2] += nNode;
                     }
+#pragma unroll
+                    for (int step = 0; step < STEPS; step++)
                     if (state == S_NODE) {
                         /* AABB::mayHit + the stackless form of BVH::hit's walk */
                         if (COUNT)
@@ -426,11 +404,6 @@ void launchGroundTruth(const GroundTruthArgs& args, hipStream_t stream);
 /* one launcher per instantiation, each defined in its own translation unit; sceneLdsBytes is the size of the scene
  * copy behind the cold path words in LDS (0 for the kernels that fetch the scene from HBM) */
 void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
-void launchBasicLdsPlain(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
-/* five waves per SIMD: 320-thread workgroups; the Gateless ones are for launches with open path length gates */
-void launchBasicLds5Gateless(const KernelArgs& args, uint32_t lanes, size_t sceneLdsBytes, hipStream_t stream);
-void launchBasic5(const KernelArgs& args, uint32_t lanes, hipStream_t stream);
-void launchFull5(const KernelArgs& args, uint32_t lanes, hipStream_t stream);
 /* the all-features kernel built for scenes whose frame time is traversal (trees far larger than the caches) */
 void launchFullWalk(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
