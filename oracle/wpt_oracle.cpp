@@ -2265,7 +2265,7 @@ void wpt_oracle_bvh_walk(const wpt_bvh_node* nodes, const float* ray8, const flo
     *final_a = hr.haveHit ? hr.a : 0.0f;
 }
 
-/* math back end probe: op 0 sin, 1 cos, 2 exp, 3 pow(a,b), 4 asin, 5 atan2(a,b) */
+/* math back end probe: op 0 sin, 1 cos, 2 exp, 3 pow(a,b), 4 asin, 5 atan2(a,b), 10 acos, 11 atan2(a, 1), 12 float(2 * asin(double)) */
 void wpt_oracle_math(int op, int n, const float* a, const float* b, float* out)
 {
     for (int i = 0; i < n; i++) {
@@ -2275,6 +2275,9 @@ void wpt_oracle_math(int op, int n, const float* a, const float* b, float* out)
         case 2: out[i] = m_exp(a[i]); break;
         case 3: out[i] = m_pow(a[i], b[i]); break;
         case 4: out[i] = m_asin(a[i]); break;
+        case 10: out[i] = m_acos(a[i]); break;
+        case 11: out[i] = m_atan2(a[i], 1.0f); break;
+        case 12: out[i] = OracleMath::twiceAsin(a[i]); break;
         default: out[i] = m_atan2(a[i], b[i]); break;
         }
     }

@@ -51,6 +51,30 @@ def test_device_pow_atan2_bit_identical(dev, oracle):
     assert np.array_equal(dev.selftest_math(5, a, b).view(np.uint32), oracle.math(5, a, b).view(np.uint32))
 
 
+@pytest.mark.parametrize("op", [0, 1, 2, 3, 4, 5, 10, 11, 12])
+def test_device_math_equals_the_c_library_on_any_bit_pattern(dev, oracle, oracle_libm, op):
+    """wpt_math.h evaluates glibc's own algorithms (tests/test_math_exact.py pins the header to the library for all 2^32
+    arguments on the host); here the DEVICE's evaluation of the header: four million arbitrary bit patterns per function --
+    huge arguments (the 192-bit reduction of sinf / cosf), subnormals, infinities, NaNs, negative bases -- plus arguments
+    at the scale the renderer uses, against the header on the host and against the host's C library itself."""
+    rng = np.random.RandomState(100 + op)
+    n = 1 << 22
+    a = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    b = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    a[: n // 4] = rng.uniform(-8, 8, n // 4).astype(np.float32)
+    b[: n // 4] = rng.uniform(-8, 8, n // 4).astype(np.float32)
+    a[n // 4: n // 2] = rng.uniform(-1, 1, n // 4).astype(np.float32)
+    b[n // 4: n // 2] = rng.uniform(0, 300, n // 4).astype(np.float32)
+    got = dev.selftest_math(op, a, b)
+    ref = oracle.math(op, a, b)
+
+    def same(x, y):
+        return bool(np.all((x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))))
+    assert same(got, ref)
+    if "fma" in open("/proc/cpuinfo").read():     # the C library selects its FMA builds, whose bits the header has
+        assert same(got, oracle_libm.math(op, a, b))
+
+
 def test_device_box_test_matches_reference_including_nan_slabs(dev, oracle, golden):
     """The kernels evaluate AABB::mayHit with min/max instructions and fall back to the
     reference's comparison chains when a slab distance is NaN (origin on a slab plane, direction

@@ -127,16 +127,14 @@ def test_parameters_and_sensor_gates(oracle):
     assert np.isfinite(fj).all()
 
 
-def test_libm_and_portable_backends_stay_close(oracle, oracle_libm):
-    """The two math back ends differ only in last bits of sin/cos/...; the image-level gap is
-    the size the survey measured between builds of the reference itself (5.6e-4 rel-L2 for FMA
-    contraction at 256x256x64 spp)."""
+def test_libm_and_default_backends_are_one(oracle, oracle_libm):
+    """Round 1's default back end (double evaluation, rounded once) differed from the C library in last bits of sin / cos /
+    ..., and frames by 1e-2 rel-L2 at this size.  Since round 2 wurblpt_amd/csrc/wpt_math.h evaluates the library's own
+    algorithms (tests/test_math_exact.py), and the two back ends render the same bits."""
     sc = host.cornell(64, 64, 1, 2)
-    a, _ = oracle.render(sc, 8)
-    b, _ = oracle_libm.render(sc, 8)
-    rel = np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / (b.astype(np.float64) ** 2).sum())
-    assert rel < 2e-2
-    assert np.allclose(a.reshape(-1, 3).mean(0), b.reshape(-1, 3).mean(0), rtol=2e-3)
+    a, ca = oracle.render(sc, 8)
+    b, cb = oracle_libm.render(sc, 8)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ca == cb
 
 
 def test_random_triangle_scene_is_consistent(oracle):

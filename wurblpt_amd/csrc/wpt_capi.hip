@@ -23,7 +23,7 @@ using namespace wptk;
 namespace {
 
 /* Bit-parity self test of the arithmetic the kernel relies on: ops 0..5 are the
- * transcendentals of wpt_math.h, 6 = IEEE division, 7 = IEEE square root. */
+ * transcendentals of wpt_math.h, 6 = IEEE division, 7 = IEEE square root, 10 acos, 11 atan2(x, 1), 12 float(2 * asin(double)). */
 __global__ void wpt_selftest_kernel(int op, int n, const float* a, const float* b, float* out)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,6 +40,9 @@ __global__ void wpt_selftest_kernel(int op, int n, const float* a, const float* 
     case 6: r = x / y; break;
     case 7: r = __builtin_sqrtf(x); break;
     case 8: r = x * y + x; break; /* must stay unfused */
+    case 10: r = wptm::acosf_(x); break;
+    case 11: r = wptm::atan2f_(x, 1.0f); break;
+    case 12: r = (float)(2.0 * wptm::asin_d((double)x)); break;
     default: r = 1.0f / x; break;
     }
     out[i] = r;
