@@ -33,7 +33,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # vector pipes: 256 CUs x 4 SIMD-32 at up to 2.4 GHz, one lane-operation per lane and cycle (MI355X_MICROARCH.md:
 # "a wave issues each VALU instruction over 2 cycles"; 157.3 TFLOP/s f32 = 2 flops per lane-operation)
 VALU_PEAK_GLANEOPS = 256 * 4 * 32 * 2.4
-LDS_SCENE_MAX_BYTES = 21 * 1024  # wpt_pathtrace.inc.h: scenes up to this size are traversed from LDS
+LDS_SCENE_MAX_BYTES = 20 * 1024  # wpt_pathtrace.inc.h: scenes up to this size are traversed from LDS
 
 WORKLOADS = {
     # name: (builder kwargs, width, height, samples_sqrt)

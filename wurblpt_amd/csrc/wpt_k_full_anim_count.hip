@@ -1,4 +1,5 @@
 /* wpt_k_full_anim_count.hip -- instantiates wpt_pathtrace<FEAT_ALL | FEAT_ANIM, true, false> (work counters) */
+#define WPT_MATH_TABLES_IN_LDS /* this unit's kernels keep the tables of expf / powf in LDS (wpt_math.h) */
 #include "wpt_pathtrace.inc.h"
 
 namespace wptk {

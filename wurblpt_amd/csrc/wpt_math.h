@@ -77,6 +77,11 @@ WPT_HD double fma_d(double a, double b, double c) { return __builtin_fma(a, b, c
 #else
 #define WPT_TABLE static const
 #endif
+/* The two tables of expf / powf (32 + 2 x 16 doubles, 512 bytes).  A kernel whose translation unit defines
+ * WPT_MATH_TABLES_IN_LDS copies them to the first 512 bytes of its dynamic LDS (wptm::tables_to_lds) and the functions read
+ * them there: a data-dependent look-up in global memory is a dependent memory round trip in the middle of a material
+ * evaluation (measured on the 10 M triangle scene, which is bound by memory latency: 50 against 56 Msamples/s). */
+#define WPT_MATH_TABLE_WORDS 64
 
 /* ---- double arc tangent and arc sine (asin_d only, see above) ---- */
 WPT_HD double atan_d(double x)
@@ -209,6 +214,31 @@ WPT_HD double asin_d(double xd)
 WPT_TABLE uint64_t exp2f_tab[32] = {
 0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull };
 
+WPT_TABLE double powf_log2_tab[16][2] = {
+    { 0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2 }, { 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2 }, { 0x1.49539f0f010b0p+0, -0x1.7418b0a1fb77bp-2 },
+    { 0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2 }, { 0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2 }, { 0x1.25e227b0b8ea0p+0, -0x1.97c1d1b3b7af0p-3 },
+    { 0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3 }, { 0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4 }, { 0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5 },
+    { 0x1.0000000000000p+0, 0x0.0p+0 }, { 0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4 }, { 0x1.ca4b31f026aa0p-1, 0x1.476a9543891bap-3 },
+    { 0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3 }, { 0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2 }, { 0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2 },
+    { 0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2 } };
+
+#if defined(__HIP_DEVICE_COMPILE__) && defined(WPT_MATH_TABLES_IN_LDS)
+extern __shared__ uint64_t wpt_math_lds[]; /* the kernel's dynamic LDS; its first WPT_MATH_TABLE_WORDS words are the tables */
+WPT_HD uint64_t exp2f_entry(uint64_t i) { return wpt_math_lds[i]; }
+WPT_HD double log2_entry(int i, int k) { return bits_to_double(wpt_math_lds[32 + 2 * i + k]); }
+/* called by every thread of the workgroup before the first use, followed by a barrier */
+WPT_HD void tables_to_lds(unsigned int thread)
+{
+    if (thread < 32)
+        wpt_math_lds[thread] = exp2f_tab[thread];
+    else if (thread < 64)
+        wpt_math_lds[thread] = double_to_bits(powf_log2_tab[(thread - 32) >> 1][thread & 1]);
+}
+#else
+WPT_HD uint64_t exp2f_entry(uint64_t i) { return exp2f_tab[i]; }
+WPT_HD double log2_entry(int i, int k) { return powf_log2_tab[i][k]; }
+#endif
+
 WPT_HD uint32_t top12(float x) { return float_to_bits(x) >> 20; }
 
 WPT_HD float expf_(float x)
@@ -231,7 +261,7 @@ WPT_HD float expf_(float x)
     uint64_t ki = double_to_bits(kd);
     kd -= SHIFT;
     double r = fma_d(InvLn2N, xd, -kd);
-    uint64_t t = exp2f_tab[ki % 32];
+    uint64_t t = exp2f_entry(ki % 32);
     t += ki << (52 - 5);
     double s = bits_to_double(t);
     double z = fma_d(C0, r, C1);
@@ -243,41 +273,44 @@ WPT_HD float expf_(float x)
 }
 
 /* sinf / cosf */
-struct sincos_t { double sign[4]; double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
-WPT_TABLE sincos_t sincosf_table[2] = {
-    { { 1.0, -1.0, -1.0, 1.0 }, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10,
-        0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13 },
-    { { 1.0, -1.0, -1.0, 1.0 }, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5, 0x1.6c087e89a359dp-10,
-        -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13 } };
+/* glibc keeps two sets of polynomial coefficients, the second with the cosine's negated (__sincosf_table[2]), and picks by
+ * quadrant; rounding is symmetric in the sign, so negating the coefficients negates every intermediate and the result,
+ * bit for bit.  Here the coefficients are literals and `negate` flips the cosine's result: no table, no loads. */
 WPT_TABLE uint32_t inv_pio4[24] = { 0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529, 0x441529fc, 0x1529fc27,
     0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0, 0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43,
     0x993c4390, 0x3c439041 };
 
 WPT_HD uint32_t abstop12(float x) { return (float_to_bits(x) >> 20) & 0x7ff; }
 
-WPT_HD float sinf_poly(double x, double x2, const sincos_t* p, int n)
+WPT_HD float sinf_poly(double x, double x2, bool negate, int n)
 {
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
     if ((n & 1) == 0) {
         double x3 = x * x2;
-        double s1 = fma_d(x2, p->s3, p->s2);
+        double t1 = fma_d(x2, s3, s2);
         double x7 = x3 * x2;
-        double s = fma_d(x3, p->s1, x);
-        return (float)fma_d(x7, s1, s);
+        double t = fma_d(x3, s1, x);
+        return (float)fma_d(x7, t1, t);
     } else {
         double x4 = x2 * x2;
-        double c2 = fma_d(x2, p->c4, p->c3);
-        double c1 = fma_d(x2, p->c1, p->c0);
+        double t2 = fma_d(x2, c4, c3);
+        double t1 = fma_d(x2, c1, c0);
         double x6 = x4 * x2;
-        double c = fma_d(x4, p->c2, c1);
-        return (float)fma_d(x6, c2, c);
+        double t = fma_d(x4, c2, t1);
+        const double r = fma_d(x6, t2, t);
+        return (float)(negate ? -r : r);
     }
 }
-WPT_HD double reduce_fast(double x, const sincos_t* p, int* np)
+/* the sign of quadrant q: 1, -1, -1, 1 */
+WPT_HD double quadrant_sign(int q) { return ((q ^ (q >> 1)) & 1) ? -1.0 : 1.0; }
+WPT_HD double reduce_fast(double x, int* np)
 {
-    double r = x * p->hpi_inv;
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    double r = x * hpi_inv;
     int n = ((int32_t)r + 0x800000) >> 24;
     *np = n;
-    return fma_d(-(double)n, p->hpi, x);
+    return fma_d(-(double)n, hpi, x);
 }
 WPT_HD double reduce_large(uint32_t xi, int* np)
 {
@@ -301,26 +334,21 @@ WPT_HD float sinf_(float y)
 {
     double x = y, s;
     int n;
-    const sincos_t* p = &sincosf_table[0];
     if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
         s = x * x;
         if (abstop12(y) < abstop12(0x1p-12f))
             return y;
-        return sinf_poly(x, s, p, 0);
+        return sinf_poly(x, s, false, 0);
     } else if (abstop12(y) < abstop12(120.0f)) {
-        x = reduce_fast(x, p, &n);
-        s = p->sign[n & 3];
-        if (n & 2)
-            p = &sincosf_table[1];
-        return sinf_poly(x * s, x * x, p, n);
+        x = reduce_fast(x, &n);
+        s = quadrant_sign(n & 3);
+        return sinf_poly(x * s, x * x, (n & 2) != 0, n);
     } else if (abstop12(y) < abstop12(bits_to_float(0x7f800000u))) {
         uint32_t xi = float_to_bits(y);
         int sign = xi >> 31;
         x = reduce_large(xi, &n);
-        s = p->sign[(n + sign) & 3];
-        if ((n + sign) & 2)
-            p = &sincosf_table[1];
-        return sinf_poly(x * s, x * x, p, n);
+        s = quadrant_sign((n + sign) & 3);
+        return sinf_poly(x * s, x * x, ((n + sign) & 2) != 0, n);
     }
     return (y - y) / (y - y);
 }
@@ -328,38 +356,27 @@ WPT_HD float cosf_(float y)
 {
     double x = y, s;
     int n;
-    const sincos_t* p = &sincosf_table[0];
     if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
         double x2 = x * x;
         if (abstop12(y) < abstop12(0x1p-12f))
             return 1.0f;
-        return sinf_poly(x, x2, p, 1);
+        return sinf_poly(x, x2, false, 1);
     } else if (abstop12(y) < abstop12(120.0f)) {
-        x = reduce_fast(x, p, &n);
-        s = p->sign[n & 3];
-        if (n & 2)
-            p = &sincosf_table[1];
-        return sinf_poly(x * s, x * x, p, n ^ 1);
+        x = reduce_fast(x, &n);
+        s = quadrant_sign(n & 3);
+        return sinf_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
     } else if (abstop12(y) < abstop12(bits_to_float(0x7f800000u))) {
         uint32_t xi = float_to_bits(y);
         int sign = xi >> 31;
         x = reduce_large(xi, &n);
-        s = p->sign[(n + sign) & 3];
-        if ((n + sign) & 2)
-            p = &sincosf_table[1];
-        return sinf_poly(x * s, x * x, p, n ^ 1);
+        s = quadrant_sign((n + sign) & 3);
+        return sinf_poly(x * s, x * x, ((n + sign) & 2) != 0, n ^ 1);
     }
     return (y - y) / (y - y);
 }
 
 /* powf */
-WPT_TABLE double powf_log2_tab[16][2] = {
-    { 0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2 }, { 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2 }, { 0x1.49539f0f010b0p+0, -0x1.7418b0a1fb77bp-2 },
-    { 0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2 }, { 0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2 }, { 0x1.25e227b0b8ea0p+0, -0x1.97c1d1b3b7af0p-3 },
-    { 0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3 }, { 0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4 }, { 0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5 },
-    { 0x1.0000000000000p+0, 0x0.0p+0 }, { 0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4 }, { 0x1.ca4b31f026aa0p-1, 0x1.476a9543891bap-3 },
-    { 0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3 }, { 0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2 }, { 0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2 },
-    { 0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2 } };
+
 
 WPT_HD double log2_inline(uint32_t ix)
 {
@@ -369,7 +386,7 @@ WPT_HD double log2_inline(uint32_t ix)
     uint32_t top = tmp & 0xff800000;
     uint32_t iz = ix - top;
     int k = (int32_t)top >> 23;
-    double invc = powf_log2_tab[i][0], logc = powf_log2_tab[i][1];
+    double invc = log2_entry(i, 0), logc = log2_entry(i, 1);
     double z = (double)bits_to_float(iz);
     double r = fma_d(z, invc, -1.0);
     double y0 = logc + (double)k;
@@ -389,7 +406,7 @@ WPT_HD float exp2_inline(double xd, uint32_t sign_bias)
     uint64_t ki = double_to_bits(kd);
     kd -= SHIFT;
     double r = xd - kd;
-    uint64_t t = exp2f_tab[ki % 32];
+    uint64_t t = exp2f_entry(ki % 32);
     uint64_t ski = ki + sign_bias;
     t += ski << (52 - 5);
     double s = bits_to_double(t);

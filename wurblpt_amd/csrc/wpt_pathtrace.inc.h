@@ -29,7 +29,7 @@
  *    leaf -> test it, then skip; otherwise -> skip.  Same visiting order, no stack, and the nodes
  *    may be STORED in any order (wpt_capi.hip lays the top of a large tree out level by level).
  *
- *  - Small scenes (nodes + triangle positions up to 21 KiB, e.g. the Cornell box: 4 KiB) are
+ *  - Small scenes (nodes + triangle positions up to 20 KiB, e.g. the Cornell box: 4 KiB) are
  *    copied into LDS once per workgroup and traversed from there; larger scenes are fetched
  *    from HBM/L2 as two dwordx4 per node and three per triangle.
  *
@@ -53,9 +53,12 @@ constexpr int WG = 256; /* threads per workgroup: 4 waves, one per SIMD */
  * first child (an empty node: NODE_CHILD | its own skip link, so that entering it is the same as skipping it) */
 constexpr uint32_t NODE_CHILD = 0xc0000000u;
 constexpr uint32_t NODE_INDEX_MASK = 0x3fffffffu;
-constexpr uint32_t COLD_BYTES = SLOT_COUNT * WG * 16; /* the paths' cold words: 32 KiB of LDS per workgroup */
+/* dynamic LDS of a workgroup: the tables of expf / powf (wpt_math.h, 512 B), the paths' cold words (32 KiB), then the
+ * scene if it is small */
+constexpr uint32_t TABLE_BYTES = WPT_MATH_TABLE_WORDS * 8;
+constexpr uint32_t COLD_BYTES = TABLE_BYTES + SLOT_COUNT * WG * 16;
 /* with the scene behind them three workgroups still fit into a CU's 160 KiB */
-constexpr uint32_t LDS_SCENE_MAX_BYTES = 21 * 1024;
+constexpr uint32_t LDS_SCENE_MAX_BYTES = 20 * 1024;
 struct KernelArgs {
     SceneView sv;
     wpt_camera cam;
@@ -93,9 +96,13 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
      * HBM the steps are memory round trips and nothing is gained (Sponza-class 118.7 - 121.0 against 120.4, 10 M
      * triangles 53 - 55 against 56.5 for 2 - 4 steps). */
     constexpr int STEPS = LDSSCENE ? 3 : 1;
-    /* [ cold path words: SLOT_COUNT x WG float4 ][ LDSSCENE: nodes, triangle positions ] */
+    /* [ math tables ][ cold path words: SLOT_COUNT x WG float4 ][ LDSSCENE: nodes, triangle positions ] */
     extern __shared__ float4 lds[];
-    float4* const ldsScene = lds + SLOT_COUNT * WG;
+    float4* const ldsCold = lds + TABLE_BYTES / 16;
+    float4* const ldsScene = ldsCold + SLOT_COUNT * WG;
+#if defined(WPT_MATH_TABLES_IN_LDS) && defined(__HIP_DEVICE_COMPILE__)
+    wptm::tables_to_lds(threadIdx.x);
+#endif
 
     const SceneView& sv = args.sv;
     const wpt_params& par = args.par;
@@ -108,8 +115,8 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             ldsScene[i] = sv.nodes[i];
         for (uint32_t i = threadIdx.x; i < t4; i += WG)
             ldsScene[n4 + i] = sv.triGeom[i];
-        __syncthreads();
     }
+    __syncthreads();
     auto node4 = [&](uint32_t i) -> float4 {
         if constexpr (LDSSCENE)
             return ldsScene[i];
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 
     /* ---- per-lane state: the pixel's path (wpt_blocks.h; its cold words in LDS) and the traversal registers ---- */
     PathLds<WG> ps;
-    ps.base = lds + threadIdx.x;
+    ps.base = ldsCold + threadIdx.x;
     pathStateInit(ps, pixel, pixel % args.width, pixel / args.width);
     LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
     /* wave-level scheduler statistics (COUNT builds): rounds and lane counts per state */
