@@ -118,11 +118,10 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 0x20, 0x21, 0x22, 0x06])
+@pytest.mark.parametrize("variant", [0, 1, 2, 0x20, 0x21, 0x22])
 def test_kernel_variants_agree_bit_for_bit(dev, oracle, variant):
     """0 = scene in LDS, 1 = scene fetched from HBM/L2, 2 = the all-features kernel;
-    +0x20 = separate SHADE / NEE-END / NEW rounds instead of the fused long round;
-    0x06 = the all-features build for large trees (kept machine LICM, no node prefetch)"""
+    +0x20 = separate SHADE / NEE-END / NEW rounds instead of the fused long round"""
     sc = host.cornell(64, 48, 1, 2)
     ref, _ = oracle.render(sc, 5)
     dev.lib().wpt_set_launch_config(0, variant)

@@ -758,8 +758,6 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
             launchBasicLds(args, grid, ldsBytes, stream);
         else if (basic)
             launchBasic(args, grid, stream);
-        else if ((scene->nodeCount >= (1u << 21) && (g_variant & 0x40u) == 0) || (g_variant & 0x04u) != 0)
-            launchFullWalk(args, grid, stream); /* tree of 64 MiB and more (variant 0x40: never, 0x04: always) */
         else
             launchFull(args, grid, stream);
     }

@@ -84,11 +84,12 @@ struct KernelArgs {
 /* lane states, in scheduling priority order for ties */
 enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5 };
 
-/* TUNE only tells apart two builds of one instantiation that are compiled with different options (Makefile) */
-template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, int TUNE = 0>
+template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC>
 __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 {
-    constexpr bool PREFETCH = !LDSSCENE && TUNE == 0;
+    /* node prefetch: for scenes in HBM (Sponza-class frame 3 % faster); not from LDS, where the eight registers cost more
+     * than the short fetch (Cornell 4 % slower) */
+    constexpr bool PREFETCH = !LDSSCENE;
     /* Node steps per look at the lane counts.  The look itself (two ballots, their counts, the leave and leaf decisions:
      * some twenty scalar instructions and two branches in every lane's way) costs a wave as much issue time as half a
      * node step.  From LDS a step is short, and taking up to three in a row before looking again gave 852 against 799
@@ -411,8 +412,6 @@ void launchGroundTruth(const GroundTruthArgs& args, hipStream_t stream);
 /* one launcher per instantiation, each defined in its own translation unit; sceneLdsBytes is the size of the scene
  * copy behind the cold path words in LDS (0 for the kernels that fetch the scene from HBM) */
 void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
-/* the all-features kernel built for scenes whose frame time is traversal (trees far larger than the caches) */
-void launchFullWalk(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream);
