@@ -376,7 +376,7 @@ def test_bvh_storage_order_never_changes_results(dev, oracle, top):
         assert bits_equal(gt_dev[name], gt_ref[name]), name
 
 
-@pytest.mark.parametrize("material", [0, 2, 3, 5])
+@pytest.mark.parametrize("material", [0, 2, 3, 5, 6, 7])
 def test_furnace_scenes_bit_exact(dev, oracle, material):
     """wurblpt-furnace-test.cpp with a tessellated sphere (Lambertian, ModPhong diffuse and
     specular lobes, GGX) in a constant environment, no pixel jitter: GPU == oracle, and for the
@@ -389,6 +389,8 @@ def test_furnace_scenes_bit_exact(dev, oracle, material):
     assert bits_equal(got, ref) and gc == rc
     if material == 0:
         assert float(np.median(got[18:30, 18:30])) == pytest.approx(0.42, rel=1e-6)
+    if material in (6, 7):      # clear glass, perfect mirror (analytic sphere): every pixel exactly 1
+        assert np.array_equal(got, np.ones_like(got))
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])

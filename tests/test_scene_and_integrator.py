@@ -220,6 +220,22 @@ def test_furnace_modphong_conserves_energy_in_expectation(oracle):
         assert 0.8 < c.mean() < 1.005
 
 
+def test_furnace_glass_and_mirror_return_exactly_what_they_receive(oracle):
+    """Clear glass (MaterialGlass, absorption 0, index 1.5) and a perfect mirror on an analytic sphere in a constant
+    environment of radiance 1: whatever a path does -- refract in, reflect inside any number of times, refract out, or
+    reflect off the outside -- its attenuation is a product of ones, Russian roulette never draws (the attenuation's
+    maximum is not below the threshold of 1), so every sample contributes exactly 1 and every pixel, on the sphere or
+    beside it, is exactly 1.0f: an analytic pin of the explicit scattering bookkeeping of tracePath, of exp(-0 * d) = 1 in
+    the glass, and of EnvironmentMap::L on escape (rows a4, a18, a19, a21) that needs no reference build."""
+    for material in (6, 7):
+        sc = host.furnace(48, 48, material)
+        frame, cnt = oracle.render(sc, 4)
+        assert np.array_equal(frame, np.ones_like(frame)), (material, frame.min(), frame.max())
+        assert cnt["scatters"] > 0.2 * cnt["samples"]       # the sphere is in the picture
+        if material == 6:
+            assert cnt["rays"] > cnt["samples"] + 1.9 * cnt["scatters"] * 0.5   # paths go through: at least two hits each
+
+
 def test_ground_truth_restatement_is_consistent(oracle):
     """The CPU restatement of getGroundTruth (wurblpt.hpp:626-761): its first hit is the path tracer's first hit, its
     arrays mean what the reference says (its building blocks are pinned in test_oracle_golden.py)."""

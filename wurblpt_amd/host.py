@@ -164,7 +164,8 @@ def courtyard_like(width, height, seed=2, triangles=10_000_000, tex_size=1024):
 def furnace(width, height, material=0, slices=64):
     """wurblpt-furnace-test.cpp with a tessellated sphere: one material in a constant environment
     of radiance 1.  material: 0 Lambertian 0.42, 1 Lambertian 1, 2 ModPhong(1,0), 3 ModPhong(0,1),
-    4 ModPhong(.5,.5), 5 GGX albedo 1 roughness 0.5."""
+    4 ModPhong(.5,.5), 5 GGX albedo 1 roughness 0.5; on an analytic sphere: 6 clear glass (no absorption, index 1.5),
+    7 perfect mirror."""
     h = lib().wpt_host_furnace(material, slices, width, height)
     return HostScene(h, width, height, "furnace(material=%d)" % material)
 

@@ -440,7 +440,15 @@ extern "C" wpt_host_scene* wpt_host_furnace(int material, int slices, unsigned i
     case 3: mat = scene.take(new MaterialModPhong(vec3(0.0f), vec3(1.0f))); break;
     case 4: mat = scene.take(new MaterialModPhong(vec3(0.5f), vec3(0.5f))); break;
     case 5: mat = scene.take(new MaterialGGX(vec3(1.0f), vec2(0.5f, 0.5f))); break;
+    /* on an analytic sphere (no facets, so no total internal reflection at facet edges): clear glass and a perfect mirror
+     * neither absorb nor emit, every path leaves with attenuation exactly 1 */
+    case 6: mat = scene.take(new MaterialGlass(vec4(0.0f), 1.5f)); break;
+    case 7: mat = scene.take(new MaterialMirror(vec3(1.0f))); break;
     default: mat = nullptr; break;
+    }
+    if (material == 6 || material == 7) {
+        scene.take(new Sphere(vec3(0.0f), 1.0f, mat));
+        return wptHostFinish(scenePtr, width, height, radians(40.0f), vec3(0.0f, 0.0f, 5.0f), vec3(0.0f, 0.0f, 0.0f), 0.0f, 1.0f);
     }
     scene.take(new MeshInstance(scene.take(generateSphere(Transformation(), slices, slices / 2)), mat));
     return wptHostFinish(scenePtr, width, height, radians(40.0f), vec3(0.0f, 0.0f, 5.0f), vec3(0.0f, 0.0f, 0.0f), 0.0f, 1.0f);
