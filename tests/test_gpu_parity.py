@@ -301,6 +301,18 @@ def test_reference_mis_test_converges_to_material_sampling(dev):
     assert np.abs(ba - bb).max() / bb.mean() < 0.05                     # no block is off by more than 5 % of the mean
 
 
+@pytest.mark.parametrize("compat", [0, 1])
+def test_texture_probe_scene_bit_exact(dev, oracle, compat):
+    """the scene whose pixels tests/test_scene_and_integrator.py evaluates independently of all code here (a textured
+    light in front of a float environment, one ray through every pixel centre): GPU == oracle, hence == that evaluation"""
+    sc = host.texture_probe(64, 48, compat)
+    p = host.default_params()
+    p.randomize_ray_over_pixel = 0
+    ref, rc = oracle.render(sc, 1, p)
+    got, gc = dev.DeviceScene(sc).render(1, params=p, with_counters=True)
+    assert bits_equal(got, ref) and gc == rc
+
+
 def test_reference_mis_test_scene_bit_exact(dev, oracle):
     """the same scene (four GGX plates from mirror-like to rough, sphere lights as hot spots) against the oracle"""
     for hot in (False, True):

@@ -236,6 +236,106 @@ def test_furnace_glass_and_mirror_return_exactly_what_they_receive(oracle):
             assert cnt["rays"] > cnt["samples"] + 1.9 * cnt["scatters"] * 0.5   # paths go through: at least two hits each
 
 
+def _independent_image_texture(desc, index, tc):
+    """TextureImage::value(texcoords) written from the reference's text (texture_image.hpp:85-212, color.hpp:275-294) in
+    float64 numpy, over the raw texels of the scene description: fract of the transformed coordinates, half-texel
+    shift clamped at 0, the far neighbours clamped to the last column / row, 8-bit values / 255 with the sRGB curve on
+    the colour channels, value factor and offset."""
+    import ctypes as C
+    t = desc.textures[index]
+    assert t.type == 2
+    w, h, comps = int(t.width), int(t.height), int(t.comps)
+    dtype = {0: np.uint8, 1: np.uint16, 2: np.float32}[int(t.texel_type)]
+    raw = np.frombuffer((C.c_uint8 * int(desc.texel_bytes)).from_address(desc.texels), dtype=np.uint8)
+    texels = raw[int(t.texel_offset): int(t.texel_offset) + w * h * comps * np.dtype(dtype).itemsize].view(dtype).reshape(h, w, comps).astype(np.float64)
+    if dtype != np.float32:
+        texels = texels / (255.0 if dtype == np.uint8 else 65535.0)
+    if t.linearize_srgb:
+        texels = np.where(texels <= 0.04045, texels / 12.92, ((texels + 0.055) / 1.055) ** 2.4)
+    uv = np.array(t.coord_factor[:2]) * np.asarray(tc, np.float64) + np.array(t.coord_offset[:2])
+    uv = uv - np.floor(uv)
+    s = max(0.0, uv[0] * w - 0.5)
+    q = max(0.0, uv[1] * h - 0.5)
+    x0, y0 = int(s), int(q)
+    x1, y1 = min(x0 + 1, w - 1), min(y0 + 1, h - 1)
+    a, b = s - x0, q - y0
+    top = texels[y0, x0] * (1 - a) + texels[y0, x1] * a
+    bottom = texels[y1, x0] * (1 - a) + texels[y1, x1] * a
+    return np.array(t.a[:3]) * (top * (1 - b) + bottom * b) + np.array(t.b[:3])
+
+
+@pytest.mark.parametrize("compat", [0, 1])
+def test_what_a_camera_ray_sees_matches_an_independent_evaluation(oracle, compat):
+    """Rows a20 (TextureImage), a21 (EnvironmentMapEquiRect::L) and the texture coordinates of a triangle hit (a9 / a10)
+    have no golden vectors from the reference (their headers need libtgd).  This is the next best thing: a scene in which
+    a pixel is nothing but LightDiffuse::emitted or L of its centre ray (host.texture_probe), and a second evaluation of
+    exactly that, written in float64 numpy from the reference's text alone -- it shares no code with the oracle or the
+    kernels and reads the camera, the triangle corners, their texture coordinates and the raw texels from the scene
+    description.  The two agree to float rounding for every pixel: row order, half-texel shift, edge clamp, wrap, sRGB
+    decoding, value transform, the Mitsuba / surround-video orientation of the environment, the interpolation of
+    texture coordinates over a hit."""
+    import ctypes as C
+    from wurblpt_amd import _abi
+    W, H = 64, 48
+    sc = host.texture_probe(W, H, compat)
+    d = sc.d
+    p = host.default_params()
+    p.randomize_ray_over_pixel = 0
+    frame, _ = oracle.render(sc, 1, p)
+    cam = C.cast(sc.camera, C.POINTER(_abi.Camera)).contents
+    q = np.array(cam.rotation[:], np.float64)           # x y z w
+
+    def rotate(v):
+        s3 = q[:3]
+        t = 2.0 * np.cross(s3, v)
+        return v + q[3] * t + np.cross(s3, t)
+    origin = np.array(cam.translation[:], np.float64)
+    light = d.materials[d.tri_geom[0].material]
+    assert light.type == 2 and light.tex[0] >= 0        # WPT_MAT_LIGHT_DIFFUSE with an emission texture
+    emit = np.array(light.v[0][:3], np.float64)
+    seen_light = seen_sky = 0
+    worst = 0.0
+    for py in range(H):
+        for px in range(W):
+            u, v = (px + 0.5) / W, (py + 0.5) / H
+            direction = rotate(np.array([cam.l + u * (cam.r - cam.l), cam.b + v * (cam.t - cam.b), -1.0]))
+            direction /= np.linalg.norm(direction)
+            expected = None
+            for k in range(d.tri_count):
+                g, at = d.tri_geom[k], d.tri_attr[k]
+                v0, v1, v2 = (np.array(c[:], np.float64) for c in (g.v0, g.v1, g.v2))
+                e1, e2 = v1 - v0, v2 - v0
+                pv = np.cross(direction, e2)
+                det = e1 @ pv
+                tv = origin - v0
+                bu = (tv @ pv) / det
+                qv = np.cross(tv, e1)
+                bv = (direction @ qv) / det
+                dist = (e2 @ qv) / det
+                if bu >= 0 and bv >= 0 and bu + bv <= 1 and dist > 0:
+                    tc = (1 - bu - bv) * np.array(at.tc0[:]) + bu * np.array(at.tc1[:]) + bv * np.array(at.tc2[:])
+                    if min(bu, bv, 1 - bu - bv) < 1e-4:
+                        expected = "edge"           # on the shared diagonal or the rim: either triangle may win
+                    else:
+                        expected = emit * _independent_image_texture(d, light.tex[0], tc)
+                        seen_light += 1
+                    break
+            if expected is None:
+                lat = np.arcsin(np.clip(direction[1], -1.0, 1.0))
+                lon = np.arctan2(-direction[0], direction[2])
+                if compat == 0:
+                    lon -= np.pi
+                    if lon < 0.0:
+                        lon += 2.0 * np.pi
+                expected = _independent_image_texture(d, d.envmap.tex, (lon * 0.5 / np.pi, lat / np.pi + 0.5))
+                seen_sky += 1
+            if isinstance(expected, str):
+                continue
+            worst = max(worst, float(np.abs(frame[py, px] - expected).max() / max(1.0, float(np.abs(expected).max()))))
+    assert seen_light > 0.1 * W * H and seen_sky > 0.3 * W * H
+    assert worst < 2e-5, worst
+
+
 def test_ground_truth_restatement_is_consistent(oracle):
     """The CPU restatement of getGroundTruth (wurblpt.hpp:626-761): its first hit is the path tracer's first hit, its
     arrays mean what the reference says (its building blocks are pinned in test_oracle_golden.py)."""

@@ -180,6 +180,15 @@ def mis_test(width, height, with_hot_spots=True, light_mask=15):
     return HostScene(h, width, height, "mis_test(hot_spots=%d,lights=%d)" % (with_hot_spots, light_mask))
 
 
+def texture_probe(width, height, compat=0):
+    """A textured quad light in front of a float environment map, for checking what a camera ray sees directly
+    (wpt_host_texture_probe); compat 0 = Mitsuba, 1 = surround video orientation of the environment."""
+    L = lib()
+    L.wpt_host_texture_probe.restype = C.c_void_p
+    L.wpt_host_texture_probe.argtypes = [C.c_int, C.c_uint, C.c_uint]
+    return HostScene(L.wpt_host_texture_probe(compat, width, height), width, height, "texture_probe(compat=%d)" % compat)
+
+
 def spheres(width, height, variant=0):
     """Scenes with analytic spheres (HitableSphere): 0 = textured / GGX / glass / mirror spheres lit by
     a sphere light and a quad light (both hot spots), 1 = the same under a cube environment map,

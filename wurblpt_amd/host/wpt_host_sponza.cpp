@@ -637,6 +637,36 @@ extern "C" wpt_host_scene* wpt_host_mis_test(int withHotSpots, unsigned int ligh
     return wptHostFinish(scenePtr, width, height, radians(50.0f), vec3(0.0f, -4.5f, -1.2f), vec3(0.0f, -4.5f, -2.2f), 0.0f, 1.0f);
 }
 
+/* A probe for what the camera sees directly: a quad light with an emission texture (an 8-bit sRGB image of 7 x 5 texels
+ * with coordinate factor / offset and value factor / offset) in the middle of the view, and around it an equirectangular
+ * environment of float texels (16 x 8).  With one sample through every pixel centre a pixel is LightDiffuse::emitted or
+ * EnvironmentMapEquiRect::L of its ray and nothing else, so TextureImage::value (texel decoding, the half-texel shift, the
+ * clamp at the far edges, fract of the transformed coordinates) and L's direction-to-coordinate mapping can be checked
+ * against an evaluation written independently from the reference's text (tests/test_scene_and_integrator.py).
+ * compat: 0 Mitsuba, 1 surround video. */
+extern "C" wpt_host_scene* wpt_host_texture_probe(int compat, unsigned int width, unsigned int height)
+{
+    Scene* scenePtr = new Scene;
+    Scene& scene = *scenePtr;
+    unsigned int state = 12345u;
+    auto next = [&state]() { state = state * 1664525u + 1013904223u; return state >> 8; };
+    Array<float> sky(16, 8, 3);
+    for (size_t i = 0; i < sky.elementCount(); i++)
+        for (int c = 0; c < 3; c++)
+            sky[i][c] = float(next() & 0xffffu) * (1.0f / 65536.0f) * 2.0f;
+    Array<uint8_t> picture(7, 5, 3);
+    for (size_t i = 0; i < picture.elementCount(); i++)
+        for (int c = 0; c < 3; c++)
+            picture[i][c] = uint8_t(next() & 0xffu);
+    Texture* skyTex = scene.take(createTextureImage(sky, LinearizeSRGB_Off));
+    scene.take(new EnvironmentMapEquiRect(skyTex, compat == 0 ? EnvironmentMapEquiRect::CompatibilityMitsuba : EnvironmentMapEquiRect::CompatibilitySurroundVideo));
+    Texture* pictureTex = scene.take(createTextureImage(picture, LinearizeSRGB_Auto, vec2(2.0f, 3.0f), vec2(0.25f, 0.1f),
+                vec4(0.9f, 0.8f, 0.7f, 1.0f), vec4(0.05f, 0.02f, 0.01f, 0.0f)));
+    Material* light = scene.take(new LightDiffuse(vec3(1.5f, 1.2f, 0.9f), pictureTex));
+    scene.take(new MeshInstance(scene.take(generateQuad(Transformation(vec3(0.1f, -0.05f, -2.0f), quat::null(), vec3(0.6f, 0.4f, 1.0f)))), light));
+    return wptHostFinish(scenePtr, width, height, radians(60.0f), vec3(0.0f, 0.0f, 0.0f), vec3(0.3f, 0.2f, -1.0f), 0.0f, 1.0f);
+}
+
 /* Builds the tables of a measured BRDF file as MaterialRGL does (include/wurblpt/rgl.hpp).
  * Returns the number of floats of the table pool (0 on error, message on stderr); copies at most
  * `capacity` of them. */
