@@ -1,0 +1,16 @@
+#!/bin/bash
+# experiment: a kind of material with few lanes may stand back twice (variant bit 0x40)
+set -o pipefail
+O=gpurun_out/r02t
+mkdir -p $O
+timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "variant or scheduler or kernel_choice" > $O/pytest.log 2>&1; echo "pytest rc $?"; tail -1 $O/pytest.log
+for V in 0 4 64 76 12; do
+  timeout -k 10 300 python bench.py --variant $V --no-cpu-baseline > $O/bench_co_$V.json 2> $O/bench_co_$V.err || exit 1
+  echo "cornell variant $V: $(python -c "import json; d=json.load(open('$O/bench_co_$V.json')); print(round(d['value'],1))")"
+done
+for V in 0 4; do
+  timeout -k 10 300 python bench.py --variant $V --workload cornell_256x256_64spp_lambertian --samples-sqrt 32 --no-cpu-baseline > $O/bench_c1_$V.json 2> $O/bench_c1_$V.err || exit 1
+  echo "config 1 variant $V: $(python -c "import json; d=json.load(open('$O/bench_c1_$V.json')); print(round(d['value'],1))")"
+done
+timeout -k 10 300 python bench.py --workload sponza_like_1920x1080_256spp_envmap_is --no-cpu-baseline > $O/bench_sp.json 2> $O/bench_sp.err || exit 1
+echo "sponza: $(python -c "import json; d=json.load(open('$O/bench_sp.json')); print(round(d['value'],1))")"

@@ -33,8 +33,8 @@ using namespace wptd;
 
 constexpr uint32_t NO_HIT = 0xffffffffu;
 
-enum { RAY_PATH = 0, RAY_NEE_LIGHT = 1, RAY_NEE_ENV = 2 };
-enum { NEXT_TRACE = 0, NEXT_NEW = 1, NEXT_DONE = 2 };
+enum { RAY_PATH = 0, RAY_NEE_LIGHT = 1, RAY_NEE_ENV = 2, RAY_PATH_WAITED = 3 /* a path ray's hit that has stood back once */ };
+enum { NEXT_TRACE = 0, NEXT_NEW = 1, NEXT_DONE = 2, NEXT_WAIT = 3 };
 
 struct LaneCounters {
     uint32_t rays, nodes, leaves, pdfs, scatters;
@@ -423,7 +423,7 @@ WPT_D int blockNew(const FrameArgs& fa, PS& ps, const SceneView* sv = nullptr)
 
 /* tracePath, one path component (wurblpt.hpp:131-252); `best` is the path ray's result */
 template<uint32_t F, bool COUNT, class Tri4, class PS>
-WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& ps, const Candidate& best, LaneCounters& lc)
+WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& ps, const Candidate& best, LaneCounters& lc, int waitBelow = 0)
 {
     const bool haveEnv = (F & FEAT_ENVMAP) && sv.envType != WPT_ENV_NONE;
     if (best.prim == NO_HIT) {
@@ -442,7 +442,6 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
     const f3 opl = add(mk3(oplSlot.x, oplSlot.y, oplSlot.z), scl(best.a, mk3(ray.ri.x, ray.ri.y, ray.ri.z)));
     if (!(pathComponent + 1 < par.max_path_components))
         return NEXT_NEW;
-    ps.set3(SLOT_OPL, opl);
     long long tSection = 0;
     auto section = [&](int k) { /* COUNT builds: close section k */
         if (COUNT) {
@@ -455,6 +454,27 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
         tSection = clock64();
     Hit h = finishHit<F>(sv, best, ray.o, ray.d, ps.time);
     const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
+    if ((F & ~(FEAT_GGX | FEAT_GLASS)) == 0 && waitBelow > 0) { /* the all-features builds have no register to spare for it */
+        /* Each kind of material is its own stretch of code below, as long for one lane as for
+         * forty.  A kind with few lanes in this round, next to lanes of other kinds, stands back
+         * once (nothing has been written yet): the next round then runs it for two rounds' worth
+         * of lanes.  Which lanes run together never changes what a lane computes. */
+        const bool waited = ps.rayKind == RAY_PATH_WAITED;
+        const unsigned long long here = __ballot(true);
+        bool wait = false;
+        for (uint32_t kind = WPT_MAT_LAMBERTIAN; kind <= WPT_MAT_RGL; kind++) {
+            if (kind == WPT_MAT_LIGHT_DIFFUSE || kind == WPT_MAT_TWOSIDED) /* a light ends the path at once; two-sided has been resolved */
+                continue;
+            const unsigned long long lanes = __ballot(m.type == kind);
+            if (lanes != 0 && lanes != here && __popcll(lanes) < waitBelow && __ballot(m.type == kind && waited) == 0 && m.type == kind)
+                wait = true;
+        }
+        if (wait) {
+            ps.rayKind = RAY_PATH_WAITED;
+            return NEXT_WAIT;
+        }
+    }
+    ps.set3(SLOT_OPL, opl);
     if (COUNT)
         lc.scatters++;
     section(0);

@@ -729,6 +729,9 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     args.leaveEighths = g_leaveEighths ? (g_leaveEighths > 8u ? 8u : g_leaveEighths) : (smallScene ? 1u : 3u);
     args.heavyMin = g_heavyMin ? g_heavyMin : (smallScene ? 16u : 8u);
     args.leafBias = g_leafBias ? g_leafBias : (smallScene ? 16u : 32u);
+    /* variant bits 2-3: 0 = default, 1 = no kind of material ever stands back, 2 / 3 = fewer than 3 / 12 lanes */
+    static const uint32_t waitBelowChoices[4] = { 6u, 0u, 3u, 12u };
+    args.waitBelow = waitBelowChoices[(g_variant >> 2) & 0x3u];
     /* kernel choice.  Low nibble of the variant word: 1 = keep the scene in HBM, 2 = all features. */
     const uint32_t force = g_variant & 0x3u;
     const bool basic = (need & ~FEAT_BASIC) == 0 && force != 2;

@@ -74,6 +74,7 @@ struct KernelArgs {
     uint32_t leaveEighths; /* scheduler: leave the NODE loop when fewer than this many eighths of the entering lanes remain */
     uint32_t heavyMin;     /* scheduler: lanes a long block needs before it runs */
     uint32_t leafBias;     /* scheduler: leaf tests run when waiting lanes * leafBias >= walking lanes * 8 */
+    uint32_t waitBelow;    /* scheduler: a kind of material with fewer lanes than this in a long round stands back once (0 = never) */
     uint32_t fuse;         /* scheduler: 1 = one long round serves SHADE, NEE-END and NEW lanes together */
     float* frame;
     wpt_counters* counters;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     auto afterBlock = [&](int next) {
         if (next == NEXT_TRACE)
             beginRay();
-        else
+        else if (next != NEXT_WAIT) /* a waiting lane keeps its state and its hit */
             state = next == NEXT_NEW ? (int)S_NEW : (int)S_DONE;
     };
 
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 sched[6] += cShade;
             }
             if (state == S_SHADE) /* tracePath, one path component (wurblpt.hpp:131-252) */
-                afterBlock(blockShade<F, COUNT>(sv, par, tri4, ps, best, lc));
+                afterBlock(blockShade<F, COUNT>(sv, par, tri4, ps, best, lc, cTrav != 0 ? (int)args.waitBelow : 0));
             if (COUNT)
                 sched[12] += (unsigned long long)(clock64() - tBlock);
         }
