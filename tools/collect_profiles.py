@@ -67,5 +67,8 @@ for letter, (short, workload) in WORK.items():
                 "valu_busy_percent": mean("VALUBusy"),
                 "pmc_file": "profiles/%s_pmc_%s.txt" % (prefix, short)})
 if traffic:
-    json.dump({"workloads": traffic}, open(os.path.join(OUT, "hbm_traffic.json"), "w"), indent=1)
+    path = os.path.join(OUT, "hbm_traffic.json")
+    merged = json.load(open(path))["workloads"] if os.path.exists(path) else {}
+    merged.update(traffic)  # workloads not profiled in this run keep their entry
+    json.dump({"workloads": merged}, open(path, "w"), indent=1)
 print(json.dumps(traffic, indent=1))

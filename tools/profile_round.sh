@@ -1,10 +1,18 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/profile_round.sh <tag> [1|2]
+# usage (on the GPU box): bash tools/profile_round.sh <tag> [1|2|c]
 # kernel-trace statistics of the default bench command, then PMC passes (each its own run);
-# part 1 = Cornell + Sponza-class, part 2 = the 10 M triangle scene (default: both)
+# part 1 = Cornell + Sponza-class, part 2 = the 10 M triangle scene (default: both); c = Cornell alone
 export TMPDIR=/tmp
 TAG=$1
 PART=${2:-12}
+if [[ $PART == *c* ]]; then
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_${TAG}_cornell -o stats --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/stats_${TAG}_cornell.log 2>&1 || exit 1
+bash tools/pmc_sq.sh ${TAG}c || exit 1
+for P in "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace -d gpurun_out/pmc_${TAG}c_$P -o pmc --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/pmc_${TAG}c_$P.log 2>&1 || exit 1
+done
+echo done cornell
+fi
 if [[ $PART == *1* ]]; then
 S="--workload sponza_like_1920x1080_256spp_envmap_is --steps 2 --warmup 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_${TAG}_cornell -o stats --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/stats_${TAG}_cornell.log 2>&1 || exit 1

@@ -1,4 +1,4 @@
-"""usage (GPU box): python tools/sched_sweep.py [cornell|sponza] [samples_sqrt]
+"""usage (GPU box): python tools/sched_sweep.py [cornell|sponza] [samples_sqrt] [variant byte 0]
 Times the frame for a grid of scheduler settings in one process (wpt_set_launch_config word: byte 1 = leave eighths + 1,
 byte 2 = lanes a long round needs + 1, byte 3 = leaf bias); results never depend on them, only the time does."""
 import os
@@ -10,6 +10,7 @@ from wurblpt_amd import device, host
 
 what = sys.argv[1] if len(sys.argv) > 1 else "cornell"
 ssqrt = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+low = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
 sc = host.cornell(1024, 1024, 1, 2) if what == "cornell" else host.sponza_like(1920, 1080)
 ds = device.DeviceScene(sc)
 frame = torch.zeros((sc.height, sc.width, 3), dtype=torch.float32, device="cuda")
@@ -32,14 +33,14 @@ def run(word):
     return sc.width * sc.height * ssqrt * ssqrt / best / 1e3
 
 
-base = run(0)
+base = run(low)
 print("default: %.1f Msamples/s" % base, flush=True)
 results = []
 leaves = (1, 2, 3) if what == "cornell" else (2, 3, 4)
 for leave in leaves:
     for heavy in (6, 8, 12, 16, 20, 24, 32):
         for bias in (8, 12, 16, 24, 32, 48):
-            word = ((leave + 1) << 8) | ((heavy + 1) << 16) | (bias << 24)
+            word = low | ((leave + 1) << 8) | ((heavy + 1) << 16) | (bias << 24)
             r = run(word)
             results.append((r, leave, heavy, bias))
             print("leave %d heavy %2d bias %2d: %.1f" % (leave, heavy, bias, r), flush=True)
