@@ -915,6 +915,41 @@ def test_interleaved_bands_in_one_launch(dev, oracle, w, h, band_rows, stride):
         ds.render_bands_into(torch.zeros((h, w, 3), dtype=torch.float32, device="cuda"), 3, band_rows, stride, stride)
 
 
+def test_pixel_pool_never_changes_results(dev, oracle):
+    """Frames with more pixels than the GPU has lanes at once are handed out pixel by pixel: lanes whose pixel is
+    finished take the next lane index of the launch from a counter (variant bit 0x10 = never).  A pixel's value depends on the pixel alone, so the frame is the
+    oracle's whatever lane renders it: one launch, ragged blocks, tiled and untiled mappings, a rank's bands."""
+    import torch
+    w, h, s = 1024, 640, 2          # 655 360 pixels against 262 144 lanes in flight on an MI355X
+    sc = host.cornell(w, h, 1, 2)
+    ref, _ = oracle.render(sc, s)
+    for variant in (0, 0x10, 0x01, 0x02, 0x20):
+        dev.lib().wpt_set_launch_config(0, variant)
+        try:
+            ds = dev.DeviceScene(sc)
+            got, _ = ds.render(s)
+            assert bits_equal(got, ref), hex(variant)
+            if variant in (0, 0x02):
+                frame = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+                cuts = [0, 8 * w * 40, 8 * w * 40 + 300001, w * h]   # tiled, untiled (ragged), untiled
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    ds.render_block_into(frame, s, (a, b - a))
+                torch.cuda.synchronize()
+                assert bits_equal(frame.cpu().numpy(), ref), hex(variant)
+                total = np.zeros_like(ref)
+                for band_rows, stride in ((8, 2), (5, 2)):            # tiled and untiled bands
+                    total[:] = 0
+                    for rank in range(stride):
+                        frame.zero_()
+                        ds.render_bands_into(frame, s, band_rows, rank, stride, stream=torch.cuda.current_stream())
+                        torch.cuda.synchronize()
+                        total += frame.cpu().numpy()
+                    assert bits_equal(total, ref), (hex(variant), band_rows)
+            ds.check()
+        finally:
+            dev.lib().wpt_set_launch_config(0, 0)
+
+
 def test_fuzz_parity_over_seeded_random_scenes():
     """tools/fuzz_parity.py, five rounds: 35 seeded random scenes of every family (triangle soups, Sponza-class, foliage,
     measured BRDFs, animated, spheres, Cornell with random lens models and camera modes) with random sizes, sample counts

@@ -737,6 +737,17 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     const bool basic = (need & ~FEAT_BASIC) == 0 && force != 2;
     const bool lds = smallScene && force != 1;
     const bool rgl = (need & FEAT_RGL) != 0; /* measured BRDFs have their own instantiation */
+    /* Pixel pool: frames with more pixels than the device has lanes at once are handed out pixel by pixel (the launchers
+     * decide); variant bit 0x10: never.  The counter is allocated and freed in stream order, so launches in flight on any
+     * number of streams never share one. */
+    uint32_t* pool = nullptr;
+    const bool pooled = !count && !(g_variant & 0x10u) && block_size < 0x80000000u && grid.x > uint32_t(scene->cuCount);
+    if (pooled && hipMallocAsync(reinterpret_cast<void**>(&pool), sizeof(uint32_t), stream) != hipSuccess) {
+        (void)hipGetLastError();
+        pool = nullptr;
+    }
+    args.pool = pool;
+    args.cuCount = uint32_t(scene->cuCount);
     if (anim) {
         /* its own instantiation, like the measured BRDFs */
         if (need & FEAT_RGL) {
@@ -766,7 +777,10 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
         else
             launchFull(args, grid, stream);
     }
-    HIP_TRY(hipGetLastError());
+    const hipError_t launched = hipGetLastError();
+    if (pool)
+        (void)hipFreeAsync(pool, stream);
+    HIP_TRY(launched);
     return WPT_OK;
 }
 

@@ -6,7 +6,7 @@ namespace wptk {
 
 void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_BASIC, false, true, 4>), grid, dim3(WG), COLD_BYTES + sceneLdsBytes, stream, args);
+    launchMaybePooled(wpt_pathtrace<FEAT_BASIC, false, true, 4>, args, grid, COLD_BYTES + sceneLdsBytes, stream);
 }
 
 }

@@ -6,7 +6,7 @@ namespace wptk {
 
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL, false, false, 4>), grid, dim3(WG), COLD_BYTES, stream, args);
+    launchMaybePooled(wpt_pathtrace<FEAT_ALL, false, false, 4>, args, grid, COLD_BYTES, stream);
 }
 
 }

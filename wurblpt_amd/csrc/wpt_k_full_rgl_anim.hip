@@ -7,7 +7,7 @@ namespace wptk {
 
 void launchFullRglAnim(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((wpt_pathtrace<FEAT_ALL | FEAT_RGL | FEAT_ANIM, false, false, 2>), grid, dim3(WG), COLD_BYTES, stream, args);
+    launchMaybePooled(wpt_pathtrace<FEAT_ALL | FEAT_RGL | FEAT_ANIM, false, false, 2>, args, grid, COLD_BYTES, stream);
 }
 
 void launchFullRglAnimCount(const KernelArgs& args, dim3 grid, hipStream_t stream)

@@ -77,6 +77,11 @@ struct KernelArgs {
     uint32_t waitBelow;    /* scheduler: a kind of material with fewer lanes than this in a long round stands back once (0 = never) */
     uint32_t fuse;         /* scheduler: 1 = one long round serves SHADE, NEE-END and NEW lanes together */
     float* frame;
+    /* Pixel pool (or NULL): lanes whose pixel is finished take the next lane index of the launch from this counter, which
+     * starts at the number of lanes launched.  A launch then is as many workgroups as the GPU holds at once, and a wave
+     * keeps its 64 lanes at work until the launch runs out of pixels instead of until its slowest pixel ends. */
+    uint32_t* pool;
+    uint32_t cuCount; /* for the launchers: compute units of the device */
     wpt_counters* counters;
     unsigned long long* schedStats; /* COUNT builds: 16 scheduler statistics, or NULL */
     uint32_t* status;               /* set to 1 by a launch that had to abort (bounded waits) */
@@ -132,30 +137,33 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             return sv.triGeom[i];
     };
 
-    /* lane -> pixel */
-    const uint32_t gid = blockIdx.x * WG + threadIdx.x;
-    bool inBlock = gid < args.blockSize;
-    uint32_t pixel;
-    if (args.tiled) {
-        const uint32_t tilesPerRow = args.width >> 3;
-        const uint32_t tile = gid >> 6, lane = gid & 63u;
-        const uint32_t tx = tile % tilesPerRow;
-        uint32_t ty = tile / tilesPerRow;
-        if (args.bandStride) {
-            /* tile rows of this launch -> tile rows of the frame (bands are whole groups of 8 rows here) */
-            const uint32_t tileRowsPerBand = args.bandPixels / (args.width << 3);
-            ty = (args.bandFirst + (ty / tileRowsPerBand) * args.bandStride) * tileRowsPerBand + ty % tileRowsPerBand;
+    /* lane index of the launch -> pixel; false: no pixel behind this index */
+    auto pixelOf = [&](uint32_t gid, uint32_t& pixel) -> bool {
+        bool inBlock = gid < args.blockSize;
+        if (args.tiled) {
+            const uint32_t tilesPerRow = args.width >> 3;
+            const uint32_t tile = gid >> 6, lane = gid & 63u;
+            const uint32_t tx = tile % tilesPerRow;
+            uint32_t ty = tile / tilesPerRow;
+            if (args.bandStride) {
+                /* tile rows of this launch -> tile rows of the frame (bands are whole groups of 8 rows here) */
+                const uint32_t tileRowsPerBand = args.bandPixels / (args.width << 3);
+                ty = (args.bandFirst + (ty / tileRowsPerBand) * args.bandStride) * tileRowsPerBand + ty % tileRowsPerBand;
+            }
+            pixel = args.blockStart + ((ty << 3) + (lane >> 3)) * args.width + (tx << 3) + (lane & 7u);
+        } else if (args.bandStride) {
+            pixel = (args.bandFirst + (gid / args.bandPixels) * args.bandStride) * args.bandPixels + gid % args.bandPixels;
+        } else {
+            pixel = args.blockStart + gid;
         }
-        pixel = args.blockStart + ((ty << 3) + (lane >> 3)) * args.width + (tx << 3) + (lane & 7u);
-    } else if (args.bandStride) {
-        pixel = (args.bandFirst + (gid / args.bandPixels) * args.bandStride) * args.bandPixels + gid % args.bandPixels;
-    } else {
-        pixel = args.blockStart + gid;
-    }
-    if (args.bandStride && pixel >= args.width * args.height)
-        inBlock = false; /* the last band may be shorter */
-    if (!inBlock)
-        pixel = args.blockStart;
+        if (args.bandStride && pixel >= args.width * args.height)
+            inBlock = false; /* the last band may be shorter */
+        if (!inBlock)
+            pixel = args.blockStart;
+        return inBlock;
+    };
+    uint32_t pixel;
+    const bool inBlock = pixelOf(blockIdx.x * WG + threadIdx.x, pixel);
     FrameArgs fa;
     fa.cam = args.cam;
     fa.par = args.par;
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     /* wave-level scheduler statistics (COUNT builds): rounds and lane counts per state */
     unsigned long long sched[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int state = inBlock ? S_NEW : S_DONE;
+    bool poolDry = false; /* wave-uniform */
     RayAux aux = rayAux(ps.d);
     uint32_t node = 0, leafPrim = 0;
     float amax = k_maxval;
@@ -362,22 +371,46 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 sched[9]++;
                 sched[10] += __popcll(__ballot(state == S_NEW));
             }
-            if (state == S_NEW) /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
-                afterBlock(blockNew<F>(fa, ps, &sv));
+            if (state == S_NEW) { /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
+                const int next = blockNew<F>(fa, ps, &sv);
+                if (next == NEXT_DONE) {
+                    /* SensorRGB::finishPixel (sensor_rgb.hpp:82-87) */
+                    const Slot acc = ps.get(SLOT_ACC);
+                    const uint32_t pxy = ps.getW(SLOT_SRDIR);
+                    float* out = args.frame + 3 * ((size_t)(pxy >> 16) * args.width + (pxy & 0xffffu));
+                    out[0] = args.invSamples * acc.x;
+                    out[1] = args.invSamples * acc.y;
+                    out[2] = args.invSamples * acc.z;
+                }
+                afterBlock(next);
+            }
+            if (!COUNT && args.pool && !poolDry) {
+                /* idle lanes take the next pixels of the launch: one atomic per wave */
+                const unsigned long long idle = __ballot(state == S_DONE);
+                if (idle != 0) {
+                    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    const uint32_t want = (uint32_t)__popcll(idle);
+                    const int leader = __ffsll((long long)idle) - 1;
+                    uint32_t first = 0;
+                    if ((int)lane == leader)
+                        first = atomicAdd(args.pool, want);
+                    first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+                    poolDry = first + want >= args.blockSize; /* the counter only grows: nothing behind it for this wave */
+                    if (state == S_DONE) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                        uint32_t nextPixel;
+                        if (pixelOf(first + rank, nextPixel)) {
+                            pathStateInit(ps, nextPixel, nextPixel % args.width, nextPixel / args.width);
+                            state = S_NEW;
+                        }
+                    }
+                }
+            }
             if (COUNT) /* shader clock spent per kind of block: [11] traversal [12] shade [13] nee-end [14] new */
                 sched[14] += (unsigned long long)(clock64() - tBlock);
         }
     }
 
-    if (inBlock) {
-        /* SensorRGB::finishPixel (sensor_rgb.hpp:82-87) */
-        const Slot acc = ps.get(SLOT_ACC);
-        const uint32_t pxy = ps.getW(SLOT_SRDIR);
-        float* out = args.frame + 3 * ((size_t)(pxy >> 16) * args.width + (pxy & 0xffffu));
-        out[0] = args.invSamples * acc.x;
-        out[1] = args.invSamples * acc.y;
-        out[2] = args.invSamples * acc.z;
-    }
     if (COUNT && args.counters && inBlock) {
         atomicAdd((unsigned long long*)&args.counters->samples, (unsigned long long)args.samplesSqrt * args.samplesSqrt);
         atomicAdd((unsigned long long*)&args.counters->rays, (unsigned long long)lc.rays);
@@ -394,6 +427,26 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         for (int i = 0; i < 8; i++)
             atomicAdd(args.schedStats + 16 + i, lc.shadeClock[i]);
     }
+}
+
+/* Launch of a product kernel.  With a pixel pool in the arguments and more workgroups than the device holds at once, the
+ * launch shrinks to the resident workgroups and the counter starts behind their lanes; otherwise the pool stays unused. */
+template<class Kernel>
+inline void launchMaybePooled(Kernel kernel, const KernelArgs& args, dim3 grid, size_t ldsBytes, hipStream_t stream)
+{
+    KernelArgs a = args;
+    if (a.pool) {
+        int perCu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, (int)WG, ldsBytes) != hipSuccess)
+            perCu = 0;
+        const uint64_t resident = (uint64_t)(perCu < 0 ? 0 : perCu) * a.cuCount;
+        if (resident == 0 || grid.x <= resident
+                || hipMemsetD32Async((hipDeviceptr_t)a.pool, (int)(resident * WG), 1, stream) != hipSuccess)
+            a.pool = nullptr;
+        else
+            grid.x = (uint32_t)resident;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(WG), ldsBytes, stream, a);
 }
 
 constexpr uint32_t FEAT_BASIC = FEAT_GGX | FEAT_GLASS;
