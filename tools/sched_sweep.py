@@ -38,8 +38,8 @@ print("default: %.1f Msamples/s" % base, flush=True)
 results = []
 leaves = (1, 2, 3) if what == "cornell" else (2, 3, 4)
 for leave in leaves:
-    for heavy in (6, 8, 12, 16, 20, 24, 32):
-        for bias in (8, 12, 16, 24, 32, 48):
+    for heavy in ((6, 8, 12, 16, 20, 24, 32) if what == "cornell" else (4, 8, 12, 16, 24)):
+        for bias in ((8, 12, 16, 24, 32, 48) if what == "cornell" else (16, 32, 48)):
             word = low | ((leave + 1) << 8) | ((heavy + 1) << 16) | (bias << 24)
             r = run(word)
             results.append((r, leave, heavy, bias))
