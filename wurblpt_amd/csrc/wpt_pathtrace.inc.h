@@ -102,7 +102,10 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
      * Msamples/s on the Cornell frame (2: 839, 4: 841, 6: 836, 8: 791: lanes that reach a leaf wait out the rest); from
      * HBM the steps are memory round trips and nothing is gained (Sponza-class 118.7 - 121.0 against 120.4, 10 M
      * triangles 53 - 55 against 56.5 for 2 - 4 steps). */
-    constexpr int STEPS = LDSSCENE ? 3 : 1;
+#ifndef WPT_LDS_STEPS
+#define WPT_LDS_STEPS 3 /* experiments build other values into a second library (Makefile: EXTRA) */
+#endif
+    constexpr int STEPS = LDSSCENE ? WPT_LDS_STEPS : 1;
     /* [ math tables ][ cold path words: SLOT_COUNT x WG float4 ][ LDSSCENE: nodes, triangle positions ] */
     extern __shared__ float4 lds[];
     float4* const ldsCold = lds + TABLE_BYTES / 16;
