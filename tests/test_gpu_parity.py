@@ -948,6 +948,30 @@ def test_pixel_pool_never_changes_results(dev, oracle):
             ds.check()
         finally:
             dev.lib().wpt_set_launch_config(0, 0)
+    # Kernels that fetch the scene from HBM render such a frame in two passes (variant bit 0x40: never): one row of
+    # strata of every pixel, timed; then the rest, the tiles that took longest first.  A pixel's samples stay one sequence.
+    s = 8
+    frames = {}
+    for variant in (0x10, 0x00, 0x01, 0x02, 0x41, 0x22):
+        dev.lib().wpt_set_launch_config(0, variant)
+        try:
+            ds = dev.DeviceScene(sc)
+            frames[variant], _ = ds.render(s)
+            if variant == 0x02:
+                frame = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+                for band_rows in (8, 5):
+                    total = np.zeros_like(ref)
+                    for rank in range(2):
+                        frame.zero_()
+                        ds.render_bands_into(frame, s, band_rows, rank, 2, stream=torch.cuda.current_stream())
+                        torch.cuda.synchronize()
+                        total += frame.cpu().numpy()
+                    frames["bands of %d rows" % band_rows] = total
+            ds.check()
+        finally:
+            dev.lib().wpt_set_launch_config(0, 0)
+    for key, got in frames.items():
+        assert bits_equal(got, frames[0x10]), key
 
 
 def test_fuzz_parity_over_seeded_random_scenes():

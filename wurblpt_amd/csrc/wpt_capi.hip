@@ -748,38 +748,83 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     }
     args.pool = pool;
     args.cuCount = uint32_t(scene->cuCount);
-    if (anim) {
-        /* its own instantiation, like the measured BRDFs */
-        if (need & FEAT_RGL) {
-            if (count)
-                launchFullRglAnimCount(args, grid, stream);
-            else
-                launchFullRglAnim(args, grid, stream);
+    args.rowStop = samples_sqrt;
+    args.carry = nullptr;
+    args.cost = nullptr;
+    args.order = nullptr;
+    args.orderCount = nullptr;
+    auto launch = [&](const wptk::KernelArgs& a) {
+        if (anim) {
+            /* its own instantiation, like the measured BRDFs */
+            if (need & FEAT_RGL) {
+                if (count)
+                    launchFullRglAnimCount(a, grid, stream);
+                else
+                    launchFullRglAnim(a, grid, stream);
+            } else if (count) {
+                launchFullAnimCount(a, grid, stream);
+            } else {
+                launchFullAnim(a, grid, stream);
+            }
         } else if (count) {
-            launchFullAnimCount(args, grid, stream);
+            if (basic)
+                launchBasicCount(a, grid, stream);
+            else if (rgl)
+                launchFullRglCount(a, grid, stream);
+            else
+                launchFullCount(a, grid, stream);
+        } else if (rgl) {
+            launchFullRgl(a, grid, stream);
         } else {
-            launchFullAnim(args, grid, stream);
+            if (basic && lds)
+                launchBasicLds(a, grid, ldsBytes, stream);
+            else if (basic)
+                launchBasic(a, grid, stream);
+            else
+                launchFull(a, grid, stream);
         }
-    } else if (count) {
-        if (basic)
-            launchBasicCount(args, grid, stream);
-        else if (rgl)
-            launchFullRglCount(args, grid, stream);
-        else
-            launchFullCount(args, grid, stream);
-    } else if (rgl) {
-        launchFullRgl(args, grid, stream);
-    } else {
-        if (basic && lds)
-            launchBasicLds(args, grid, ldsBytes, stream);
-        else if (basic)
-            launchBasic(args, grid, stream);
-        else
-            launchFull(args, grid, stream);
+    };
+    /* Two passes for the kernels that fetch the scene from HBM (variant bit 0x40: never): with 2 to 64 pixels per lane the
+     * end of a launch, when lanes run out of pixels one by one, is a noticeable part of it.  The first pass renders one row
+     * of strata of every pixel and times it, the second renders the rest, the 8x8 tiles that took longest first
+     * (Sponza-class frame +2.9 %, 10 M triangles +1.8 %).  Not for the scene in LDS: there the launch is bound by how well
+     * a wave's lanes keep in step, any order but the frame's own costs that more than the shorter end gives (Cornell
+     * 938 against 954). */
+    const uint64_t lanesAtOnce = uint64_t(scene->cuCount) * 4u * WG;
+    const bool sceneInLds = basic && lds && !anim && !rgl;
+    const bool twoPasses = pool != nullptr && !(g_variant & 0x40u) && !sceneInLds && samples_sqrt >= 8
+            && uint64_t(block_size) >= 2u * lanesAtOnce && uint64_t(block_size) <= 64u * lanesAtOnce;
+    float4* carry = nullptr;
+    uint32_t *cost = nullptr, *order = nullptr, *work = nullptr;
+    bool passesDone = false;
+    if (twoPasses) {
+        const size_t pixels = size_t(width) * height;
+        if (hipMallocAsync(reinterpret_cast<void**>(&carry), pixels * 2 * sizeof(float4), stream) == hipSuccess
+                && hipMallocAsync(reinterpret_cast<void**>(&cost), pixels * sizeof(uint32_t), stream) == hipSuccess
+                && hipMallocAsync(reinterpret_cast<void**>(&order), size_t(block_size) * sizeof(uint32_t), stream) == hipSuccess
+                && hipMallocAsync(reinterpret_cast<void**>(&work), (3 * wptk::ORDER_BUCKETS + 1) * sizeof(uint32_t), stream) == hipSuccess) {
+            wptk::KernelArgs first = args;
+            first.rowStop = 1;
+            first.carry = carry;
+            first.cost = cost;
+            launch(first);
+            wptk::launchOrderBuild(first, order, work, stream);
+            wptk::KernelArgs second = args;
+            second.carry = carry;
+            second.order = order;
+            second.orderCount = work + 3 * wptk::ORDER_BUCKETS;
+            launch(second);
+            passesDone = true;
+        } else {
+            (void)hipGetLastError();
+        }
     }
+    if (!passesDone)
+        launch(args);
     const hipError_t launched = hipGetLastError();
-    if (pool)
-        (void)hipFreeAsync(pool, stream);
+    for (void* p : { static_cast<void*>(pool), static_cast<void*>(carry), static_cast<void*>(cost), static_cast<void*>(order), static_cast<void*>(work) })
+        if (p)
+            (void)hipFreeAsync(p, stream);
     HIP_TRY(launched);
     return WPT_OK;
 }

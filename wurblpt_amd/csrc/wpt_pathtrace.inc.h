@@ -81,11 +81,47 @@ struct KernelArgs {
      * starts at the number of lanes launched.  A launch then is as many workgroups as the GPU holds at once, and a wave
      * keeps its 64 lanes at work until the launch runs out of pixels instead of until its slowest pixel ends. */
     uint32_t* pool;
+    /* Two passes over a frame (or NULL / 0): the first renders rowStop rows of every pixel's strata, stores what the pixel
+     * carries on (generator, sum, next stratum) and the time it took; the second takes the pixels in `order` (the tiles
+     * that took longest first, wpt_k_order.hip: the pixels that end the launch are the short ones) and goes on where the
+     * first stopped.  A pixel's samples stay one sequence from one generator, so the frame is the same bit for bit. */
+    uint32_t rowStop;             /* rows of strata to render in this launch; samplesSqrt: to the end */
+    float4* carry;                /* per pixel of the frame: prng slot, acc slot */
+    uint32_t* cost;               /* per pixel of the frame: shader clock of the first pass */
+    const uint32_t* order;        /* second pass: pixels in the order they are handed out */
+    const uint32_t* orderCount;   /* second pass: entries of `order` */
     uint32_t cuCount; /* for the launchers: compute units of the device */
     wpt_counters* counters;
     unsigned long long* schedStats; /* COUNT builds: 16 scheduler statistics, or NULL */
     uint32_t* status;               /* set to 1 by a launch that had to abort (bounded waits) */
 };
+
+/* lane index of the launch -> pixel; false: no pixel behind this index */
+WPT_D bool lanePixel(const KernelArgs& args, uint32_t gid, uint32_t& pixel)
+{
+    bool inBlock = gid < args.blockSize;
+    if (args.tiled) {
+        const uint32_t tilesPerRow = args.width >> 3;
+        const uint32_t tile = gid >> 6, lane = gid & 63u;
+        const uint32_t tx = tile % tilesPerRow;
+        uint32_t ty = tile / tilesPerRow;
+        if (args.bandStride) {
+            /* tile rows of this launch -> tile rows of the frame (bands are whole groups of 8 rows here) */
+            const uint32_t tileRowsPerBand = args.bandPixels / (args.width << 3);
+            ty = (args.bandFirst + (ty / tileRowsPerBand) * args.bandStride) * tileRowsPerBand + ty % tileRowsPerBand;
+        }
+        pixel = args.blockStart + ((ty << 3) + (lane >> 3)) * args.width + (tx << 3) + (lane & 7u);
+    } else if (args.bandStride) {
+        pixel = (args.bandFirst + (gid / args.bandPixels) * args.bandStride) * args.bandPixels + gid % args.bandPixels;
+    } else {
+        pixel = args.blockStart + gid;
+    }
+    if (args.bandStride && pixel >= args.width * args.height)
+        inBlock = false; /* the last band may be shorter */
+    if (!inBlock)
+        pixel = args.blockStart;
+    return inBlock;
+}
 
 /* lane states, in scheduling priority order for ties */
 enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5 };
@@ -140,33 +176,9 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             return sv.triGeom[i];
     };
 
-    /* lane index of the launch -> pixel; false: no pixel behind this index */
-    auto pixelOf = [&](uint32_t gid, uint32_t& pixel) -> bool {
-        bool inBlock = gid < args.blockSize;
-        if (args.tiled) {
-            const uint32_t tilesPerRow = args.width >> 3;
-            const uint32_t tile = gid >> 6, lane = gid & 63u;
-            const uint32_t tx = tile % tilesPerRow;
-            uint32_t ty = tile / tilesPerRow;
-            if (args.bandStride) {
-                /* tile rows of this launch -> tile rows of the frame (bands are whole groups of 8 rows here) */
-                const uint32_t tileRowsPerBand = args.bandPixels / (args.width << 3);
-                ty = (args.bandFirst + (ty / tileRowsPerBand) * args.bandStride) * tileRowsPerBand + ty % tileRowsPerBand;
-            }
-            pixel = args.blockStart + ((ty << 3) + (lane >> 3)) * args.width + (tx << 3) + (lane & 7u);
-        } else if (args.bandStride) {
-            pixel = (args.bandFirst + (gid / args.bandPixels) * args.bandStride) * args.bandPixels + gid % args.bandPixels;
-        } else {
-            pixel = args.blockStart + gid;
-        }
-        if (args.bandStride && pixel >= args.width * args.height)
-            inBlock = false; /* the last band may be shorter */
-        if (!inBlock)
-            pixel = args.blockStart;
-        return inBlock;
-    };
-    uint32_t pixel;
-    const bool inBlock = pixelOf(blockIdx.x * WG + threadIdx.x, pixel);
+    auto pixelOf = [&](uint32_t gid, uint32_t& pixel) -> bool { return lanePixel(args, gid, pixel); };
+    const bool firstPass = args.rowStop < args.samplesSqrt;
+    const uint32_t laneLimit = args.order ? *args.orderCount : args.blockSize; /* indices a lane may take */
     FrameArgs fa;
     fa.cam = args.cam;
     fa.par = args.par;
@@ -180,7 +192,28 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     /* ---- per-lane state: the pixel's path (wpt_blocks.h; its cold words in LDS) and the traversal registers ---- */
     PathLds<WG> ps;
     ps.base = ldsCold + threadIdx.x;
-    pathStateInit(ps, pixel, pixel % args.width, pixel / args.width);
+    /* the lane takes the pixel behind index `at` of the launch; false: there is none */
+    auto startPixel = [&](uint32_t at) -> bool {
+        uint32_t pixel = args.blockStart;
+        bool have;
+        if (args.order) {
+            have = at < laneLimit;
+            if (have)
+                pixel = args.order[at];
+        } else {
+            have = pixelOf(at, pixel);
+        }
+        pathStateInit(ps, pixel, pixel % args.width, pixel / args.width);
+        if (have && args.order) {
+            /* where the first pass stopped */
+            ps.base[SLOT_PRNG * WG] = args.carry[2 * (size_t)pixel];
+            ps.base[SLOT_ACC * WG] = args.carry[2 * (size_t)pixel + 1];
+        }
+        if (have && firstPass)
+            args.cost[pixel] = (uint32_t)clock64();
+        return have;
+    };
+    const bool inBlock = startPixel(blockIdx.x * WG + threadIdx.x);
     LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
     /* wave-level scheduler statistics (COUNT builds): rounds and lane counts per state */
     unsigned long long sched[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -375,15 +408,23 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 sched[10] += __popcll(__ballot(state == S_NEW));
             }
             if (state == S_NEW) { /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
-                const int next = blockNew<F>(fa, ps, &sv);
+                const bool passEnds = firstPass && (ps.getW(SLOT_ACC) >> 16) >= args.rowStop;
+                const int next = passEnds ? (int)NEXT_DONE : blockNew<F>(fa, ps, &sv);
                 if (next == NEXT_DONE) {
-                    /* SensorRGB::finishPixel (sensor_rgb.hpp:82-87) */
-                    const Slot acc = ps.get(SLOT_ACC);
                     const uint32_t pxy = ps.getW(SLOT_SRDIR);
-                    float* out = args.frame + 3 * ((size_t)(pxy >> 16) * args.width + (pxy & 0xffffu));
-                    out[0] = args.invSamples * acc.x;
-                    out[1] = args.invSamples * acc.y;
-                    out[2] = args.invSamples * acc.z;
+                    const size_t at = (size_t)(pxy >> 16) * args.width + (pxy & 0xffffu);
+                    if (firstPass) {
+                        args.carry[2 * at] = ps.base[SLOT_PRNG * WG];
+                        args.carry[2 * at + 1] = ps.base[SLOT_ACC * WG];
+                        args.cost[at] = (uint32_t)clock64() - args.cost[at];
+                    } else {
+                        /* SensorRGB::finishPixel (sensor_rgb.hpp:82-87) */
+                        const Slot acc = ps.get(SLOT_ACC);
+                        float* out = args.frame + 3 * at;
+                        out[0] = args.invSamples * acc.x;
+                        out[1] = args.invSamples * acc.y;
+                        out[2] = args.invSamples * acc.z;
+                    }
                 }
                 afterBlock(next);
             }
@@ -398,14 +439,11 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                     if ((int)lane == leader)
                         first = atomicAdd(args.pool, want);
                     first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
-                    poolDry = first + want >= args.blockSize; /* the counter only grows: nothing behind it for this wave */
+                    poolDry = first + want >= laneLimit; /* the counter only grows: nothing behind it for this wave */
                     if (state == S_DONE) {
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                        uint32_t nextPixel;
-                        if (pixelOf(first + rank, nextPixel)) {
-                            pathStateInit(ps, nextPixel, nextPixel % args.width, nextPixel / args.width);
+                        if (startPixel(first + rank))
                             state = S_NEW;
-                        }
                     }
                 }
             }
@@ -468,6 +506,10 @@ void launchGroundTruth(const GroundTruthArgs& args, hipStream_t stream);
 
 /* one launcher per instantiation, each defined in its own translation unit; sceneLdsBytes is the size of the scene
  * copy behind the cold path words in LDS (0 for the kernels that fetch the scene from HBM) */
+/* wpt_k_order.hip: from the first pass's times to the second pass's order of pixels, longest first.  `work` is
+ * 3 * ORDER_BUCKETS + 1 words of device memory; work[3 * ORDER_BUCKETS] receives the number of pixels in `order`. */
+constexpr uint32_t ORDER_BUCKETS = 128;
+void launchOrderBuild(const KernelArgs& args, uint32_t* order, uint32_t* work, hipStream_t stream);
 void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
