@@ -298,7 +298,8 @@ def main():
         avg_ms = sum(m for m, _ in launches) / max(1, len(launches))
         avg_samples = sum(s for _, s in launches) / max(1, len(launches))
         achieved = bps * avg_samples / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-        basis = "algorithmic bytes of one launch / its duration (HIP events on the launch's stream)"
+        basis = ("algorithmic bytes of one launch / its duration (HIP events on the launch's stream); a launch is one render call: "
+                 "kernel_launches_per_launch launches of the kernel, whose durations add up to it")
         if sharded and launches and (args.dynamic_blocks or world == 1):
             # this rank's launches overlap on its streams: price its whole share against the timed region instead
             achieved = bps * sum(s for _, s in launches) / elapsed / 1e9
@@ -319,7 +320,7 @@ def main():
         counted = "%dx%d x %d spp" % (width, height, count_sqrt ** 2)
         per_sample = {k: cnt[k] / float(cnt["samples"]) for k in ("rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")}
         common = {"traffic": traffic, "basis": basis, "kernel": device.lib().wpt_kernel_name().decode(), "avg_launch_ms": avg_ms,
-                  "launches": len(launches), "bytes_per_sample": bps, "algorithmic_gbps": achieved, "per_sample": per_sample, "counted_on": counted}
+                  "launches": len(launches), "kernel_launches_per_launch": int(device.lib().wpt_last_render_passes()), "bytes_per_sample": bps, "algorithmic_gbps": achieved, "per_sample": per_sample, "counted_on": counted}
         if in_lds and pmc.get("valu_insts_per_sample") and launches:
             # the scene is LDS resident: what binds is vector issue.  Executed lane-operations = wave instructions x 64 lanes x
             # the fraction of lanes active in them (both from the committed PMC pass of this workload), at the live sample rate

@@ -446,6 +446,10 @@ const char* wpt_kernel_name(void);
  * marketing name and architecture of HIP device `device` ("AMD Instinct MI355X (gfx950:...)", or "" if there is none), and
  * the compiler and options the kernels were built with.  The strings live until the next call from the same thread. */
 const char* wpt_device_name(int device);
+/* Launches of the path tracing kernel the last render call of this process took for its pixels: 1, or 2 when the frame
+ * was rendered in two passes (timed first row of strata, then the rest with the longest tiles first). Profilers see
+ * that many kernel launches per frame; what is rendered does not depend on it. */
+uint32_t wpt_last_render_passes(void);
 const char* wpt_build_info(void);
 
 const char* wpt_last_error(void);

@@ -19,8 +19,14 @@ WORK = {"c": ("cornell", "cornell_1024x1024_1024spp_ggx_glass"),
 SAMPLES = {"c": 1024 * 1024 * 1024, "s": 1920 * 1080 * 256, "y": 1920 * 1080 * 121}  # samples per launch of the product kernel
 
 
+RATIOS = ("Busy", "Utilization", "Occupancy", "Stalled", "_avr")   # averaged over a launch, not summed
+
+
 def counters(suffix):
-    agg = collections.defaultdict(list)
+    """(kernel, counter) -> (value per frame, frames, launches).  A frame may be several launches of one kernel (two
+    passes): summed counters add up over a frame's launches, averaged ones are weighted by the launches' durations; a
+    frame is counted for every launch that takes more than half of the longest."""
+    raw = collections.defaultdict(list)
     for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_*" % suffix, ""))):
         f = os.path.join(d, "pmc_counter_collection.csv")
         if not os.path.exists(f):
@@ -28,7 +34,16 @@ def counters(suffix):
         for r in csv.DictReader(open(f)):
             if "wpt_pathtrace" in r["Kernel_Name"]:
                 k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-                agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+                raw[(k, r["Counter_Name"])].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    agg = {}
+    for (k, c), rows in raw.items():
+        longest = max(t for _, t in rows)
+        frames = sum(1 for _, t in rows if 2 * t > longest)
+        if any(x in c for x in RATIOS):
+            value = sum(v * t for v, t in rows) / sum(t for _, t in rows)
+        else:
+            value = sum(v for v, _ in rows) / frames
+        agg[(k, c)] = (value, frames, len(rows))
     return agg
 
 
@@ -46,20 +61,20 @@ for letter, (short, workload) in WORK.items():
     if not agg:
         continue
     with open(os.path.join(OUT, "%s_pmc_%s.txt" % (prefix, short)), "w") as f:
-        f.write("# rocprofv3 --pmc passes (one counter group per run, tools/profile_round.sh) of\n# python3 bench.py --workload %s --no-cpu-baseline; mean over the launches of each kernel\n" % workload)
-        for (k, c), v in sorted(agg.items()):
-            f.write("%-58s %-30s launches=%d mean=%.6g\n" % (k, c, len(v), sum(v) / len(v)))
+        f.write("# rocprofv3 --pmc passes (one counter group per run, tools/profile_round.sh) of\n# python3 bench.py --workload %s --no-cpu-baseline; per frame: counters summed over a frame's launches (two passes = two\n# launches of one kernel), busy / utilisation / occupancy weighted by the launches' durations\n" % workload)
+        for (k, c), (v, frames, launches) in sorted(agg.items()):
+            f.write("%-58s %-30s frames=%d launches=%d per_frame=%.6g\n" % (k, c, frames, launches, v))
     prod = [k for (k, c) in agg if c == "FETCH_SIZE" and "u, true, " not in k]  # not the counting build
     if prod:
         k = prod[0]
-        fetch = sum(agg[(k, "FETCH_SIZE")]) / len(agg[(k, "FETCH_SIZE")])
-        write = sum(agg[(k, "WRITE_SIZE")]) / len(agg[(k, "WRITE_SIZE")]) if (k, "WRITE_SIZE") in agg else 0.0
+        fetch = agg[(k, "FETCH_SIZE")][0]
+        write = agg[(k, "WRITE_SIZE")][0] if (k, "WRITE_SIZE") in agg else 0.0
         traffic[workload] = {
-            "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
+            "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),  # per frame: all launches of a frame
             "fetch_size_kib": fetch, "write_size_kib": write, "kernel": k,
             "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_%s.txt); "
                    "FETCH_SIZE x 2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KiB -> bytes" % (prefix, short)}
-        mean = lambda c: sum(agg[(k, c)]) / len(agg[(k, c)]) if (k, c) in agg else None
+        mean = lambda c: agg[(k, c)][0] if (k, c) in agg else None
         if mean("SQ_INSTS_VALU") and mean("VALUUtilization") and letter in SAMPLES:
             traffic[workload].update({
                 "valu_insts_per_sample": mean("SQ_INSTS_VALU") / SAMPLES[letter],

@@ -155,6 +155,7 @@ uint32_t g_variant = 0;
 uint32_t g_leaveEighths = 0; /* 0 = default: chosen per scene size (single-role kernel) / patience 8 rounds (ray-pool kernel) */
 uint32_t g_heavyMin = 0; /* 0 = chosen per scene size at launch */
 uint32_t g_leafBias = 0;
+uint32_t g_lastPasses = 1; /* path tracing launches the last render call took for its pixels (wpt_last_render_passes) */
 uint32_t g_topNodes = 65536; /* nodes of a large tree that are stored level by level in front (wpt_set_top_nodes) */
 unsigned long long* g_schedStats = nullptr;
 
@@ -821,6 +822,7 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     }
     if (!passesDone)
         launch(args);
+    g_lastPasses = passesDone ? 2u : 1u;
     const hipError_t launched = hipGetLastError();
     for (void* p : { static_cast<void*>(pool), static_cast<void*>(carry), static_cast<void*>(cost), static_cast<void*>(order), static_cast<void*>(work) })
         if (p)
@@ -1132,6 +1134,11 @@ const char* wpt_device_name(int device)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         name = std::string(prop.name) + " (" + prop.gcnArchName + ", " + std::to_string(prop.multiProcessorCount) + " CUs)";
     return name.c_str();
+}
+
+uint32_t wpt_last_render_passes(void)
+{
+    return g_lastPasses;
 }
 
 const char* wpt_build_info(void)

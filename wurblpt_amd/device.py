@@ -19,7 +19,7 @@ def lib_path():
 EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_current_device", "wpt_scene_upload", "wpt_scene_free", "wpt_scene_check",
            "wpt_postproc_to_srgb", "wpt_postproc_max_luminance", "wpt_postproc_uniform_rational_quantization",
            "wpt_postproc_scale_luminance", "wpt_postproc_host", "wpt_ground_truth_device", "wpt_ground_truth", "wpt_render_bands_device", "wpt_render_bands",
-           "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_set_top_nodes", "wpt_kernel_name", "wpt_device_name", "wpt_build_info",
+           "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_set_top_nodes", "wpt_kernel_name", "wpt_device_name", "wpt_build_info", "wpt_last_render_passes",
            "wpt_last_error"]
 
 
@@ -41,6 +41,7 @@ def lib():
         L.wpt_device_name.restype = C.c_char_p
         L.wpt_device_name.argtypes = [C.c_int]
         L.wpt_build_info.restype = C.c_char_p
+        L.wpt_last_render_passes.restype = C.c_uint32
         L.wpt_select_device.argtypes = [C.c_int]
         L.wpt_scene_upload.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(C.c_void_p)]
         L.wpt_scene_free.argtypes = [C.c_void_p]
