@@ -951,20 +951,24 @@ def test_pixel_pool_never_changes_results(dev, oracle):
     # Kernels that fetch the scene from HBM render such a frame in two passes (variant bit 0x40: never): one row of
     # strata of every pixel, timed; then the rest, the tiles that took longest first.  A pixel's samples stay one sequence.
     s = 8
+    w, h = 1536, 1024               # a rank's half of it still is three pixels per lane
+    sc = host.cornell(w, h, 1, 2)
     frames = {}
     for variant in (0x10, 0x00, 0x01, 0x02, 0x41, 0x22):
         dev.lib().wpt_set_launch_config(0, variant)
         try:
             ds = dev.DeviceScene(sc)
             frames[variant], _ = ds.render(s)
+            assert dev.lib().wpt_last_render_passes() == (2 if variant in (0x01, 0x02, 0x22) else 1), hex(variant)
             if variant == 0x02:
                 frame = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
                 for band_rows in (8, 5):
-                    total = np.zeros_like(ref)
+                    total = np.zeros((h, w, 3), np.float32)
                     for rank in range(2):
                         frame.zero_()
                         ds.render_bands_into(frame, s, band_rows, rank, 2, stream=torch.cuda.current_stream())
                         torch.cuda.synchronize()
+                        assert dev.lib().wpt_last_render_passes() == 2
                         total += frame.cpu().numpy()
                     frames["bands of %d rows" % band_rows] = total
             ds.check()
