@@ -124,7 +124,7 @@ WPT_D bool lanePixel(const KernelArgs& args, uint32_t gid, uint32_t& pixel)
 }
 
 /* lane states, in scheduling priority order for ties */
-enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5 };
+enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5, S_START = 6 /* within a long round: has a ray to start */ };
 
 template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC>
 __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
@@ -239,9 +239,16 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     /* state after the walk has left the tree */
     auto endOfRayState = [&]() { return ps.rayKind == RAY_PATH ? (int)S_SHADE : (int)S_NEEEND; };
     /* what a block of wpt_blocks.h asks for next */
+    /* what a block of wpt_blocks.h asks for next.  Rays start together at the end of the long round: the reciprocals and
+     * the shear of a direction (three divisions and the axis choice, some sixty instructions) then run once for the
+     * SHADE, NEE-END and NEW lanes of the round, not once behind each of their blocks. */
     auto afterBlock = [&](int next) {
         if (next == NEXT_TRACE)
+#ifdef WPT_SEPARATE_STARTS /* experiments: every block starts its own rays */
             beginRay();
+#else
+            state = S_START;
+#endif
         else if (next != NEXT_WAIT) /* a waiting lane keeps its state and its hit */
             state = next == NEXT_NEW ? (int)S_NEW : (int)S_DONE;
     };
@@ -450,6 +457,8 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             if (COUNT) /* shader clock spent per kind of block: [11] traversal [12] shade [13] nee-end [14] new */
                 sched[14] += (unsigned long long)(clock64() - tBlock);
         }
+        if (pick != S_NODE && state == S_START)
+            beginRay();
     }
 
     if (COUNT && args.counters && inBlock) {
