@@ -193,20 +193,31 @@ template<class PS> WPT_D void pathStateInit(PS& ps, uint32_t pixel, uint32_t px,
     ps.animCached = -1;
 }
 
-/* HitableTriangle::pdfValue (hitable_triangle.hpp:405-423) for one hot spot */
-WPT_D float hotSpotPdfValue(float4 g0, float4 g1, float4 g2, f3 org, f3 dir, const RayAux& h)
+/* What HitableTriangle::pdfValue (hitable_triangle.hpp:405-423) derives from the corners alone: the unit face normal and
+ * the face area.  Evaluated once per hot spot at upload (wpt_capi.hip) with exactly these operations; a moving light's
+ * corners change, there they are evaluated per call. */
+WPT_D float4 hotSpotFace(f3 v0, f3 v1, f3 v2)
+{
+    f3 edgeCross = cross(sub(v1, v0), sub(v2, v0));
+    float edgeCrossLength = __builtin_sqrtf(dot(edgeCross, edgeCross));
+    f3 faceNormal = divs(edgeCross, edgeCrossLength);
+    float faceArea = 0.5f * edgeCrossLength;
+    return make_float4(faceNormal.x, faceNormal.y, faceNormal.z, faceArea);
+}
+
+/* HitableTriangle::pdfValue (hitable_triangle.hpp:405-423) for one hot spot; FACE: `face` holds hotSpotFace() of the corners */
+template<bool FACE>
+WPT_D float hotSpotPdfValue(float4 g0, float4 g1, float4 g2, f3 org, f3 dir, const RayAux& h, float4 face)
 {
     const f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
     Candidate c;
     float value = 0.0f;
     if (triangleTest(v0, v1, v2, org, h, 0.0f, k_maxval, c)) {
-        f3 edgeCross = cross(sub(v1, v0), sub(v2, v0));
-        float edgeCrossLength = __builtin_sqrtf(dot(edgeCross, edgeCross));
-        f3 faceNormal = divs(edgeCross, edgeCrossLength);
-        float faceArea = 0.5f * edgeCrossLength;
-        float cosine = __builtin_fabsf(dot(faceNormal, neg(dir)));
+        if (!FACE)
+            face = hotSpotFace(v0, v1, v2);
+        float cosine = __builtin_fabsf(dot(mk3(face.x, face.y, face.z), neg(dir)));
         float distance_squared = c.a * c.a;
-        value = distance_squared / (cosine * faceArea);
+        value = distance_squared / (cosine * face.w);
     }
     return value;
 }
@@ -279,9 +290,9 @@ WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, cons
             g0.x = v0.x; g0.y = v0.y; g0.z = v0.z;
             g1.x = v1.x; g1.y = v1.y; g1.z = v1.z;
             g2.x = v2.x; g2.y = v2.y; g2.z = v2.z;
-            sum += hotSpotPdfValue(g0, g1, g2, org, dir, h);
+            sum += hotSpotPdfValue<false>(g0, g1, g2, org, dir, h, g0);
         } else
-            sum += hotSpotPdfValue(tri4(3 * p), tri4(3 * p + 1), tri4(3 * p + 2), org, dir, h);
+            sum += hotSpotPdfValue<true>(tri4(3 * p), tri4(3 * p + 1), tri4(3 * p + 2), org, dir, h, sv.hotspotFace[i]);
         if (COUNT)
             lc.pdfs++;
     }

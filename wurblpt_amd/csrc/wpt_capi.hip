@@ -73,6 +73,22 @@ __global__ void wpt_env_importance_kernel(SceneView sv, int N, float* importance
     importance[i] = L.x + L.y + L.z + L.w;
 }
 
+/* per triangle hot spot: what its pdf needs of the corners alone (wpt_blocks.h hotSpotFace; the corners are the world-space
+ * positions the walk tests, tri_geom) */
+__global__ void wpt_hotspot_face_kernel(SceneView sv, float4* face)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sv.hotspotCount)
+        return;
+    float4 f = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (sv.hotspots[i].kind != WPT_HOTSPOT_SPHERE) {
+        const uint32_t p = sv.hotspots[i].prim;
+        const float4 g0 = sv.triGeom[3 * p], g1 = sv.triGeom[3 * p + 1], g2 = sv.triGeom[3 * p + 2];
+        f = wptk::hotSpotFace(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z));
+    }
+    face[i] = f;
+}
+
 /* decodes one image texture into the RGBA float4 pool (see imageTexelDecode) */
 __global__ void wpt_expand_texels_kernel(const uint8_t* pool, const wpt_texture t, float4* out)
 {
@@ -568,6 +584,20 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     s->view.nodeCount = desc->node_count;
     s->view.triCount = desc->tri_count;
     s->view.hotspotCount = desc->hotspot_count;
+    if (desc->hotspot_count > 0) {
+        float4* face = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&face), size_t(desc->hotspot_count) * sizeof(float4));
+        if (e == hipSuccess) {
+            s->allocations.push_back(face);
+            hipLaunchKernelGGL(wpt_hotspot_face_kernel, dim3((desc->hotspot_count + 255) / 256), dim3(256), 0, 0, s->view, face);
+            e = hipDeviceSynchronize();
+        }
+        if (e != hipSuccess) {
+            wpt_scene_free(s);
+            return fail(e == hipErrorOutOfMemory ? WPT_ERR_OUT_OF_MEMORY : WPT_ERR_HIP, std::string("hot spot faces: ") + hipGetErrorString(e));
+        }
+        s->view.hotspotFace = face;
+    }
     s->view.envType = desc->envmap.type;
     s->view.envCompat = desc->envmap.compat;
     s->view.envTex = desc->envmap.tex;
