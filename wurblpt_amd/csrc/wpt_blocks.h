@@ -296,7 +296,7 @@ WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, cons
         if (COUNT)
             lc.pdfs++;
     }
-    sum *= 1.0f / (float)sv.hotspotCount;
+    sum *= here(sv.invHotspotCount); /* 1.0f / (float)sv.hotspotCount */
     return sum;
 }
 

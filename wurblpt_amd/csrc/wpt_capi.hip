@@ -584,6 +584,7 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     s->view.nodeCount = desc->node_count;
     s->view.triCount = desc->tri_count;
     s->view.hotspotCount = desc->hotspot_count;
+    s->view.invHotspotCount = desc->hotspot_count ? 1.0f / float(desc->hotspot_count) : 0.0f;
     if (desc->hotspot_count > 0) {
         float4* face = nullptr;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&face), size_t(desc->hotspot_count) * sizeof(float4));

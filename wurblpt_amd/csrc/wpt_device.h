@@ -444,6 +444,7 @@ struct SceneView {
     const wpt_texture* textures;
     const float4* texels4; /* decoded RGBA texels of all image textures */
     const wpt_hotspot* hotspots;
+    float invHotspotCount;     /* 1.0f / (float)hotspotCount, divided once on the host (IEEE, the same bits) */
     const float4* hotspotFace; /* per triangle hot spot: unit face normal, face area (wpt_hotspot_face_kernel, at upload) */
     const wpt_sphere* spheres;
     const wpt_rgl_brdf* rglBrdfs; /* measured BRDFs and the pool their tables live in */
