@@ -1,5 +1,5 @@
 #!/bin/bash
-# face normal and area of the light triangles evaluated once at upload instead of in every pdf evaluation
+# one division instead of three for the pdf evaluations of the lights
 set -o pipefail
 O=gpurun_out/r02ap
 mkdir -p $O

@@ -511,7 +511,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
     }
     if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
         /* light sampling with MIS (wurblpt.hpp:179-220) */
-        const float hotSpotsPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, sr.dir, rayAux(sr.dir), ps, lc);
+        const float hotSpotsPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, sr.dir, rayAux<true>(sr.dir), ps, lc);
         nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
         section(3);
         uint32_t idx = (uint32_t)(in01(prng) * (float)sv.hotspotCount);
@@ -535,7 +535,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
             directDir = normalize(sub(p, h.p));
         }
         section(4);
-        const float directPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, directDir, rayAux(directDir), ps, lc);
+        const float directPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, directDir, rayAux<true>(directDir), ps, lc);
         section(5);
         if (directPdf > 0.0f) {
             float dpdf;

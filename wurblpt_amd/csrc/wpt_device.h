@@ -283,10 +283,13 @@ struct RayAux {
 WPT_D int auxKx(const RayAux& h) { return h.k & 3; }
 WPT_D int auxKy(const RayAux& h) { return (h.k >> 2) & 3; }
 WPT_D int auxKz(const RayAux& h) { return (h.k >> 4) & 3; }
-WPT_D RayAux rayAux(f3 dir)
+/* SHEAR_ONLY: for triangle tests alone (the pdf of a light), which read the reciprocal of the direction's largest
+ * component and nothing else of `inv`: that one division instead of three, the same bits */
+template<bool SHEAR_ONLY = false> WPT_D RayAux rayAux(f3 dir)
 {
     RayAux h;
-    h.inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    if (!SHEAR_ONLY)
+        h.inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     float ax = __builtin_fabsf(dir.x), ay = __builtin_fabsf(dir.y), az = __builtin_fabsf(dir.z);
     int kx, ky, kz;
     if (az >= ay && az >= ax)
@@ -306,7 +309,13 @@ WPT_D RayAux rayAux(f3 dir)
         kx = ky;
         ky = tmp;
     }
-    float invz = comp(h.inv, kz);
+    float invz;
+    if (SHEAR_ONLY) {
+        invz = 1.0f / comp(dir, kz);
+        h.inv = mk3(invz, invz, invz);
+    } else {
+        invz = comp(h.inv, kz);
+    }
     h.Sx = comp(dir, kx) * invz;
     h.Sy = comp(dir, ky) * invz;
     h.k = kx | (ky << 2) | (kz << 4);
