@@ -266,20 +266,27 @@ WPT_CALL DirectionDraw sphereDirection(const wpt_sphere& sp, f3 org, Prng prng)
     return r;
 }
 
-/* mean pdf over all hot spots of hitting them from org along dir (wurblpt.hpp:181-184); `h` = rayAux(dir) */
+/* Mean pdf over all hot spots of hitting them from org, for two directions at once: the scattered direction and the
+ * direction towards the sampled light (wurblpt.hpp:181-184 and :196-199).  Every light's corners are fetched once, and
+ * the two tests, which share nothing but them, run side by side; each direction's sum adds its terms in the order of the
+ * hot spots, as the reference's loop does. */
 template<uint32_t F, bool COUNT, class Tri4>
-WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, const RayAux& h, PathHot& ps, LaneCounters& lc)
+WPT_D void hotSpotsMeanPdfPair(const SceneView& sv, Tri4 tri4, f3 org, f3 dirA, f3 dirB, PathHot& ps, LaneCounters& lc, float& meanA, float& meanB)
 {
-    float sum = 0.0f;
+    const RayAux hA = rayAux<true>(dirA), hB = rayAux<true>(dirB);
+    float sumA = 0.0f, sumB = 0.0f;
     for (uint32_t i = 0; i < sv.hotspotCount; i++) {
         const uint32_t p = sv.hotspots[i].prim;
         if ((F & FEAT_SPHERES) && sv.hotspots[i].kind == WPT_HOTSPOT_SPHERE) {
             const wpt_sphere& sp = sv.spheres[p];
             if ((F & FEAT_ANIM) && sp.animation >= 0) {
                 const wptanim::Trs T = animationTrs(sv, ps, sp.animation);
-                sum += spherePdfValue(sphereMovedForPdf(sp, T), sphereMoved(sp, T), org, dir);
+                const wpt_sphere forPdf = sphereMovedForPdf(sp, T), moved = sphereMoved(sp, T);
+                sumA += spherePdfValue(forPdf, moved, org, dirA);
+                sumB += spherePdfValue(forPdf, moved, org, dirB);
             } else {
-                sum += spherePdfValue(sp, sp, org, dir);
+                sumA += spherePdfValue(sp, sp, org, dirA);
+                sumB += spherePdfValue(sp, sp, org, dirB);
             }
         } else if ((F & FEAT_ANIM) && sv.hotspots[i].animation >= 0) {
             /* the light moves: its corners at the path's time (hitable_triangle.hpp:209-218,405-423) */
@@ -290,14 +297,18 @@ WPT_D float hotSpotsMeanPdf(const SceneView& sv, Tri4 tri4, f3 org, f3 dir, cons
             g0.x = v0.x; g0.y = v0.y; g0.z = v0.z;
             g1.x = v1.x; g1.y = v1.y; g1.z = v1.z;
             g2.x = v2.x; g2.y = v2.y; g2.z = v2.z;
-            sum += hotSpotPdfValue<false>(g0, g1, g2, org, dir, h, g0);
-        } else
-            sum += hotSpotPdfValue<true>(tri4(3 * p), tri4(3 * p + 1), tri4(3 * p + 2), org, dir, h, sv.hotspotFace[i]);
+            sumA += hotSpotPdfValue<false>(g0, g1, g2, org, dirA, hA, g0);
+            sumB += hotSpotPdfValue<false>(g0, g1, g2, org, dirB, hB, g0);
+        } else {
+            const float4 g0 = tri4(3 * p), g1 = tri4(3 * p + 1), g2 = tri4(3 * p + 2), face = sv.hotspotFace[i];
+            sumA += hotSpotPdfValue<true>(g0, g1, g2, org, dirA, hA, face);
+            sumB += hotSpotPdfValue<true>(g0, g1, g2, org, dirB, hB, face);
+        }
         if (COUNT)
-            lc.pdfs++;
+            lc.pdfs += 2;
     }
-    sum *= here(sv.invHotspotCount); /* 1.0f / (float)sv.hotspotCount */
-    return sum;
+    meanA = sumA * here(sv.invHotspotCount);
+    meanB = sumB * here(sv.invHotspotCount);
 }
 
 /* SensorRGB::accumulateRadiance (sensor_rgb.hpp:63-80): read - add - write of the accumulator slot; a closed
@@ -510,10 +521,8 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
             nextAtt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
-        /* light sampling with MIS (wurblpt.hpp:179-220) */
-        const float hotSpotsPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, sr.dir, rayAux<true>(sr.dir), ps, lc);
-        nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
-        section(3);
+        /* light sampling with MIS (wurblpt.hpp:179-220).  The pdf of the scattered direction draws nothing from the
+         * generator, so it can wait for the direction towards the light and be evaluated together with that one's. */
         uint32_t idx = (uint32_t)(in01(prng) * (float)sv.hotspotCount);
         idx = idx < sv.hotspotCount - 1 ? idx : sv.hotspotCount - 1;
         const wpt_hotspot& hs = sv.hotspots[idx];
@@ -535,7 +544,9 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
             directDir = normalize(sub(p, h.p));
         }
         section(4);
-        const float directPdf = hotSpotsMeanPdf<F, COUNT>(sv, tri4, h.p, directDir, rayAux<true>(directDir), ps, lc);
+        float hotSpotsPdf, directPdf;
+        hotSpotsMeanPdfPair<F, COUNT>(sv, tri4, h.p, sr.dir, directDir, ps, lc, hotSpotsPdf, directPdf);
+        nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
         section(5);
         if (directPdf > 0.0f) {
             float dpdf;
