@@ -474,7 +474,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
     };
     if (COUNT)
         tSection = clock64();
-    Hit h = finishHit<F>(sv, best, ray.o, ray.d, ps.time);
+    Hit h = finishHit<F>(sv, best, ray.o, ray.d, ps.time, tri4);
     const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
     if ((F & ~(FEAT_GGX | FEAT_GLASS)) == 0 && waitBelow > 0) { /* the all-features builds have no register to spare for it */
         /* Each kind of material is its own stretch of code below, as long for one lane as for
@@ -605,14 +605,14 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
 
 /* the next-event ray's result (wurblpt.hpp:208-218: only the CHOSEN hot spot as nearest hit
  * counts; :240-250: the environment counts if nothing was hit), then the path continues */
-template<uint32_t F, class PS>
-WPT_D int blockNeeEnd(const SceneView& sv, const wpt_params& par, PS& ps, const Candidate& best)
+template<uint32_t F, class Tri4, class PS>
+WPT_D int blockNeeEnd(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& ps, const Candidate& best)
 {
     const Slot oplSlot = ps.get(SLOT_OPL);
     if (ps.rayKind == RAY_NEE_LIGHT) {
         const Slot nee = ps.get(SLOT_NEE);
         if (best.prim == nee.w) {
-            Hit lh = finishHit<F>(sv, best, ps.o, ps.d, ps.time);
+            Hit lh = finishHit<F>(sv, best, ps.o, ps.d, ps.time, tri4);
             const wpt_material& lm = resolveMaterial<F>(sv, lh.material, lh);
             f4 rad = mul(mk4(nee.x, nee.y, nee.z, 0.0f), materialEmitted<F>(sv, lm, lh));
             const f4 ri = ps.get4(SLOT_RI);

@@ -595,17 +595,22 @@ template<uint32_t F = 0> static __device__ __attribute__((noinline)) Hit finishS
 }
 
 /* Rebuilds the HitRecord of the surviving candidate (hitable_triangle.hpp:273-324). */
-template<uint32_t F = 0>
-WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir, float time = 0.0f)
+/* where the walk found the triangles' positions (LDS or HBM), the words behind them are fetched from as well */
+struct TriGeomFromScene {
+    const float4* triGeom;
+    WPT_D float4 operator()(uint32_t i) const { return triGeom[i]; }
+};
+template<uint32_t F = 0, class Tri4 = TriGeomFromScene>
+WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir, float time, Tri4 tri4)
 {
     if ((F & FEAT_SPHERES) && (c.prim & PRIM_SPHERE))
         return finishSphereHit<F>(sv, c, org, dir, time);
     Hit h;
     h.a = c.a;
     h.prim = c.prim;
-    const float4 g0 = sv.triGeom[3 * (size_t)c.prim + 0];
-    const float4 g1 = sv.triGeom[3 * (size_t)c.prim + 1];
-    const float4 g2 = sv.triGeom[3 * (size_t)c.prim + 2];
+    const float4 g0 = tri4(3 * c.prim + 0);
+    const float4 g1 = tri4(3 * c.prim + 1);
+    const float4 g2 = tri4(3 * c.prim + 2);
     const uint32_t instance = __float_as_uint(g0.w);
     h.material = __float_as_uint(g1.w);
     const uint32_t flags = __float_as_uint(g2.w);
@@ -654,6 +659,13 @@ WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir, flo
     h.t = tan;
     h.backside = backfacing;
     return h;
+}
+template<uint32_t F = 0>
+WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir, float time = 0.0f)
+{
+    TriGeomFromScene fromScene;
+    fromScene.triGeom = sv.triGeom;
+    return finishHit<F>(sv, c, org, dir, time, fromScene);
 }
 
 /* ---- textures (texture.hpp:160-246, texture_image.hpp:85-212, color.hpp:275-294) ---- */

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 sched[8] += cNee;
             }
             if (state == S_NEEEND) /* the next-event ray's contribution, then the path continues */
-                afterBlock(blockNeeEnd<F>(sv, par, ps, best));
+                afterBlock(blockNeeEnd<F>(sv, par, tri4, ps, best));
             if (COUNT)
                 sched[13] += (unsigned long long)(clock64() - tBlock);
         }
