@@ -422,7 +422,7 @@ wpt_status wpt_postproc_scale_luminance(const float* rgb_device, float* out_devi
 wpt_status wpt_postproc_host(int op, const float* rgb_host, void* out_host, uint64_t pixels, float a, float b);
 
 /* Kernel launch geometry knobs (0 = default); for benchmarking only, results do not change.
- * variant, byte 0: 0x01 scene from HBM even if it fits LDS, 0x02 all-features kernel, 0x20 separate SHADE / NEE-END / NEW rounds, 0x10 no pixel pool (every lane renders the one pixel it was launched for), 0x40 never two passes over a frame (timed first row of strata, then the rest with the longest tiles first; scenes fetched from HBM), bits 0x0c: a kind of material with few lanes in a long round stands back once (0 = fewer than 6 lanes, 0x04 = never, 0x08 = fewer than 3, 0x0c = fewer than 12; kernels without textures / spheres / environment only); byte 1: leave threshold of the traversal loop in eighths + 1; byte 2: lanes a long round needs + 1; byte 3:
+ * variant, byte 0: 0x01 scene from HBM even if it fits LDS, 0x02 all-features kernel, 0x20 separate SHADE / NEE-END / NEW rounds, 0x10 no pixel pool (every lane renders the one pixel it was launched for), 0x80 material records from HBM even where they fit into LDS next to the scene, 0x40 never two passes over a frame (timed first row of strata, then the rest with the longest tiles first; scenes fetched from HBM), bits 0x0c: a kind of material with few lanes in a long round stands back once (0 = fewer than 6 lanes, 0x04 = never, 0x08 = fewer than 3, 0x0c = fewer than 12; kernels without textures / spheres / environment only); byte 1: leave threshold of the traversal loop in eighths + 1; byte 2: lanes a long round needs + 1; byte 3:
  * leaf bias (DESIGN.md section 4 has what each was measured to do). */
 wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant);
 /* Storage order of the BVH nodes in HBM for scenes uploaded from now on: the first `nodes` nodes of a tree that is

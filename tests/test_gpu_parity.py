@@ -118,12 +118,12 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 0x20, 0x21, 0x22, 0x04, 0x08, 0x0c, 0x2d])
+@pytest.mark.parametrize("variant", [0, 1, 2, 0x20, 0x21, 0x22, 0x04, 0x08, 0x0c, 0x2d, 0x80])
 def test_kernel_variants_agree_bit_for_bit(dev, oracle, variant):
     """0 = scene in LDS, 1 = scene fetched from HBM/L2, 2 = the all-features kernel;
     +0x20 = separate SHADE / NEE-END / NEW rounds instead of the fused long round;
     bits 2-3: kinds of material with few lanes in a long round stand back once (0 = default, fewer
-    than 6 lanes; 0x04 = never; 0x08 / 0x0c = fewer than 3 / 12)"""
+    than 6 lanes; 0x04 = never; 0x08 / 0x0c = fewer than 3 / 12); 0x80 = material records from HBM, not LDS"""
     sc = host.cornell(64, 48, 1, 2)
     ref, _ = oracle.render(sc, 5)
     dev.lib().wpt_set_launch_config(0, variant)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the corners' normals / texture coordinates / tangents in LDS too (variant bit 0x80: not)
+# material records in LDS (variant bit 0x80: not)
 set -o pipefail
 O=gpurun_out/r02as
 mkdir -p $O

@@ -519,6 +519,7 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     s->view.triAttr = attr;
     UP(uploadArray(s, desc->instances, desc->instance_count, &s->view.instances));
     UP(uploadArray(s, desc->materials, desc->material_count, &s->view.materials));
+    s->view.materialCount = desc->material_count;
     {
         /* Image textures are decoded once, here, into one pool of RGBA float4 texels (16 bytes
          * per texel whatever the file format was: HBM is large, instructions per lookup are
@@ -780,6 +781,8 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     }
     args.pool = pool;
     args.cuCount = uint32_t(scene->cuCount);
+    /* the material records join the scene in LDS where a quarter of a compute unit's 160 KiB holds a workgroup with them */
+    args.materialsInLds = (!(g_variant & 0x80u) && COLD_BYTES + ldsBytes + size_t(scene->view.materialCount) * sizeof(wpt_material) <= 40960u) ? 1u : 0u;
     args.rowStop = samples_sqrt;
     args.carry = nullptr;
     args.cost = nullptr;
@@ -809,7 +812,7 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
             launchFullRgl(a, grid, stream);
         } else {
             if (basic && lds)
-                launchBasicLds(a, grid, ldsBytes, stream);
+                launchBasicLds(a, grid, ldsBytes + (a.materialsInLds ? size_t(scene->view.materialCount) * sizeof(wpt_material) : 0), stream);
             else if (basic)
                 launchBasic(a, grid, stream);
             else

@@ -450,6 +450,7 @@ struct SceneView {
     const float4* triAttr;   /* 6 x float4 per triangle */
     const wpt_instance* instances;
     const wpt_material* materials;
+    uint32_t materialCount;
     const wpt_texture* textures;
     const float4* texels4; /* decoded RGBA texels of all image textures */
     const wpt_hotspot* hotspots;

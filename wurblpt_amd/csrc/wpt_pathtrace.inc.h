@@ -91,6 +91,7 @@ struct KernelArgs {
     const uint32_t* order;        /* second pass: pixels in the order they are handed out */
     const uint32_t* orderCount;   /* second pass: entries of `order` */
     uint32_t cuCount; /* for the launchers: compute units of the device */
+    uint32_t materialsInLds; /* scene in LDS: the material records are there too */
     wpt_counters* counters;
     unsigned long long* schedStats; /* COUNT builds: 16 scheduler statistics, or NULL */
     uint32_t* status;               /* set to 1 by a launch that had to abort (bounded waits) */
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     wptm::tables_to_lds(threadIdx.x);
 #endif
 
-    const SceneView& sv = args.sv;
+    SceneView sv = args.sv;
     const wpt_params& par = args.par;
     const uint32_t nodeCount = sv.nodeCount;
 
@@ -161,6 +162,14 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             ldsScene[i] = sv.nodes[i];
         for (uint32_t i = threadIdx.x; i < t4; i += WG)
             ldsScene[n4 + i] = sv.triGeom[i];
+        if (args.materialsInLds) {
+            /* the material record is what a hit's shading waits for first: fetched from LDS through a generic pointer */
+            const uint32_t m4 = sv.materialCount * (uint32_t)(sizeof(wpt_material) / 16);
+            const float4* from = reinterpret_cast<const float4*>(sv.materials);
+            for (uint32_t i = threadIdx.x; i < m4; i += WG)
+                ldsScene[n4 + t4 + i] = from[i];
+            sv.materials = reinterpret_cast<const wpt_material*>(ldsScene + n4 + t4);
+        }
     }
     __syncthreads();
     auto node4 = [&](uint32_t i) -> float4 {
