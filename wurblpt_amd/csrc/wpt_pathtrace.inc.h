@@ -151,7 +151,10 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     wptm::tables_to_lds(threadIdx.x);
 #endif
 
-    SceneView sv = args.sv;
+    /* the kernel with the scene in LDS points its own copy of the scene view at the material records there; the others
+     * read the launch arguments where they lie (a copy costs the all-features kernel 2 %) */
+    SceneView svInLds = args.sv;
+    const SceneView& sv = LDSSCENE ? static_cast<const SceneView&>(svInLds) : args.sv;
     const wpt_params& par = args.par;
     const uint32_t nodeCount = sv.nodeCount;
 
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             const float4* from = reinterpret_cast<const float4*>(sv.materials);
             for (uint32_t i = threadIdx.x; i < m4; i += WG)
                 ldsScene[n4 + t4 + i] = from[i];
-            sv.materials = reinterpret_cast<const wpt_material*>(ldsScene + n4 + t4);
+            svInLds.materials = reinterpret_cast<const wpt_material*>(ldsScene + n4 + t4);
         }
     }
     __syncthreads();
