@@ -324,16 +324,18 @@ def test_reference_mis_test_scene_bit_exact(dev, oracle):
         assert bits_equal(got, ref) and gc == rc
 
 
-def test_sponza_like_textures_modphong_envmap_bit_exact(dev, oracle):
+@pytest.mark.parametrize("bins", [16, 12])
+def test_sponza_like_textures_modphong_envmap_bit_exact(dev, oracle, bins):
     """BASELINE config 3 stand-in at test size: textured Lambertian + normal maps, ModPhong with
     specular / shininess / alpha textures, two-sided curtains, GGX, mirror, equirect float
     environment map with importance-sampled next-event estimation; scene in HBM, all-features
-    kernel.  Importance tables built by the device equal the oracle's bit for bit."""
+    kernel.  Importance tables built by the device equal the oracle's bit for bit.  N = 16 bins per
+    side takes a sampled bin apart by mask and shift, N = 12 by the reference's % and /."""
     import ctypes as C
-    sc = host.sponza_like(64, 36, detail=0.05, tex_size=32, env_width=64, importance_n=16)
-    assert sc.d.envmap.N == 16 and sc.d.texture_count >= 10
+    sc = host.sponza_like(64, 36, detail=0.05, tex_size=32, env_width=64, importance_n=bins)
+    assert sc.d.envmap.N == bins and sc.d.texture_count >= 10
     ds = dev.DeviceScene(sc)  # tables built at upload (device L() + host sort)
-    n2 = 16 * 16
+    n2 = bins * bins
     M = np.zeros(n2, np.float32); Ms = np.zeros(n2, np.int32); Mcs = np.zeros(n2, np.float32)
     st = dev.lib().wpt_scene_get_envmap_tables(ds._handle, C.c_void_p(M.ctypes.data), C.c_void_p(Ms.ctypes.data), C.c_void_p(Mcs.ctypes.data))
     assert st == 0

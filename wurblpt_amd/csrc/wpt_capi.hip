@@ -604,6 +604,7 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     s->view.envCompat = desc->envmap.compat;
     s->view.envTex = desc->envmap.tex;
     s->view.envN = 0;
+    s->view.envLog2N = -1;
     if (desc->envmap.type != WPT_ENV_NONE && desc->envmap.N > 0) {
         const int N = desc->envmap.N;
         const size_t bins = size_t(N) * N;
@@ -672,6 +673,11 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
             }
         }
         s->view.envN = N;
+        s->view.envLog2N = -1;
+        if (N > 0 && (N & (N - 1)) == 0)
+            for (int b = 0; b < 31; b++)
+                if ((1 << b) == N)
+                    s->view.envLog2N = b;
     }
 #undef UP
     *out_scene = s;

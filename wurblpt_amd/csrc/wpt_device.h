@@ -466,6 +466,7 @@ struct SceneView {
     uint32_t hotspotCount;
     uint32_t envType, envCompat;
     int32_t envTex, envN;
+    int32_t envLog2N; /* log2(envN) if envN is a power of two, else -1 */
     int32_t envCube[6]; /* WPT_ENV_CUBE: textures +x -x +y -y +z -z */
     const int32_t* envLut; /* envLutSize + 1 entries: first bin whose cumulative importance reaches k / envLutSize, or NULL */
     uint32_t envLutSize;   /* a power of two */
@@ -907,8 +908,14 @@ WPT_D f3 envD(const SceneView& sv, Prng& prng)
         bin = (sv.envMcs[a] >= r ? a : b);
     }
     bin = sv.envMs[bin];
-    int x = bin % N;
-    int y = bin / N;
+    int x, y;
+    if (sv.envLog2N >= 0) { /* bin >= 0: mask and shift are % and / */
+        x = bin & (N - 1);
+        y = bin >> sv.envLog2N;
+    } else {
+        x = bin % N;
+        y = bin / N;
+    }
     f2 uv;
     uv.x = ((float)x + in01(prng)) / (float)N;
     uv.y = ((float)y + in01(prng)) / (float)N;
