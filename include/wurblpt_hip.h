@@ -430,6 +430,17 @@ wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant);
  * (0 = the whole tree depth-first, the reference's own array order; default 65536 = 2 MiB).  Visiting order and
  * results do not depend on it. */
 wpt_status wpt_set_top_nodes(uint32_t nodes);
+/* Which form of the path tracer renders frames whose scene is fetched from HBM (results do not depend on it):
+ * mode 0 = the library decides per launch (default), 1 = the wavefront form wherever it exists (trace and shade as two
+ * kernels that hand rays through HBM, wpt_wavefront.inc.h: everything but counting launches and moving scenes), 2 = never.
+ * groups: groups of lanes that iterate on streams of their own (0 = default); chunk: queue entries a wave of the trace
+ * takes per atomic (0 = default); flags bit 0: the shade walks the ray queue in its own order instead of by kind of
+ * material, bits 1-7: nodes in front of the node array that the trace walks from LDS, in units of 128 (0 = default, 0x7f =
+ * none), bits 8-15: lanes of a wave that must have finished before the trace deals it new rays (0 = default), bits 16-31: node
+ * steps a ray takes per launch of the trace before its walk is suspended until the next (0 = default, 0xffff = no limit).
+ * Process-global like wpt_set_launch_config and wpt_set_top_nodes: a hook for tests and measurements, set it before
+ * rendering starts, not while other threads render. */
+wpt_status wpt_set_wavefront(uint32_t mode, uint32_t groups, uint32_t chunk, uint32_t flags);
 
 /* Profiling hook: `stats_device` (device pointer to 24 uint64, or NULL to switch off) receives
  * the wave scheduler's statistics of launches that also count work (counters_device != NULL):

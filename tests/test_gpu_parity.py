@@ -990,3 +990,97 @@ def test_fuzz_parity_over_seeded_random_scenes():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "5", "7"], capture_output=True, timeout=900, cwd=root)
     assert r.returncode == 0 and b"35 scenes, 0 mismatches" in r.stdout, r.stdout.decode()[-2000:] + r.stderr.decode()[-2000:]
+
+
+def _wavefront(dev, mode, groups=0, chunk=0, flags=0):
+    dev.lib().wpt_set_wavefront(mode, groups, chunk, flags)
+
+
+@pytest.mark.parametrize("groups,chunk,flags", [(1, 0, 0), (2, 64, 1 | (7 << 16)), (3, 32, 0x800 | (1 << 16)), (2, 0, 0x2000 | (0xffff << 16)),
+                                                (2, 0, (33 << 16) | 0xfe), (1, 16, (2 << 1) | (5 << 16))])
+def test_wavefront_kernels_bit_exact(dev, oracle, groups, chunk, flags):
+    """The wavefront form (wpt_wavefront.inc.h: trace and shade as two kernels that hand every ray through HBM, pixels filed by
+    kind of material, walks suspended after a budget of node steps and taken up again by the next launch, the top of the tree in
+    LDS, groups of lanes on streams of their own) against the oracle, for every family of scene it exists for and over its launch
+    geometry: whole frames, a ragged block, interleaved bands.  wpt_kernel_name() tells which kernels rendered."""
+    import torch
+    p = host.default_params()
+    p.max_path_components = 8
+    scenes = [
+        ("cornell", host.cornell(48, 40, 1, 2), 3, None, False),
+        ("triangles + lens", host.random_triangles(1500, 5, with_texcoords=True, width=64, height=48, aperture=0.05), 2, p, False),
+        ("sponza-like", host.sponza_like(64, 48, seed=3, detail=0.03, tex_size=16, env_width=32, importance_n=8), 3, None, True),
+        ("courtyard-like", host.courtyard_like(56, 40, seed=4, triangles=4000, tex_size=16), 2, None, False),
+        ("measured", host.measured_like(48, 40, host.rgl_fixture("iso"), host.rgl_fixture("aniso"), seed=5, detail=0.03, tex_size=16, env_width=32,
+                                        importance_n=8), 2, None, True),
+        ("spheres", host.spheres(48, 40, 3), 3, None, False),
+    ]
+    try:
+        for label, sc, s, params, tables in scenes:
+            if tables and sc.d.envmap.N > 0:
+                t = oracle.envmap_tables(sc)
+                ds = dev.DeviceScene(sc)   # the device builds its own tables at upload
+                sc.set_envmap_tables(*t)
+            else:
+                ds = dev.DeviceScene(sc)
+            ref, _ = oracle.render(sc, s, params)
+            _wavefront(dev, 1, groups, chunk, flags)
+            got, _ = ds.render(s, params=params)
+            assert dev.lib().wpt_kernel_name() == b"wf_trace + wf_shade", label
+            assert dev.lib().wpt_last_render_passes() >= 3, label     # the launches of a frame: first rays, then trace + shade per iteration
+            assert bits_equal(got, ref), label
+            h_, w_ = ref.shape[:2]
+            start, size = 37, w_ * h_ - 101
+            part, _ = ds.render(s, block=(start, size), params=params)
+            assert bits_equal(part.reshape(-1, 3)[start:start + size], ref.reshape(-1, 3)[start:start + size]), label
+            assert not part.reshape(-1, 3)[:start].any() and not part.reshape(-1, 3)[start + size:].any(), label
+            total = np.zeros_like(ref)
+            for rank in range(3):
+                fr = torch.zeros((h_, w_, 3), dtype=torch.float32, device="cuda")
+                ds.render_bands_into(fr, s, 5, rank, 3, params=params, stream=torch.cuda.current_stream())
+                torch.cuda.synchronize()
+                total += fr.cpu().numpy()
+            assert bits_equal(total, ref), label
+            _wavefront(dev, 2)
+            single, _ = ds.render(s, params=params)
+            assert dev.lib().wpt_kernel_name() == b"wpt_pathtrace", label
+            assert bits_equal(single, ref), label
+    finally:
+        _wavefront(dev, 0)
+
+
+def test_wavefront_is_the_default_only_where_it_was_measured_faster(dev, oracle):
+    """Large frames of scenes with measured BRDFs go to the wavefront kernels by themselves; everything else, counting launches
+    and moving scenes stay with the single kernel whatever is asked for."""
+    sc = host.measured_like(1024, 1024, host.rgl_fixture("iso"), host.rgl_fixture("aniso"), seed=5, detail=0.03, tex_size=16, env_width=32, importance_n=8)
+    tables = oracle.envmap_tables(sc)
+    ds = dev.DeviceScene(sc)            # the device builds its own tables at upload
+    sc.set_envmap_tables(*tables)
+    got, _ = ds.render(1)
+    assert dev.lib().wpt_kernel_name() == b"wf_trace + wf_shade"
+    try:
+        _wavefront(dev, 2)
+        single, _ = ds.render(1)
+        assert dev.lib().wpt_kernel_name() == b"wpt_pathtrace"
+    finally:
+        _wavefront(dev, 0)
+    assert bits_equal(got, single)
+    rows = slice(500, 502)
+    ref, _ = oracle.render(sc, 1, block=(500 * 1024, 2 * 1024))
+    assert bits_equal(got[rows], ref[rows])
+    small = dev.DeviceScene(host.cornell(64, 64, 1, 2))
+    small.render(2)
+    assert dev.lib().wpt_kernel_name() == b"wpt_pathtrace"
+    try:
+        _wavefront(dev, 1)
+        _, counters = small.render(2, with_counters=True)             # counting launches have no wavefront form
+        assert dev.lib().wpt_kernel_name() == b"wpt_pathtrace" and counters["rays"] > 0
+        moving = host.animated(64, 48, 8, 0.0, 1.0)
+        mp = host.default_params()
+        mp.t0, mp.t1 = 0.0, 1.0
+        mref, _ = oracle.render(moving, 2, mp)
+        mgot, _ = dev.DeviceScene(moving).render(2, params=mp)        # nor have moving scenes
+        assert dev.lib().wpt_kernel_name() == b"wpt_pathtrace"
+        assert bits_equal(mgot, mref)
+    finally:
+        _wavefront(dev, 0)

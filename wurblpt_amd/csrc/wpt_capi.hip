@@ -15,6 +15,7 @@
 
 #include "../../include/wurblpt_hip.h"
 #include "wpt_pathtrace.inc.h"
+#include "wpt_wavefront.inc.h"
 #include "wpt_postproc.h"
 
 using namespace wptd;
@@ -174,6 +175,10 @@ uint32_t g_leafBias = 0;
 uint32_t g_lastPasses = 1; /* path tracing launches the last render call took for its pixels (wpt_last_render_passes) */
 uint32_t g_topNodes = 65536; /* nodes of a large tree that are stored level by level in front (wpt_set_top_nodes) */
 unsigned long long* g_schedStats = nullptr;
+/* wpt_set_wavefront: 0 = the library decides, 1 = wavefront wherever it exists, 2 = never; launch geometry (0 = defaults) */
+uint32_t g_wfMode = 0;
+wptk::WfConfig g_wfConfig = { 0, 0, 0, 1, 0, 0, 0 };
+thread_local const char* g_kernelName = nullptr; /* the calling thread's last render: which kernel family ran */
 
 template<typename T> wpt_status uploadArray(wpt_scene* s, const T* src, size_t count, const T** dst)
 {
@@ -498,7 +503,8 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
                 return fail(WPT_ERR_INVALID_ARGUMENT, "BVH conversion: the links do not reach every node exactly once");
             }
         }
-        std::vector<float4> dev(size_t(n) * 2);
+        /* one node of padding: kernels that fetch aligned pairs of nodes read the whole last pair */
+        std::vector<float4> dev(size_t(n) * 2 + 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         for (uint32_t i = 0; i < n; i++) {
             const wpt_bvh_node& nd = desc->nodes[i];
             const uint32_t skip = place[end[i]];
@@ -779,6 +785,33 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     /* Pixel pool: frames with more pixels than the device has lanes at once are handed out pixel by pixel (the launchers
      * decide); variant bit 0x10: never.  The counter is allocated and freed in stream order, so launches in flight on any
      * number of streams never share one. */
+    /* Wavefront form (wpt_wavefront.inc.h): trace and shade as two kernels that hand rays through HBM.  Not for counting
+     * launches and moving scenes (those instantiations exist for the single kernel only). */
+    const bool wfExists = !count && !anim;
+    /* The library's own choice (measured): frames of a million pixels and more whose scene has measured
+     * BRDFs -- long shading that pays for being sorted by kind of material (Bistro-class frame 111 against 90 Msamples/s).
+     * Scenes whose time is the walk stay with the single kernel: the wavefront trace meets the same wall of the memory
+     * system (Sponza-class 105 against 134, 10 M triangles 38 against 63) and pays for the rays' way through HBM on top. */
+    const bool wfAuto = rgl && block_size >= (1u << 20);
+    if (wfExists && (g_wfMode == 1u || (g_wfMode == 0u && wfAuto))) {
+        args.pool = nullptr;
+        args.cuCount = uint32_t(scene->cuCount);
+        args.materialsInLds = 0;
+        args.rowStop = samples_sqrt;
+        args.carry = nullptr;
+        args.cost = nullptr;
+        args.order = nullptr;
+        args.orderCount = nullptr;
+        const wptk::WfLaunchers& kernels = rgl ? wptk::wfFullRgl() : (basic ? wptk::wfBasic() : wptk::wfFull());
+        uint32_t launches = 0;
+        const hipError_t e = wptk::renderWavefront(args, kernels, g_wfConfig, stream, &launches);
+        g_lastPasses = launches;
+        g_kernelName = "wf";
+        if (e != hipSuccess)
+            return fail(WPT_ERR_HIP, std::string("wavefront render: ") + hipGetErrorString(e));
+        return WPT_OK;
+    }
+    g_kernelName = nullptr;
     uint32_t* pool = nullptr;
     const bool pooled = !count && !(g_variant & 0x10u) && block_size < 0x80000000u && grid.x > uint32_t(scene->cuCount);
     if (pooled && hipMallocAsync(reinterpret_cast<void**>(&pool), sizeof(uint32_t), stream) != hipSuccess) {
@@ -1037,6 +1070,23 @@ wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant)
     return WPT_OK;
 }
 
+wpt_status wpt_set_wavefront(uint32_t mode, uint32_t groups, uint32_t chunk, uint32_t flags)
+{
+    if (mode > 2u)
+        return fail(WPT_ERR_INVALID_ARGUMENT, "wavefront mode must be 0, 1 or 2");
+    g_wfMode = mode;
+    g_wfConfig.groups = groups;
+    g_wfConfig.chunk = chunk;
+    g_wfConfig.buckets = (flags & 1u) ? 0u : 1u;
+    g_wfConfig.refillIdle = (flags >> 8) & 0xffu;
+    g_wfConfig.leafBias = 0;
+    /* bits 16-31: node steps a ray takes per launch of the trace before it is suspended (0 = default, 0xffff = no limit) */
+    g_wfConfig.stepBudget = (flags >> 16) == 0xffffu ? 0xffffffffu : (flags >> 16);
+    /* bits 1-7: nodes in front of the node array that the trace walks from LDS, in units of 128 (0 = default, 0x7f = none) */
+    g_wfConfig.topNodes = ((flags >> 1) & 0x7fu) == 0x7fu ? 0xffffffffu : ((flags >> 1) & 0x7fu) * 128u;
+    return WPT_OK;
+}
+
 wpt_status wpt_set_top_nodes(uint32_t nodes)
 {
     g_topNodes = nodes;
@@ -1163,7 +1213,8 @@ wpt_status wpt_set_scheduler_stats(unsigned long long* stats_device)
 
 const char* wpt_kernel_name(void)
 {
-    return "wpt_pathtrace";
+    /* the kernel family of the calling thread's last render call */
+    return g_kernelName ? "wf_trace + wf_shade" : "wpt_pathtrace";
 }
 
 const char* wpt_device_name(int device)

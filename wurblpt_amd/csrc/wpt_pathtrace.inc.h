@@ -124,6 +124,49 @@ WPT_D bool lanePixel(const KernelArgs& args, uint32_t gid, uint32_t& pixel)
     return inBlock;
 }
 
+/* A node's two quadwords for the lanes that `need` them, fetched by PAIRS of lanes: in a first instruction lanes 2i and
+ * 2i + 1 load the two halves of lane 2i's node, in a second those of lane 2i + 1's, and the halves change lanes by DPP.
+ * Every instruction then asks for a cache line once, from two neighbouring lanes.  With one lane loading both halves in
+ * two instructions the line is asked for twice, and with many waves on a compute unit the second request no longer
+ * finds it in L1: measured (tools/micro/node_fetch.hip, 17 MB of nodes, four waves per SIMD) 118 G fetches per second
+ * against 262 G for walks that do nothing else.  Called by all lanes of the wave together (the exchange reads the
+ * neighbour's registers).  The path tracer's own walks are not bound there: in the single kernel the pairs cut the L1
+ * accesses of the Sponza-class frame by 40 %, left the L2 requests as they were (the second half found its line in L1
+ * all along) and added half as many vector instructions again, 255 -> 310 ms (gpurun_out/pmc_wf2_summary.txt); it is
+ * an option of the wavefront trace only. */
+WPT_D void fetchNodePaired(const float4* nodes, uint32_t node, bool need, float4& pn0, float4& pn1)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int SWAP = 0xb1; /* quad_perm [1, 0, 3, 2]: each lane reads its pair's other lane */
+    const uint32_t odd = threadIdx.x & 1u;
+    const uint32_t mine = need ? node : 0xffffffffu;
+    const uint32_t theirs = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, SWAP, 0xf, 0xf, false);
+    const uint32_t nodeA = odd ? theirs : mine, nodeB = odd ? mine : theirs; /* the even lane's node, the odd lane's */
+    float4 qa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), qb = qa;
+    if (nodeA != 0xffffffffu)
+        qa = nodes[2 * (size_t)nodeA + odd];
+    if (nodeB != 0xffffffffu)
+        qb = nodes[2 * (size_t)nodeB + odd];
+    /* the even lane holds its own first half (qa) and sends the odd lane's first half (qb); the odd lane holds its own
+     * second half (qb) and sends the even lane's second half (qa) */
+    const float4 send = odd ? qa : qb;
+    float4 got;
+    got.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.x), SWAP, 0xf, 0xf, false));
+    got.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.y), SWAP, 0xf, 0xf, false));
+    got.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.z), SWAP, 0xf, 0xf, false));
+    got.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.w), SWAP, 0xf, 0xf, false));
+    if (need) {
+        pn0 = odd ? got : qa;
+        pn1 = odd ? qb : got;
+    }
+#else
+    if (need) {
+        pn0 = nodes[2 * (size_t)node];
+        pn1 = nodes[2 * (size_t)node + 1];
+    }
+#endif
+}
+
 /* lane states, in scheduling priority order for ties */
 enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5, S_START = 6 /* within a long round: has a ray to start */ };
 

@@ -1,0 +1,587 @@
+/*
+ * wpt_wavefront.inc.h -- the wavefront form of the path tracer, for scenes that are fetched from HBM / L2.
+ *
+ * The single kernel of wpt_pathtrace.inc.h keeps a pixel in one lane through every stage, so its waves run node steps,
+ * leaf tests and the long shading round with a fraction of their lanes each, at the register budget of the largest
+ * stage (128 registers, four waves per SIMD).  Here the same path logic (wpt_blocks.h, unchanged) and the same walk
+ * (same visiting order as bvh.hpp:277-311) are two kernels that hand a pixel's ray back and forth through HBM:
+ *
+ *   wf_trace   persistent waves at 64 registers / eight waves per SIMD that hold nothing but rays: origin, reciprocals,
+ *              shear, node, bound, candidate.  A wave takes rays from the iteration's queue in chunks (one atomic per
+ *              chunk) and deals them to its lanes as they finish, so its lanes are always walking; a finished lane
+ *              writes the candidate to the pixel's record and files the pixel under the kind of shading it needs next
+ *              (per-wave staging in LDS, one atomic per flush of up to 64 pixels).
+ *   wf_shade   one lane per filed pixel, a wave per kind: the pixel's cold words are copied from its record into the LDS
+ *              slots the blocks of wpt_blocks.h work on (the layout of the single kernel's long round), one path
+ *              component is evaluated (blockShade / blockNeeEnd, then blockNew where the path ended), record and next
+ *              ray are written back and the pixel is queued for the next trace (one atomic per workgroup).
+ *
+ * One pixel still has one ray in flight and draws from its one generator in the reference's order (prng.hpp:79-101,
+ * wurblpt.hpp:342-366): a frame is the same bit for bit as the single kernel's and the oracle's.  An iteration is
+ * trace + shade; the number of iterations is the largest number of rays any pixel of the launch traces.  The launch's
+ * lanes are cut into groups that iterate on streams of their own, so that one group's shading runs beside another's
+ * walk and the end of one kernel (its longest rays) is filled by the other.
+ *
+ * Per lane of the launch: one record of 16 quadwords (256 B) in HBM --
+ *   0..7   the cold words of wpt_blocks.h (generator, attenuations, accumulator, ...), one 128-byte line
+ *   8      ray origin, time          9   ray direction, kind of ray
+ *   10     candidate: primitive, distance, 1 / det, U        11   V, W
+ *   12     a suspended walk: next node, bound
+ *
+ * A launch of the trace walks a ray for at most WfArgs::stepBudget node steps.  The walk has no stack: what it needs to
+ * go on is the next node, the bound and the candidate, eight words.  A ray that is not through by then is written
+ * back with them and queued for the next iteration's trace, which takes it up where it stopped -- same visiting order,
+ * same result; its pixel simply is not shaded in between.  Without the budget every iteration lasts as long as its
+ * longest ray (the trees here are 50 levels deep and ray lengths have a long tail): measured, the waves of a trace
+ * launch were on the device for 53 % of its duration on average.
+ */
+#ifndef WPT_WAVEFRONT_INC_H
+#define WPT_WAVEFRONT_INC_H
+
+#include "wpt_pathtrace.inc.h"
+
+namespace wptk {
+
+constexpr uint32_t WF_SLOTS = 16; /* quadwords per lane record */
+/* Waves per SIMD the trace is built for.  More waves do not walk faster: dependent fetches of random nodes reach their
+ * highest rate at two to four waves per SIMD and fall off beyond (tools/micro/node_fetch.hip: 262 G fetches per second at
+ * four, 137 G at eight for 17 MB of nodes) -- the lines a compute unit's lanes have in flight outgrow its L1. */
+#ifndef WF_TRACE_WAVES
+#define WF_TRACE_WAVES 4
+#endif
+enum { WF_RAY_O = 8, WF_RAY_D = 9, WF_HIT0 = 10, WF_HIT1 = 11, WF_WALK = 12 };
+constexpr uint32_t WF_RESUME = 0x100u; /* in the kind-of-ray word: the record holds a suspended walk */
+
+/* kinds a traced pixel is filed under for shading; a wave of wf_shade serves one kind */
+enum {
+    WF_B_MISS = 0,     /* path ray left the scene: environment radiance, next sample */
+    WF_B_NEE = 1,      /* a next-event ray came back */
+    WF_B_LIGHT = 2,    /* path ray on an emitter: emission, path ends */
+    WF_B_LAMBERT = 3,
+    WF_B_MODPHONG = 4,
+    WF_B_GGX = 5,
+    WF_B_EXPLICIT = 6, /* glass, mirror */
+    WF_B_RGL = 7,
+    WF_BUCKETS = 8
+};
+
+/* counters of one iteration; a ring of them, cleared ahead by the host */
+struct WfIter {
+    uint32_t rayCount;    /* pixels queued for this iteration's trace (appended by the shade before it) */
+    uint32_t traceCursor; /* next queue entry to hand to a wave */
+    uint32_t pad[2];
+    uint32_t bucketCount[WF_BUCKETS]; /* traced pixels by kind (appended by the trace) */
+};
+constexpr uint32_t WF_RING = 256; /* ring entries, a power of two; the host clears one batch of iterations ahead */
+
+struct WfArgs {
+    KernelArgs k;       /* scene, camera, parameters, frame, lane -> pixel mapping of the launch */
+    float4* state;      /* WF_SLOTS quadwords per lane of the launch */
+    uint32_t* rayQueue[2];    /* lane indices queued for the trace of even / odd iterations (the group's own arrays) */
+    uint32_t* bucketQueue;    /* WF_BUCKETS arrays of laneCount entries: traced lanes by kind */
+    WfIter* ring;
+    uint32_t laneFirst, laneCount; /* this group's lanes of the launch */
+    uint32_t iteration;
+    uint32_t buckets;    /* 1: the trace files pixels by kind and the shade takes them from there; 0: the shade walks the ray queue */
+    uint32_t chunk;      /* queue entries a wave of the trace takes per atomic */
+    uint32_t refillIdle; /* the trace deals new rays once this many lanes of a wave have finished */
+    uint32_t leafBias;
+    uint32_t stepBudget; /* node steps a ray may take per launch of the trace (0: no limit) */
+    uint32_t topNodes;   /* the first topNodes nodes of the array (the top of a large tree, stored level by level) are walked from LDS */
+};
+
+WPT_D uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+WPT_D uint32_t rankIn(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+/* ---- trace ---- */
+enum { T_NODE = 0, T_LEAF = 1, T_DONE = 2, T_IDLE = 3, T_SUSPEND = 4 };
+
+/* kind of shading a traced ray needs (TwoSided resolved as resolveMaterial does, material.hpp:273-320).  Only the
+ * grouping of lanes into waves depends on it, never a value. */
+template<bool SPHERES> WPT_D uint32_t shadeKind(const SceneView& sv, uint32_t rayKind, uint32_t prim, float invDet)
+{
+    if (rayKind != RAY_PATH)
+        return WF_B_NEE;
+    if (prim == NO_HIT)
+        return WF_B_MISS;
+    uint32_t mat;
+    const bool backside = invDet < 0.0f; /* spheres: the hit record decides; a wrong guess only files the pixel elsewhere */
+    if (SPHERES && (prim & PRIM_SPHERE))
+        mat = sv.spheres[prim & ~PRIM_SPHERE].material;
+    else
+        mat = __float_as_uint(reinterpret_cast<const float*>(sv.triGeom + 3 * (size_t)prim + 1)[3]);
+    const wpt_material* m = sv.materials + mat;
+    for (int guard = 0; guard < 4 && m->type == WPT_MAT_TWOSIDED; guard++)
+        m = sv.materials + (backside ? m->tex[1] : m->tex[0]);
+    switch (m->type) {
+    case WPT_MAT_LIGHT_DIFFUSE: return WF_B_LIGHT;
+    case WPT_MAT_LAMBERTIAN: return WF_B_LAMBERT;
+    case WPT_MAT_MODPHONG: return WF_B_MODPHONG;
+    case WPT_MAT_GGX: return WF_B_GGX;
+    case WPT_MAT_RGL: return WF_B_RGL;
+    default: return WF_B_EXPLICIT;
+    }
+}
+
+template<bool SPHERES, bool PAIRED>
+__global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
+{
+    const SceneView& sv = a.k.sv;
+    WfIter* const cur = a.ring + (a.iteration & (WF_RING - 1));
+    WfIter* const nxt = a.ring + ((a.iteration + 1) & (WF_RING - 1));
+    uint32_t* const queueNext = a.rayQueue[(a.iteration + 1) & 1u];
+    const uint32_t count = cur->rayCount;
+    const uint32_t nodeCount = sv.nodeCount;
+    const float amin = a.k.par.min_hit_distance;
+    /* The top of the tree in LDS: every ray starts there, and with thousands of lanes per compute unit in flight L1 does
+     * not keep those lines, so the same few lines would be asked of the same few L2 channels by every compute unit. */
+    extern __shared__ float4 ldsTop[];
+    const uint32_t topNodes = count != 0 ? a.topNodes : 0u;
+    for (uint32_t i = threadIdx.x; i < 2 * topNodes; i += WG)
+        ldsTop[i] = sv.nodes[i];
+    __syncthreads();
+    /* Fetch of the node a lane tests next, behind the step that found it.  PAIRED: a lane fetches the aligned PAIR of
+     * nodes (64 bytes) that holds its node and keeps it: the line comes up from L2 whole whatever part of it is read,
+     * seven steps of ten go on to the node behind the current one (first child, or whatever follows a leaf), and for
+     * an even node that one is the pair's other half -- no request at all. */
+    float4 pq0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pq1 = pq0, pq2 = pq0, pq3 = pq0;
+    uint32_t pairAt = 0xffffffffu;
+    auto fetchNode = [&](uint32_t node, bool want, float4& pn0, float4& pn1) {
+        if (!want)
+            return;
+        if (node < topNodes) {
+            pn0 = ldsTop[2 * node];
+            pn1 = ldsTop[2 * node + 1];
+        } else if constexpr (PAIRED) {
+            if ((node >> 1) != pairAt) {
+                const float4* at = sv.nodes + 4 * (size_t)(node >> 1);
+                pq0 = at[0];
+                pq1 = at[1];
+                pq2 = at[2];
+                pq3 = at[3];
+                pairAt = node >> 1;
+            }
+            pn0 = (node & 1u) ? pq2 : pq0;
+            pn1 = (node & 1u) ? pq3 : pq1;
+        } else {
+            pn0 = sv.nodes[2 * (size_t)node];
+            pn1 = sv.nodes[2 * (size_t)node + 1];
+        }
+    };
+    const uint32_t* const queue = a.rayQueue[a.iteration & 1u];
+    const uint32_t lane = laneId();
+    /* filed pixels are staged per wave and kind in LDS (64 entries each) and flushed to the kind's queue with one atomic */
+    __shared__ uint32_t stage[WG / 64][WF_BUCKETS][64];
+    uint32_t (*const myStage)[64] = stage[threadIdx.x >> 6];
+    unsigned long long fills = 0; /* wave-uniform: eight 8-bit fill counts */
+    auto flush = [&](uint32_t kd, uint32_t n) {
+        uint32_t base = 0;
+        if (lane == 0)
+            base = atomicAdd(&cur->bucketCount[kd], n);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (lane < n)
+            a.bucketQueue[(size_t)kd * a.laneCount + base + lane] = myStage[kd][lane];
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    uint32_t chunkNext = 0, chunkEnd = 0; /* wave-uniform: this wave's entries of the queue */
+    bool dry = false;
+    int state = T_IDLE;
+    f3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
+    RayAux aux;
+    aux.inv = o;
+    aux.k = 0;
+    aux.Sx = aux.Sy = 0.0f;
+    uint32_t node = 0, leafPrim = 0, gid = 0, stepsLeft = 0;
+    float amax = k_maxval;
+    Candidate best;
+    best.prim = NO_HIT;
+    best.a = best.invDet = best.U = best.V = best.W = 0.0f;
+    float4 pn0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pn1 = pn0;
+
+    for (;;) {
+        /* ---- deal rays to the lanes that have none ---- */
+        const unsigned long long idle = __ballot(state == T_IDLE);
+        if (idle != 0) {
+            if (chunkNext == chunkEnd && !dry) {
+                uint32_t first = 0;
+                if (lane == 0)
+                    first = atomicAdd(&cur->traceCursor, a.chunk);
+                first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+                if (first >= count) {
+                    dry = true; /* the cursor only grows: nothing more for this wave */
+                } else {
+                    chunkNext = first;
+                    chunkEnd = first + a.chunk < count ? first + a.chunk : count;
+                }
+            }
+            const uint32_t avail = chunkEnd - chunkNext, want = (uint32_t)__popcll(idle);
+            const uint32_t take = avail < want ? avail : want;
+            if (take != 0) {
+                const uint32_t rank = rankIn(idle);
+                bool dealt = false;
+                if (state == T_IDLE && rank < take) {
+                    dealt = true;
+                    gid = queue[chunkNext + rank];
+                    const float4* rec = a.state + (size_t)gid * WF_SLOTS;
+                    const float4 ro = rec[WF_RAY_O], rd = rec[WF_RAY_D];
+                    o = mk3(ro.x, ro.y, ro.z);
+                    d = mk3(rd.x, rd.y, rd.z);
+                    aux = rayAux(d);
+                    node = 0;
+                    amax = k_maxval;
+                    best.prim = NO_HIT;
+                    if (__float_as_uint(rd.w) & WF_RESUME) { /* a suspended walk goes on */
+                        const float4 h0 = rec[WF_HIT0], h1 = rec[WF_HIT1], wk = rec[WF_WALK];
+                        best.prim = __float_as_uint(h0.x);
+                        best.a = h0.y;
+                        best.invDet = h0.z;
+                        best.U = h0.w;
+                        best.V = h1.x;
+                        best.W = h1.y;
+                        node = __float_as_uint(wk.x);
+                        amax = wk.y;
+                    }
+                    stepsLeft = a.stepBudget ? a.stepBudget : 0xffffffffu;
+                    state = T_NODE;
+                }
+                fetchNode(node, dealt, pn0, pn1);
+                chunkNext += take;
+            }
+        }
+        if (__ballot(state != T_IDLE) == 0) {
+            if (dry)
+                break;
+            continue; /* the chunk ran out: take the next one */
+        }
+        /* walk until refillIdle lanes have finished (while there is something to deal them), or to the end */
+        const bool canRefill = chunkNext != chunkEnd || !dry;
+        int leaveBelow = canRefill ? 65 - (int)a.refillIdle : 1;
+        leaveBelow = leaveBelow < 1 ? 1 : leaveBelow;
+        for (;;) {
+            const int nNode = __popcll(__ballot(state == T_NODE));
+            const int nLeaf = __popcll(__ballot(state == T_LEAF));
+            if (nNode + nLeaf < leaveBelow)
+                break;
+            if (nLeaf * (int)a.leafBias >= nNode * 8 && nLeaf > 0) {
+                bool wantNode = false;
+                if (state == T_LEAF) {
+                    /* HitableTriangle::hit / HitableSphere::hit, candidate part; `node` already is the node to go on with */
+                    Candidate c;
+                    bool accepted;
+                    if (SPHERES && (leafPrim & PRIM_SPHERE)) {
+                        c.invDet = c.U = c.V = c.W = 0.0f;
+                        accepted = sphereTest(sv.spheres[leafPrim & ~PRIM_SPHERE], o, d, amin, amax, c.a);
+                    } else {
+                        const float4* g = sv.triGeom + 3 * (size_t)leafPrim;
+                        const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+                        accepted = triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), o, aux, amin, amax, c);
+                    }
+                    if (accepted) {
+                        c.prim = leafPrim;
+                        best = c;
+                        amax = c.a;
+                    }
+                    state = node >= nodeCount ? (int)T_DONE : (int)T_NODE;
+                    if (state == T_NODE && stepsLeft == 0)
+                        state = T_SUSPEND; /* between two nodes: nothing pending but (node, bound, candidate) */
+                    wantNode = state == T_NODE;
+                }
+                fetchNode(node, wantNode, pn0, pn1);
+            } else {
+                bool wantNode = false;
+                if (state == T_NODE) {
+                    /* AABB::mayHit + the stackless form of BVH::hit's walk (wpt_pathtrace.inc.h) */
+                    const float4 n0 = pn0, n1 = pn1;
+                    const uint32_t skip = __float_as_uint(n1.z);
+                    const uint32_t word = __float_as_uint(n1.w);
+                    const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, aux.inv, amin, amax);
+                    const bool inner = word >= NODE_CHILD;
+                    const bool toLeaf = hit && !inner;
+                    leafPrim = toLeaf ? word : leafPrim;
+                    node = (hit && inner) ? (word & NODE_INDEX_MASK) : skip;
+                    state = toLeaf ? (int)T_LEAF : (int)T_NODE;
+                    if (!toLeaf && node >= nodeCount)
+                        state = T_DONE;
+                    stepsLeft = stepsLeft ? stepsLeft - 1 : 0;
+                    if (state == T_NODE && stepsLeft == 0)
+                        state = T_SUSPEND;
+                    wantNode = state == T_NODE;
+                }
+                fetchNode(node, wantNode, pn0, pn1);
+            }
+        }
+        /* ---- finished rays: the candidate goes to the pixel's record, the pixel to the queue of its kind; rays out of
+         * steps are written back as they stand and queued for the next trace ---- */
+        if (__ballot(state == T_DONE || state == T_SUSPEND) != 0) {
+            uint32_t kind = WF_BUCKETS;
+            const bool suspend = state == T_SUSPEND;
+            if (state == T_DONE || suspend) {
+                float4* rec = a.state + (size_t)gid * WF_SLOTS;
+                rec[WF_HIT0] = make_float4(__uint_as_float(best.prim), best.a, best.invDet, best.U);
+                rec[WF_HIT1] = make_float4(best.V, best.W, 0.0f, 0.0f);
+                uint32_t* kindWord = reinterpret_cast<uint32_t*>(rec + WF_RAY_D) + 3;
+                const uint32_t kw = *kindWord; /* the kind of ray is read again here: one register less while walking */
+                if (suspend) {
+                    rec[WF_WALK] = make_float4(__uint_as_float(node), amax, 0.0f, 0.0f);
+                    if (!(kw & WF_RESUME))
+                        *kindWord = kw | WF_RESUME;
+                } else {
+                    if (kw & WF_RESUME)
+                        *kindWord = kw & ~WF_RESUME; /* through: the record holds a result again */
+                    if (a.buckets)
+                        kind = shadeKind<SPHERES>(sv, kw & ~WF_RESUME, best.prim, best.invDet);
+                }
+                state = T_IDLE;
+            }
+            const unsigned long long suspended = __ballot(suspend);
+            if (suspended != 0) {
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&nxt->rayCount, (uint32_t)__popcll(suspended));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (suspend)
+                    queueNext[base + rankIn(suspended)] = gid;
+            }
+            unsigned long long left = __ballot(kind < WF_BUCKETS);
+            while (left != 0) {
+                const int leader = __ffsll((long long)left) - 1;
+                const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)kind, leader);
+                const unsigned long long mine = __ballot(kind == kd);
+                left &= ~mine;
+                const uint32_t n = (uint32_t)__popcll(mine);
+                uint32_t f = (uint32_t)(fills >> (8 * kd)) & 0xffu;
+                if (f + n > 64u) {
+                    flush(kd, f);
+                    f = 0;
+                }
+                if (kind == kd)
+                    myStage[kd][f + rankIn(mine)] = gid;
+                __builtin_amdgcn_wave_barrier();
+                f += n;
+                if (f == 64u) {
+                    flush(kd, f);
+                    f = 0;
+                }
+                fills = (fills & ~(0xffull << (8 * kd))) | ((unsigned long long)f << (8 * kd));
+            }
+        }
+    }
+    if (a.buckets) {
+        for (uint32_t kd = 0; kd < WF_BUCKETS; kd++) {
+            const uint32_t f = (uint32_t)(fills >> (8 * kd)) & 0xffu;
+            if (f != 0)
+                flush(kd, f);
+        }
+    }
+}
+
+/* ---- shade ---- */
+
+/* Workgroup -> (kind, first entry) over the kinds' queues laid end to end, each kind rounded up to whole workgroups.
+ * false: nothing for this workgroup. */
+WPT_D bool shadeSlice(const WfIter* cur, uint32_t group, uint32_t& kind, uint32_t& first, uint32_t& count)
+{
+    uint32_t at = 0;
+    for (uint32_t kd = 0; kd < WF_BUCKETS; kd++) {
+        const uint32_t n = cur->bucketCount[kd];
+        const uint32_t groups = (n + WG - 1) / WG;
+        if (group < at + groups) {
+            kind = kd;
+            first = (group - at) * WG;
+            count = n;
+            return true;
+        }
+        at += groups;
+    }
+    return false;
+}
+
+/* INIT: the first launch of a group -- every lane takes its pixel, seeds the generator and starts the first sample.
+ * Otherwise one path component per queued pixel. */
+template<uint32_t F, bool INIT>
+__global__ __launch_bounds__(WG, 4) void wf_shade(const WfArgs a)
+{
+    /* [ math tables ][ cold path words: SLOT_COUNT x WG float4 ][ 8 words: compaction ] */
+    extern __shared__ float4 lds[];
+    float4* const ldsCold = lds + TABLE_BYTES / 16;
+    uint32_t* const ldsWords = reinterpret_cast<uint32_t*>(ldsCold + SLOT_COUNT * WG);
+#if defined(WPT_MATH_TABLES_IN_LDS) && defined(__HIP_DEVICE_COMPILE__)
+    wptm::tables_to_lds(threadIdx.x);
+#endif
+    const SceneView& sv = a.k.sv;
+    const wpt_params& par = a.k.par;
+    WfIter* const cur = a.ring + (a.iteration & (WF_RING - 1));
+    WfIter* const nxt = a.ring + ((a.iteration + 1) & (WF_RING - 1));
+    uint32_t* const queueOut = a.rayQueue[(a.iteration + 1) & 1u];
+
+    /* which entry of which queue */
+    uint32_t kind = WF_BUCKETS, first = blockIdx.x * WG, count = 0;
+    const uint32_t* queueIn = nullptr;
+    if (INIT) {
+        count = a.laneCount;
+    } else if (a.buckets) {
+        if (shadeSlice(cur, blockIdx.x, kind, first, count))
+            queueIn = a.bucketQueue + (size_t)kind * a.laneCount;
+        else
+            return; /* uniform for the workgroup */
+    } else {
+        count = cur->rayCount;
+        queueIn = a.rayQueue[a.iteration & 1u];
+        if (first >= count)
+            return;
+    }
+    __syncthreads(); /* the tables */
+
+    FrameArgs fa;
+    fa.cam = a.k.cam;
+    fa.par = a.k.par;
+    fa.width = a.k.width;
+    fa.height = a.k.height;
+    fa.samplesSqrt = a.k.samplesSqrt;
+    fa.invWidth = a.k.invWidth;
+    fa.invHeight = a.k.invHeight;
+    fa.invSamplesSqrt = a.k.invSamplesSqrt;
+    TriGeomFromScene tri4;
+    tri4.triGeom = sv.triGeom;
+
+    PathLds<WG> ps;
+    ps.base = ldsCold + threadIdx.x;
+    const uint32_t entry = first + threadIdx.x;
+    bool have = entry < count;
+    uint32_t gid = 0;
+    float4* rec = a.state;
+    Candidate best;
+    best.prim = NO_HIT;
+    best.a = best.invDet = best.U = best.V = best.W = 0.0f;
+    int next = NEXT_DONE;
+    if (INIT) {
+        gid = a.laneFirst + entry;
+        uint32_t pixel = a.k.blockStart;
+        if (have)
+            have = lanePixel(a.k, gid, pixel);
+        pathStateInit(ps, pixel, pixel % a.k.width, pixel / a.k.width);
+        rec = a.state + (size_t)gid * WF_SLOTS;
+        next = NEXT_NEW;
+    } else {
+        ps.time = 0.0f;
+        ps.animCached = -1;
+        ps.rayKind = RAY_PATH;
+        ps.o = ps.d = mk3(0.0f, 0.0f, 1.0f);
+        if (have) {
+            gid = queueIn[entry];
+            rec = a.state + (size_t)gid * WF_SLOTS;
+#pragma unroll
+            for (int k = 0; k < SLOT_COUNT; k++)
+                ps.base[k * WG] = rec[k];
+            const float4 ro = rec[WF_RAY_O], rd = rec[WF_RAY_D], h0 = rec[WF_HIT0], h1 = rec[WF_HIT1];
+            ps.o = mk3(ro.x, ro.y, ro.z);
+            ps.time = ro.w;
+            ps.d = mk3(rd.x, rd.y, rd.z);
+            ps.rayKind = (int)__float_as_uint(rd.w);
+            if (__float_as_uint(rd.w) & WF_RESUME)
+                have = false; /* (walking the ray queue) a suspended walk: the trace has queued it again itself */
+            best.prim = __float_as_uint(h0.x);
+            best.a = h0.y;
+            best.invDet = h0.z;
+            best.U = h0.w;
+            best.V = h1.x;
+            best.W = h1.y;
+        }
+    }
+    if (have) {
+        LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
+        if (!INIT) {
+            if (ps.rayKind == RAY_PATH)
+                next = blockShade<F, false>(sv, par, tri4, ps, best, lc, 0); /* tracePath, one path component (wurblpt.hpp:131-252) */
+            else
+                next = blockNeeEnd<F>(sv, par, tri4, ps, best);            /* the next-event ray's contribution, then the path continues */
+        }
+        if (next == NEXT_NEW) { /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
+            next = blockNew<F>(fa, ps, &sv);
+            if (next == NEXT_DONE) {
+                /* SensorRGB::finishPixel (sensor_rgb.hpp:82-87) */
+                const uint32_t pxy = ps.getW(SLOT_SRDIR);
+                const size_t at = (size_t)(pxy >> 16) * a.k.width + (pxy & 0xffffu);
+                const Slot acc = ps.get(SLOT_ACC);
+                float* out = a.k.frame + 3 * at;
+                out[0] = a.k.invSamples * acc.x;
+                out[1] = a.k.invSamples * acc.y;
+                out[2] = a.k.invSamples * acc.z;
+            }
+        }
+        if (next == NEXT_TRACE) {
+#pragma unroll
+            for (int k = 0; k < SLOT_COUNT; k++)
+                rec[k] = ps.base[k * WG];
+            rec[WF_RAY_O] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.time);
+            rec[WF_RAY_D] = make_float4(ps.d.x, ps.d.y, ps.d.z, __uint_as_float((uint32_t)ps.rayKind));
+        }
+    }
+    /* ---- the pixels that go on are queued for the next trace: one atomic per workgroup ---- */
+    const bool alive = have && next == NEXT_TRACE;
+    const unsigned long long aliveMask = __ballot(alive);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0)
+        ldsWords[wave] = (uint32_t)__popcll(aliveMask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = ldsWords[0] + ldsWords[1] + ldsWords[2] + ldsWords[3];
+        ldsWords[4] = total ? atomicAdd(&nxt->rayCount, total) : 0u;
+    }
+    __syncthreads();
+    if (alive) {
+        uint32_t at = ldsWords[4] + rankIn(aliveMask);
+        for (uint32_t w = 0; w < wave; w++)
+            at += ldsWords[w];
+        queueOut[at] = gid;
+    }
+}
+
+constexpr size_t WF_SHADE_LDS = COLD_BYTES + 32;
+
+/* launch geometry of a wavefront render (wpt_set_wavefront); 0 = default */
+struct WfConfig {
+    uint32_t groups, chunk, refillIdle, buckets, leafBias, stepBudget, topNodes;
+};
+struct WfLaunchers;
+/* The host side (wpt_wavefront_host.hip): renders the pixels of `args` (the lane -> pixel mapping of one launch of the
+ * single kernel) in wavefront form into args.frame.  Work is enqueued on streams of the calling thread's own that wait
+ * for `stream`; the call returns when the frame is complete (the number of iterations is only known as they run).
+ * *launches receives the number of kernel launches. */
+hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, const WfConfig& cfg, hipStream_t stream, uint32_t* launches);
+
+/* one launcher set per feature set, each in its own translation unit */
+struct WfLaunchers {
+    void (*trace)(const WfArgs&, dim3, hipStream_t);
+    void (*init)(const WfArgs&, dim3, hipStream_t);
+    void (*shade)(const WfArgs&, dim3, hipStream_t);
+    int (*traceBlocksPerCu)();
+};
+const WfLaunchers& wfBasic();
+const WfLaunchers& wfFull();
+const WfLaunchers& wfFullRgl();
+
+#define WPT_WF_LAUNCHERS(NAME, FEATURES, SPHERES, PAIRED)                                                                              \
+    static void NAME##Trace(const WfArgs& a, dim3 grid, hipStream_t s) { hipLaunchKernelGGL((wf_trace<SPHERES, PAIRED>), grid, dim3(WG), size_t(a.topNodes) * 32, s, a); } \
+    static void NAME##Init(const WfArgs& a, dim3 grid, hipStream_t s) { hipLaunchKernelGGL((wf_shade<FEATURES, true>), grid, dim3(WG), WF_SHADE_LDS, s, a); } \
+    static void NAME##Shade(const WfArgs& a, dim3 grid, hipStream_t s) { hipLaunchKernelGGL((wf_shade<FEATURES, false>), grid, dim3(WG), WF_SHADE_LDS, s, a); } \
+    static int NAME##TraceBlocks()                                                                                             \
+    {                                                                                                                          \
+        int perCu = 0;                                                                                                         \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, wf_trace<SPHERES, PAIRED>, (int)WG, 0) != hipSuccess)                 \
+            perCu = 0;                                                                                                         \
+        return perCu;                                                                                                          \
+    }                                                                                                                          \
+    const WfLaunchers& NAME()                                                                                                  \
+    {                                                                                                                          \
+        static const WfLaunchers l = { NAME##Trace, NAME##Init, NAME##Shade, NAME##TraceBlocks };                              \
+        return l;                                                                                                              \
+    }
+
+} /* namespace wptk */
+
+#endif

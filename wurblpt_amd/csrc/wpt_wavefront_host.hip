@@ -1,0 +1,210 @@
+/*
+ * wpt_wavefront_host.hip -- host side of the wavefront form (wpt_wavefront.inc.h): buffers, the groups' streams, the
+ * iteration loop.  An iteration of a group is two launches on the group's stream, trace then shade; how many
+ * iterations a frame takes is the largest number of rays one of its pixels traces, which only the device knows, so the
+ * host enqueues iterations in batches and reads the number of pixels still queued behind each batch -- one batch
+ * ahead, so that the device never waits for the host (the batches behind the last pixel are empty launches).
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include "wpt_wavefront.inc.h"
+
+namespace wptk {
+
+namespace {
+
+constexpr uint32_t BATCH = 32;        /* iterations between two looks at a group's queue length; divides WF_RING */
+constexpr uint32_t MAX_GROUPS = 8;
+
+/* per host thread and device: the groups' streams, events, and the pinned words the queue lengths are copied to */
+struct ThreadResources {
+    hipStream_t stream[MAX_GROUPS];
+    hipEvent_t batchDone[MAX_GROUPS][2];
+    hipEvent_t fork, join[MAX_GROUPS];
+    uint32_t* pinned; /* [MAX_GROUPS][2] */
+    bool ok;
+};
+
+ThreadResources* threadResources(int device)
+{
+    thread_local std::map<int, ThreadResources> perDevice;
+    auto it = perDevice.find(device);
+    if (it != perDevice.end())
+        return it->second.ok ? &it->second : nullptr;
+    ThreadResources r;
+    r.ok = true;
+    r.pinned = nullptr;
+    for (uint32_t g = 0; g < MAX_GROUPS && r.ok; g++) {
+        r.ok = r.ok && hipStreamCreateWithFlags(&r.stream[g], hipStreamNonBlocking) == hipSuccess;
+        r.ok = r.ok && hipEventCreateWithFlags(&r.batchDone[g][0], hipEventDisableTiming) == hipSuccess;
+        r.ok = r.ok && hipEventCreateWithFlags(&r.batchDone[g][1], hipEventDisableTiming) == hipSuccess;
+        r.ok = r.ok && hipEventCreateWithFlags(&r.join[g], hipEventDisableTiming) == hipSuccess;
+    }
+    r.ok = r.ok && hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess;
+    r.ok = r.ok && hipHostMalloc(reinterpret_cast<void**>(&r.pinned), MAX_GROUPS * 2 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    auto& stored = perDevice[device] = r;
+    return stored.ok ? &stored : nullptr;
+}
+
+struct Group {
+    WfArgs args;
+    uint32_t known;     /* upper bound of the pixels still queued (queues only shrink) */
+    uint32_t iteration; /* next iteration to enqueue */
+    bool active;
+};
+
+} /* namespace */
+
+hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, const WfConfig& cfg, hipStream_t stream, uint32_t* launches)
+{
+#define WF_TRY(expr)                  \
+    do {                              \
+        const hipError_t e_ = (expr); \
+        if (e_ != hipSuccess)         \
+            return e_;                \
+    } while (0)
+    uint32_t launched = 0;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess)
+        return hipErrorInvalidDevice;
+    ThreadResources* tr = threadResources(device);
+    if (!tr)
+        return hipErrorOutOfMemory;
+    const uint32_t lanes = args.blockSize;
+    /* groups of whole workgroups, none smaller than a quarter of what the device holds at once */
+    const uint32_t resident = std::max(1u, args.cuCount) * WF_TRACE_WAVES * WG;
+    uint32_t groupCount = cfg.groups ? cfg.groups : 2u;
+    groupCount = std::min(groupCount, MAX_GROUPS);
+    while (groupCount > 1 && lanes / groupCount < resident / 4u)
+        groupCount--;
+    const uint32_t perGroup = ((lanes + groupCount - 1) / groupCount + WG - 1) / WG * WG;
+    const uint32_t chunk = cfg.chunk ? cfg.chunk : 128u;
+    int perCu = kernels.traceBlocksPerCu();
+    perCu = perCu < 1 ? 1 : (perCu > WF_TRACE_WAVES ? WF_TRACE_WAVES : perCu);
+    if (const char* e = getenv("WPT_WF_TRACE_PER_CU")) /* experiments: workgroups of the trace per compute unit */
+        perCu = std::max(1, std::min(perCu, atoi(e)));
+    const uint32_t traceResident = uint32_t(perCu) * std::max(1u, args.cuCount);
+
+    float4* state = nullptr;
+    uint32_t* queues = nullptr;
+    WfIter* rings = nullptr;
+    std::vector<Group> groups;
+    const size_t queueWords = size_t(perGroup) * (2 + WF_BUCKETS);
+    auto body = [&]() -> hipError_t {
+    WF_TRY(hipMallocAsync(reinterpret_cast<void**>(&state), size_t(lanes) * WF_SLOTS * sizeof(float4), stream));
+    WF_TRY(hipMallocAsync(reinterpret_cast<void**>(&queues), queueWords * groupCount * sizeof(uint32_t), stream));
+    WF_TRY(hipMallocAsync(reinterpret_cast<void**>(&rings), size_t(groupCount) * WF_RING * sizeof(WfIter), stream));
+    WF_TRY(hipMemsetAsync(rings, 0, size_t(groupCount) * WF_RING * sizeof(WfIter), stream));
+    WF_TRY(hipEventRecord(tr->fork, stream));
+    for (uint32_t g = 0; g < groupCount; g++) {
+        Group gr;
+        gr.args.k = args;
+        gr.args.k.pool = nullptr;
+        gr.args.state = state;
+        uint32_t* q = queues + queueWords * g;
+        gr.args.rayQueue[0] = q;
+        gr.args.rayQueue[1] = q + perGroup;
+        gr.args.bucketQueue = q + 2 * size_t(perGroup);
+        gr.args.ring = rings + size_t(g) * WF_RING;
+        gr.args.laneFirst = g * perGroup;
+        gr.args.laneCount = gr.args.laneFirst < lanes ? std::min(perGroup, lanes - gr.args.laneFirst) : 0u;
+        gr.args.iteration = 0;
+        gr.args.buckets = cfg.buckets;
+        gr.args.chunk = chunk;
+        gr.args.refillIdle = cfg.refillIdle ? cfg.refillIdle : 16u;
+        gr.args.leafBias = cfg.leafBias ? cfg.leafBias : 32u;
+        gr.args.stepBudget = cfg.stepBudget == 0xffffffffu ? 0u : (cfg.stepBudget ? cfg.stepBudget : 512u);
+        /* the top of the tree in LDS: with the 8 KiB of staging, four workgroups per compute unit hold 32 KiB each */
+        gr.args.topNodes = cfg.topNodes == 0xffffffffu ? 0u : std::min(std::min(cfg.topNodes ? cfg.topNodes : 768u, 768u), args.sv.nodeCount);
+        gr.known = gr.args.laneCount;
+        gr.iteration = 0;
+        gr.active = gr.args.laneCount != 0;
+        groups.push_back(gr);
+        WF_TRY(hipStreamWaitEvent(tr->stream[g], tr->fork, 0));
+        if (gr.active) {
+            /* the first samples' camera rays; they are queued as iteration 0's rays */
+            groups[g].args.iteration = ~0u; /* appends to iteration 0's queue */
+            kernels.init(groups[g].args, dim3((gr.args.laneCount + WG - 1) / WG), tr->stream[g]);
+            launched++;
+        }
+    }
+    {
+        auto enqueueBatch = [&](uint32_t g, uint32_t parity) -> hipError_t {
+            Group& gr = groups[g];
+            hipStream_t s = tr->stream[g];
+            /* counters of the iterations this batch's shades append to: entries iteration + 1 .. iteration + BATCH of the
+             * ring (the batch's first entry holds the queue length the batch before left there) */
+            if (gr.iteration != 0) { /* the first batch finds the whole ring cleared */
+                const uint32_t from = (gr.iteration + 1) & (WF_RING - 1);
+                const uint32_t firstPiece = std::min(BATCH, WF_RING - from);
+                hipError_t e = hipMemsetAsync(gr.args.ring + from, 0, firstPiece * sizeof(WfIter), s);
+                if (e == hipSuccess && firstPiece < BATCH)
+                    e = hipMemsetAsync(gr.args.ring, 0, (BATCH - firstPiece) * sizeof(WfIter), s);
+                if (e != hipSuccess)
+                    return e;
+            }
+            const uint32_t traceGroups = std::max(1u, std::min(traceResident, (gr.known + chunk * (WG / 64) - 1) / (chunk * (WG / 64))));
+            const uint32_t shadeGroups = (gr.known + WG - 1) / WG + (gr.args.buckets ? WF_BUCKETS : 0u);
+            for (uint32_t i = 0; i < BATCH; i++) {
+                gr.args.iteration = gr.iteration + i;
+                kernels.trace(gr.args, dim3(traceGroups), s);
+                kernels.shade(gr.args, dim3(shadeGroups), s);
+            }
+            launched += 2 * BATCH;
+            gr.iteration += BATCH;
+            hipError_t e = hipMemcpyAsync(tr->pinned + 2 * g + parity, &gr.args.ring[gr.iteration & (WF_RING - 1)].rayCount, sizeof(uint32_t),
+                    hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess)
+                e = hipEventRecord(tr->batchDone[g][parity], s);
+            return e;
+        };
+        uint32_t parity = 0;
+        for (uint32_t g = 0; g < groupCount; g++)
+            if (groups[g].active)
+                WF_TRY(enqueueBatch(g, parity));
+        for (;;) {
+            /* one batch ahead: enqueue the next before waiting for the one in flight */
+            for (uint32_t g = 0; g < groupCount; g++)
+                if (groups[g].active)
+                    WF_TRY(enqueueBatch(g, parity ^ 1u));
+            bool any = false;
+            for (uint32_t g = 0; g < groupCount; g++) {
+                if (!groups[g].active)
+                    continue;
+                WF_TRY(hipEventSynchronize(tr->batchDone[g][parity]));
+                groups[g].known = tr->pinned[2 * g + parity];
+                if (groups[g].known == 0)
+                    groups[g].active = false; /* the batch already enqueued behind it finds empty queues */
+                else
+                    any = true;
+            }
+            parity ^= 1u;
+            if (!any)
+                break;
+        }
+    }
+    return hipGetLastError();
+    };
+    const hipError_t status = body();
+    /* the caller's stream goes on behind the groups' streams; the buffers are freed behind that */
+    for (uint32_t g = 0; g < groupCount && g < MAX_GROUPS; g++) {
+        if (hipEventRecord(tr->join[g], tr->stream[g]) == hipSuccess)
+            (void)hipStreamWaitEvent(stream, tr->join[g], 0);
+        if (status != hipSuccess)
+            (void)hipStreamSynchronize(tr->stream[g]);
+    }
+    for (void* p : { static_cast<void*>(state), static_cast<void*>(queues), static_cast<void*>(rings) })
+        if (p)
+            (void)hipFreeAsync(p, stream);
+    if (launches)
+        *launches = launched;
+    return status;
+#undef WF_TRY
+}
+
+} /* namespace wptk */
