@@ -3,23 +3,29 @@
 
 One "step" = one render of the whole frame of the workload (BASELINE.json configs[1] by
 default: Cornell box 1024x1024, 1024 spp, GGX tall box + glass short box) with the scene
-already resident in HBM.  N = 1: one launch covers the frame (the reference's single-process
+already resident in HBM.  N = 1: one render call covers the frame (the reference's single-process
 path hands out the whole frame as one block, mpi.hpp:241-254).  N > 1: one process per GPU
-(torch.distributed over RCCL); ranks pull pixel blocks from a shared counter in the c10d store
-(MPICoordinator::getBlock semantics, mpi.hpp:125-134), render them into a zero-initialised
-full frame on their GPU and the frames are summed onto rank 0 with one RCCL reduce
-(blocks are disjoint, so the sum is exact).  The frame is fixed, so scaling is "strong".
+(torch.distributed over RCCL); the frame is cut into bands of rows, band i goes to rank i mod N, every rank renders
+its bands in one call into a zero-initialised full frame on its GPU and the frames are summed onto rank 0 with one RCCL
+reduce (the bands are disjoint, so the sum is exact).  The frame is fixed, so scaling is "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline      the bound that binds the path-tracing kernel: scenes that fit LDS never touch HBM while they traverse,
                 so their line is priced against the vector pipes (bound "valu": executed lane-operations per second
                 from the committed PMC pass x the live sample rate, against 1024 SIMD-32 at 2.4 GHz); scenes in HBM
-                against the HBM roofline from ALGORITHMIC bytes.  The algorithmic GB/s is reported for
-                both as `algorithmic_gbps`.
-  cpu_baseline  the CPU restatement (oracle/, "port") timed on this box's host cores
+                against the HBM roofline from ALGORITHMIC bytes, with the memory-side rate of the committed
+                PMC pass and the share of wave time spent waiting beside it.  `pmc_matches_binary` says whether the
+                committed PMC pass was taken with the library that is running.
+  cpu_baseline  the CPU restatement (oracle/, "port") timed on this box's host cores on a block of the same frame
+  parity        that block of the GPU's frame against the oracle's, bit for bit
+  secondary     (N = 1) the same measurement of the Sponza-class workload (BASELINE configs[2]), whose scene is fetched
+                from HBM: value, ms_per_step, roofline, cpu_baseline, parity
+With --obj FILE.obj --envmap FILE.hdr the Sponza-class workload renders the real files the way wurblpt-sponza.cpp:46-71,145-148
+sets its scene up instead of the procedural stand-in.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -34,12 +40,13 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # "a wave issues each VALU instruction over 2 cycles"; 157.3 TFLOP/s f32 = 2 flops per lane-operation)
 VALU_PEAK_GLANEOPS = 256 * 4 * 32 * 2.4
 LDS_SCENE_MAX_BYTES = 20 * 1024  # wpt_pathtrace.inc.h: scenes up to this size are traversed from LDS
+SECONDARY = "sponza_like_1920x1080_256spp_envmap_is"
 
 WORKLOADS = {
     # name: (builder kwargs, width, height, samples_sqrt)
     "cornell_1024x1024_1024spp_ggx_glass": dict(kind="cornell", tall=1, short=2, width=1024, height=1024, samples_sqrt=32),
     "cornell_256x256_64spp_lambertian": dict(kind="cornell", tall=0, short=0, width=256, height=256, samples_sqrt=8),
-    # BASELINE configs[2]: procedural Sponza-class stand-in (the real OBJ is not available offline)
+    # BASELINE configs[2]: procedural Sponza-class stand-in (the real OBJ is not available offline; --obj / --envmap take it)
     "sponza_like_1920x1080_256spp_envmap_is": dict(kind="sponza", width=1920, height=1080, samples_sqrt=16),
     # BASELINE configs[3]: procedural San-Miguel-class stand-in, ~10 M triangles; 128 spp is not a perfect
     # square (spp = samplesSqrt^2, wurblpt.hpp:304), so 11^2 = 121 spp as SURVEY.md section 8(d) says
@@ -56,6 +63,17 @@ def build_scene(w):
         return host.cornell(w["width"], w["height"], w["tall"], w["short"])
     if w["kind"] == "sponza":
         return host.sponza_like(w["width"], w["height"], seed=1, detail=w.get("detail", 1.0))
+    if w["kind"] == "obj":
+        # wurblpt-sponza.cpp:46-59 (import transformation, environment map), :145-148 (camera)
+        if w.get("envmap"):
+            sc = host.import_obj_env(w["obj"], w["envmap"], w["width"], w["height"], (0.0, 1.7, 0.0), (0.0, 1.7, -1.0), 70.0,
+                                     scale=0.01, rotate_y_degrees=90.0, importance_n=w.get("importance_n", 512))
+        else:
+            sc = host.import_obj(w["obj"], w["width"], w["height"], (0.0, 1.7, 0.0), (0.0, 1.7, -1.0), 70.0,
+                                 scale=0.01, rotate_y_degrees=90.0, env_radiance=6.0)  # the constant environment of wurblpt-sponza.cpp:60-63
+        if sc is None:
+            raise SystemExit("cannot import %s (environment map %s)" % (w["obj"], w.get("envmap")))
+        return sc
     if w["kind"] == "measured":
         import importlib.util
         import tempfile
@@ -96,9 +114,22 @@ def host_cores():
     return cores
 
 
+def library_identity():
+    """Which build of the HIP library this process runs: path (WPT_LIB_DIR selects a second build), content hash, and
+    what it says about itself."""
+    from wurblpt_amd import device
+    path = device.lib_path()
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return {"path": os.path.relpath(path, ROOT), "sha256": h.hexdigest()[:16], "build": device.lib().wpt_build_info().decode()}
+
+
 def cpu_baseline(scene, w, target_seconds):
     """The CPU restatement on the host cores, on a bounded block of the same workload: a short
-    probe sizes the block so that the timed run takes about target_seconds."""
+    probe sizes the block so that the timed run takes about target_seconds.  Returns the record for the JSON line and
+    the oracle's frame with the block it rendered (start, pixels)."""
     from tests import oracle_loader
     orc = oracle_loader.load("portable")
     width, height = w["width"], w["height"]
@@ -111,18 +142,134 @@ def cpu_baseline(scene, w, target_seconds):
         start = max(0, (width * height - pixels) // 2)
         start -= start % width
         t0 = time.time()
-        _, cnt = orc.render(scene, w["samples_sqrt"], block=(start, pixels), threads=cores)
-        return cnt["samples"], time.time() - t0, start, pixels
+        frame, cnt = orc.render(scene, w["samples_sqrt"], block=(start, pixels), threads=cores)
+        return cnt["samples"], time.time() - t0, start, pixels, frame
 
-    n, dt, _, _ = run(4 * width)
+    n, dt, _, _, _ = run(4 * width)
     rate = n / max(dt, 1e-3)
     want = int(rate * target_seconds / (w["samples_sqrt"] ** 2))
-    n, dt, start, pixels = run(max(4 * width, want))
-    return {
+    n, dt, start, pixels, frame = run(max(4 * width, want))
+    record = {
         "value": n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": "%d pixels (rows %d-%d) x %d spp of the same frame, %.1f s" % (
             pixels, start // width, (start + pixels - 1) // width, w["samples_sqrt"] ** 2, dt),
     }
+    return record, frame, start, pixels
+
+
+def parity_of(gpu_frame, oracle_frame, start, pixels, width):
+    """The block the oracle rendered against the same pixels of the GPU's frame: differing values (bit patterns) and
+    rel-L2 (a timed GPU run carries its parity)."""
+    import numpy as np
+    a = np.ascontiguousarray(gpu_frame.reshape(-1, 3)[start:start + pixels])
+    b = np.ascontiguousarray(oracle_frame.reshape(-1, 3)[start:start + pixels])
+    differ = int((a.view(np.uint32) != b.view(np.uint32)).sum())
+    norm = float(np.sqrt((b.astype(np.float64) ** 2).sum()))
+    rel = float(np.sqrt(((a.astype(np.float64) - b.astype(np.float64)) ** 2).sum()) / norm) if norm > 0 else 0.0
+    return {"rows": "%d-%d" % (start // width, (start + pixels - 1) // width), "pixels": pixels, "values": int(a.size), "bits_differ": differ,
+            "rel_l2": rel, "max_abs": float(np.abs(a - b).max()) if a.size else 0.0, "against": "oracle (CPU restatement), same seeds"}
+
+
+def load_pmc(name):
+    """Per launch of this workload, from the committed rocprofv3 PMC passes (separate runs; tools/profile_round.sh +
+    tools/collect_profiles.py): HBM bytes (FETCH_SIZE / WRITE_SIZE), vector instructions (SQ_INSTS_VALU), the fraction
+    of lanes active in them (VALUUtilization), the share of wave time spent waiting, and the library they were taken with."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        return json.load(open(tpath)).get("workloads", {}).get(name, {})
+    except Exception:
+        return {}
+
+
+def roofline_of(name, scene, cnt, spp, count_sqrt, avg_ms, avg_samples, n_launches, basis, lib_id, device, with_pmc=True):
+    width, height = scene.width, scene.height
+    bps, _ = bytes_per_sample(cnt, scene, spp)
+    achieved = bps * avg_samples / (avg_ms * 1e-3) / 1e9 if n_launches else 0.0
+    pmc = load_pmc(name) if with_pmc else {}
+    traffic = pmc.get("hbm_bytes_per_launch")
+    in_lds = int(scene.d.node_count) * 32 + int(scene.d.tri_count) * 48 <= LDS_SCENE_MAX_BYTES
+    per_sample = {k: cnt[k] / float(cnt["samples"]) for k in ("rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")}
+    common = {"traffic": traffic, "basis": basis, "kernel": device.lib().wpt_kernel_name().decode(), "avg_launch_ms": avg_ms,
+              "launches": n_launches, "kernel_launches_per_launch": int(device.lib().wpt_last_render_passes()), "bytes_per_sample": bps,
+              "algorithmic_gbps": achieved, "per_sample": per_sample, "counted_on": "%dx%d x %d spp" % (width, height, count_sqrt ** 2),
+              # the committed PMC pass describes this build only if it was taken with this very library
+              "pmc_matches_binary": bool(pmc) and pmc.get("library_sha256") == lib_id["sha256"], "pmc_library_sha256": pmc.get("library_sha256")}
+    if in_lds and pmc.get("valu_insts_per_sample") and n_launches:
+        # the scene is LDS resident: what binds is vector issue.  Executed lane-operations = wave instructions x 64 lanes x
+        # the fraction of lanes active in them (both from the committed PMC pass of this workload), at the live sample rate
+        lane_ops = pmc["valu_insts_per_sample"] * 64.0 * pmc["valu_active_lane_fraction"] * avg_samples / (avg_ms * 1e-3) / 1e9
+        roofline = dict(common, bound="valu", achieved=lane_ops, peak=VALU_PEAK_GLANEOPS, unit="Glane-op/s", frac=lane_ops / VALU_PEAK_GLANEOPS,
+                        issue_slot_frac=pmc["valu_insts_per_sample"] * 2.0 * avg_samples / (avg_ms * 1e-3) / (1024 * 2.4e9),
+                        active_lane_fraction=pmc["valu_active_lane_fraction"], valu_insts_per_sample=pmc["valu_insts_per_sample"],
+                        note="scene in LDS: HBM sees the frame only (traffic); frac = issue_slot_frac x active_lane_fraction; "
+                             "counters from " + pmc.get("pmc_file", "profiles/") + ("" if common["pmc_matches_binary"] else
+                             " -- taken with ANOTHER build of the library: instruction count and lane fraction may be stale"))
+    else:
+        roofline = dict(common, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s", frac=min(1.0, achieved / HBM_PEAK_GBPS))
+        if in_lds:
+            roofline["note"] = "scene in LDS and no committed PMC pass for this workload: algorithmic bytes never reach HBM, frac is capped at 1"
+        else:
+            roofline["note"] = ("frac prices ALGORITHMIC bytes (SURVEY 8d: the reference's record sizes and walk) against the HBM peak; what the "
+                                "memory side really moved is hbm_gbps_from_traffic / hbm_frac_from_traffic (L2 misses incl. Infinity-Cache hits), "
+                                "and wait_any_share of the waves' time was spent parked at s_waitcnt: a scene that fits the caches is bound by "
+                                "the latency and request rate of dependent node fetches, not by HBM bandwidth")
+        if traffic and n_launches:
+            roofline["hbm_gbps_from_traffic"] = traffic / (avg_ms * 1e-3) / 1e9
+            roofline["hbm_frac_from_traffic"] = roofline["hbm_gbps_from_traffic"] / HBM_PEAK_GBPS
+        for k in ("wait_any_share", "l2_hit_rate", "valu_active_lane_fraction", "valu_busy_percent"):
+            if pmc.get(k) is not None:
+                roofline[k] = pmc[k]
+    return roofline
+
+
+def measure_one_gpu(name, w, scene, dscene, steps, warmup, cpu_seconds, lib_id, torch, device, host, barrier=None):
+    """W untimed + K timed renders of the workload's frame on this GPU (one render call each), the counted pass for the
+    roofline, the CPU baseline on a block of the same frame and the parity of that block."""
+    width, height, ssqrt = w["width"], w["height"], w["samples_sqrt"]
+    spp, pixels = ssqrt * ssqrt, width * height
+    params = host.default_params()
+    frame = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+    # counted pass (untimed): work per sample for the roofline's algorithmic bytes; the counting build renders the timed
+    # frame, sample for sample
+    counters = torch.zeros(6, dtype=torch.int64, device="cuda")
+    dscene.render_block_into(frame, ssqrt, None, params, counters, stream)
+    torch.cuda.synchronize()
+    cnt = dict(zip(("samples", "rays", "node_visits", "leaf_tests", "pdf_tests", "scatters"), [int(x) for x in counters.cpu().tolist()]))
+    frame.zero_()
+    events = []
+
+    def step(timed):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        dscene.render_block_into(frame, ssqrt, None, params, None, stream)
+        e1.record(stream)
+        if timed:
+            events.append((e0, e1))
+
+    sync = barrier or torch.cuda.synchronize
+    for _ in range(warmup):
+        step(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ms = [a.elapsed_time(b) for a, b in events]
+    avg_ms = sum(ms) / max(1, len(ms))
+    basis = ("algorithmic bytes of one launch / its duration (HIP events on the launch's stream); a launch is one render call: "
+             "kernel_launches_per_launch launches of the kernel(s), whose durations add up to it")
+    out = {
+        "value": float(pixels) * spp * steps / elapsed / 1e6, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
+        "roofline": roofline_of(name, scene, cnt, spp, ssqrt, avg_ms, float(pixels) * spp, len(ms), basis, lib_id, device),
+        "frame_finite": bool(torch.isfinite(frame).all().item()),
+    }
+    if cpu_seconds > 0:
+        record, oracle_frame, start, block = cpu_baseline(scene, w, cpu_seconds)
+        out["cpu_baseline"] = record
+        out["parity"] = parity_of(frame.cpu().numpy(), oracle_frame, start, block, width)
+    return out, frame
 
 
 def main():
@@ -134,6 +281,10 @@ def main():
     ap.add_argument("--samples-sqrt", type=int, default=0, help="override spp (debug only; changes the workload name)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: do not measure the Sponza-class workload beside the primary one")
+    ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--obj", default=None, help="the real Sponza OBJ file: the Sponza-class workload imports it (wurblpt-sponza.cpp:46-71) instead of the procedural stand-in")
+    ap.add_argument("--envmap", default=None, help="environment map image for --obj (HDR / EXR / PFM); without it the constant environment of wurblpt-sponza.cpp:60-63")
     ap.add_argument("--streams", type=int, default=8, help="concurrent block launches per GPU when N > 1")
     ap.add_argument("--force-blocks", type=int, default=0, metavar="RANKS",
                     help="N = 1 only (rehearsal): run the N > 1 code path -- block queue, worker threads, streams -- as if RANKS ranks shared the frame; this process renders every block")
@@ -142,6 +293,7 @@ def main():
     ap.add_argument("--verify", action="store_true",
                     help="after the timed steps rank 0 renders the frame once more in a single launch and compares (bit for bit)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant / scheduler tuning word for wpt_set_launch_config (experiments)")
+    ap.add_argument("--wavefront", type=int, default=0, help="wpt_set_wavefront mode: 0 = the library decides, 1 = wavefront kernels wherever they exist, 2 = never")
     ap.add_argument("--top-nodes", type=int, default=-1, help="BVH nodes stored level by level in front of the array (wpt_set_top_nodes; experiments)")
     args = ap.parse_args()
 
@@ -166,18 +318,30 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the path tracer has no CPU fallback"
     # rehearsal on a one-GPU box: WPT_BENCH_DEVICE=0 WPT_BENCH_BACKEND=gloo puts every rank on cuda:0
     # (RCCL refuses two ranks on one device); the driver's runs use neither
-    if "WPT_BENCH_DEVICE" in os.environ:
+    rehearsal = "WPT_BENCH_DEVICE" in os.environ
+    if rehearsal:
         local_rank = int(os.environ["WPT_BENCH_DEVICE"])
     backend = os.environ.get("WPT_BENCH_BACKEND", "nccl")
+    if world > 1 and backend == "nccl" and not rehearsal:
+        # one rank per GPU of this node: a rank without a device of its own would render on somebody else's
+        assert torch.cuda.device_count() >= world and local_rank < torch.cuda.device_count(), \
+            "%d ranks need %d GPUs on this node, %d are visible" % (world, world, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world and dist.get_rank() == rank
 
-    w = dict(WORKLOADS[args.workload])
-    name = args.workload
+    def workload(name):
+        w = dict(WORKLOADS[name])
+        if args.obj and w["kind"] == "sponza":
+            w.update(kind="obj", obj=args.obj, envmap=args.envmap)
+            name = "sponza_obj_%s_%dx%d_%dspp" % (os.path.splitext(os.path.basename(args.obj))[0], w["width"], w["height"], w["samples_sqrt"] ** 2)
+        return name, w
+
+    name, w = workload(args.workload)
     if args.samples_sqrt:
         w["samples_sqrt"] = args.samples_sqrt
         name += "_override%dspp" % (args.samples_sqrt ** 2)
@@ -190,7 +354,7 @@ def main():
         from wurblpt_amd import scenefile
         shared = "/dev/shm/wpt_bench_scene_%s.bin" % os.environ.get("MASTER_PORT", "0")
         t_build = time.perf_counter()
-        scene = scenefile.build_once(lambda: build_scene(w), shared, rank, dist.barrier)
+        scene = scenefile.build_once(lambda: build_scene(w), shared, rank, dist.barrier, dist.broadcast_object_list)
         t_build = time.perf_counter() - t_build
     else:
         t_build = time.perf_counter()
@@ -198,53 +362,85 @@ def main():
         t_build = time.perf_counter() - t_build
     if args.variant:
         device.lib().wpt_set_launch_config(0, args.variant)
+    if args.wavefront:
+        device.lib().wpt_set_wavefront(args.wavefront, 0, 0, 0)
     if args.top_nodes >= 0:
         device.lib().wpt_set_top_nodes(args.top_nodes)
+    lib_id = library_identity()
     dscene = device.DeviceScene(scene)
     params = host.default_params()
+    cpu_seconds = 0.0 if args.no_cpu_baseline else args.cpu_seconds
+    config = {"workload": name, "width": width, "height": height, "spp": spp, "triangles": int(scene.d.tri_count), "bvh_nodes": int(scene.d.node_count)}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sharded = world > 1 or args.force_blocks > 0
+    if not sharded:
+        # ---- N = 1: one render call per step ----
+        m, frame = measure_one_gpu(name, w, scene, dscene, args.steps, args.warmup, cpu_seconds, lib_id, torch, device, host, barrier)
+        verified = None
+        out = {
+            "metric": "Msamples/s", "value": m["value"], "unit": "Msamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": dict(config, parallelism="1 launch"), "roofline": m["roofline"], "frame_finite": m["frame_finite"],
+            "scene_build_s": t_build, "library": lib_id,
+        }
+        for k in ("cpu_baseline", "parity"):
+            if k in m:
+                out[k] = m[k]
+        if not args.no_secondary and args.workload != SECONDARY and not args.samples_sqrt:
+            # the Sponza-class workload under the same clock: its scene is fetched from HBM (the primary one lives in LDS)
+            del dscene, frame
+            sname, sw = workload(SECONDARY)
+            t2 = time.perf_counter()
+            sscene = build_scene(sw)
+            t2 = time.perf_counter() - t2
+            sd = device.DeviceScene(sscene)
+            sm, _ = measure_one_gpu(sname, sw, sscene, sd, args.secondary_steps, 1, min(cpu_seconds, 8.0), lib_id, torch, device, host)
+            sm.update(workload=sname, unit="Msamples/s", scene_build_s=t2,
+                      config={"workload": sname, "width": sw["width"], "height": sw["height"], "spp": sw["samples_sqrt"] ** 2,
+                              "triangles": int(sscene.d.tri_count), "bvh_nodes": int(sscene.d.node_count), "parallelism": "1 launch"})
+            out["secondary"] = [sm]
+        print(json.dumps(out), flush=True)
+        return
+
+    # ---- N > 1 (or its rehearsal on one GPU): the frame is shared out ----
     frame = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
     main_stream = torch.cuda.current_stream()
-
-    # ---- counted pass (untimed): work per sample for the roofline's algorithmic bytes ----
-    count_sqrt = ssqrt  # the counting build renders the timed frame, sample for sample
     counters = torch.zeros(6, dtype=torch.int64, device="cuda")
-    dscene.render_block_into(frame, count_sqrt, None, params, counters, main_stream)
+    dscene.render_block_into(frame, ssqrt, None, params, counters, main_stream)  # counted pass (untimed), the whole frame
     torch.cuda.synchronize()
     cnt = dict(zip(("samples", "rays", "node_visits", "leaf_tests", "pdf_tests", "scatters"), [int(x) for x in counters.cpu().tolist()]))
-    bps, tri_bytes = bytes_per_sample(cnt, scene, spp)
-
-    # ---- the step ----
-    kernel_ms = []  # (milliseconds, samples) per launch on this rank, timed steps only
+    kernel_ms = []   # (event, event, samples) per render call on this rank, timed steps only
+    reduce_ms = []   # host-timed seconds of the frame reduce per timed step
     from wurblpt_amd import blocks
-    sharded = world > 1 or args.force_blocks > 0
     store = dist.distributed_c10d._get_default_store() if world > 1 else None
-    streams = [torch.cuda.Stream() for _ in range(args.streams)] if sharded else []
-    block_size = blocks.plan_block_size(pixels, width, max(world, args.force_blocks), args.streams) if sharded else pixels
+    streams = [torch.cuda.Stream() for _ in range(args.streams)]
+    block_size = blocks.plan_block_size(pixels, width, max(world, args.force_blocks), args.streams)
+    band_rows = max(1, block_size // width)
+    bands = -(-height // band_rows)
+    my_pixels = sum(min(band_rows, height - b * band_rows) for b in range(rank, bands, world)) * width if world > 1 else pixels
 
     def step(index, timed):
-        if not sharded:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(main_stream)
-            dscene.render_block_into(frame, ssqrt, None, params, None, main_stream)
-            e1.record(main_stream)
-            if timed:
-                kernel_ms.append((e0, e1, pixels * spp))
-            return
         frame.zero_()
         torch.cuda.synchronize()
         if world > 1 and not args.dynamic_blocks:
             # this rank's interleaved share (band i to rank i mod N) in one launch
-            band_rows = max(1, block_size // width)
-            bands = -(-height // band_rows)
-            mine = sum(min(band_rows, height - b * band_rows) for b in range(rank, bands, world)) * width
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main_stream)
             dscene.render_bands_into(frame, ssqrt, band_rows, rank, world, params, None, main_stream)
             e1.record(main_stream)
             torch.cuda.synchronize()
             if timed:
-                kernel_ms.append((e0, e1, mine * spp))
+                kernel_ms.append((e0, e1, my_pixels * spp))
+            t = time.perf_counter()
             blocks.reduce_frame(frame, dst=0)
+            torch.cuda.synchronize()
+            if timed:
+                reduce_ms.append(time.perf_counter() - t)
             return
         if args.dynamic_blocks or world == 1:
             queue = blocks.BlockQueue(pixels, block_size, store, "wpt_block_counter_%d" % index)
@@ -264,12 +460,11 @@ def main():
 
         blocks.render_sharded(queue, render_block, len(streams))
         torch.cuda.synchronize()
+        t = time.perf_counter()
         blocks.reduce_frame(frame, dst=0)  # final framebuffer reduce over xGMI
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
         torch.cuda.synchronize()
+        if timed:
+            reduce_ms.append(time.perf_counter() - t)
 
     for i in range(args.warmup):
         step(i, False)
@@ -279,6 +474,9 @@ def main():
         step(args.warmup + i, True)
     barrier()
     elapsed = time.perf_counter() - t0
+    launches = [(a.elapsed_time(b), s) for a, b, s in kernel_ms]
+    # per rank: its kernel time per step, its reduce time per step, how many of its pixels there are per lane of its GPU
+    per_rank = blocks.rank_stats(sum(m for m, _ in launches) / max(1, args.steps), 1e3 * sum(reduce_ms) / max(1, len(reduce_ms)), my_pixels, "cuda")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -292,81 +490,41 @@ def main():
         dscene.render_block_into(whole, ssqrt, None, params, None, main_stream)
         torch.cuda.synchronize()
         verified = bool(torch.equal(whole.view(torch.int32), frame.view(torch.int32)))
-    launches = [(a.elapsed_time(b), s) for a, b, s in kernel_ms]
     if rank == 0:
         total_samples = float(pixels) * spp * args.steps
         avg_ms = sum(m for m, _ in launches) / max(1, len(launches))
         avg_samples = sum(s for _, s in launches) / max(1, len(launches))
-        achieved = bps * avg_samples / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         basis = ("algorithmic bytes of one launch / its duration (HIP events on the launch's stream); a launch is one render call: "
-                 "kernel_launches_per_launch launches of the kernel, whose durations add up to it")
-        if sharded and launches and (args.dynamic_blocks or world == 1):
+                 "kernel_launches_per_launch launches of the kernel(s), whose durations add up to it")
+        if launches and (args.dynamic_blocks or world == 1):
             # this rank's launches overlap on its streams: price its whole share against the timed region instead
-            achieved = bps * sum(s for _, s in launches) / elapsed / 1e9
+            avg_ms = elapsed * 1e3
+            avg_samples = sum(s for _, s in launches)
             basis = "algorithmic bytes of rank 0's %d overlapping launches / the timed region" % len(launches)
-        traffic = None
-        pmc = {}
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and world == 1:
-            # per launch of this workload, from the committed rocprofv3 PMC passes (separate runs;
-            # tools/profile_round.sh + tools/collect_profiles.py): HBM bytes (FETCH_SIZE / WRITE_SIZE), vector
-            # instructions (SQ_INSTS_VALU) and the fraction of lanes active in them (VALUUtilization)
-            try:
-                pmc = json.load(open(tpath)).get("workloads", {}).get(name, {})
-                traffic = pmc.get("hbm_bytes_per_launch")
-            except Exception:
-                pmc, traffic = {}, None
-        in_lds = int(scene.d.node_count) * 32 + int(scene.d.tri_count) * 48 <= LDS_SCENE_MAX_BYTES
-        counted = "%dx%d x %d spp" % (width, height, count_sqrt ** 2)
-        per_sample = {k: cnt[k] / float(cnt["samples"]) for k in ("rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")}
-        common = {"traffic": traffic, "basis": basis, "kernel": device.lib().wpt_kernel_name().decode(), "avg_launch_ms": avg_ms,
-                  "launches": len(launches), "kernel_launches_per_launch": int(device.lib().wpt_last_render_passes()), "bytes_per_sample": bps, "algorithmic_gbps": achieved, "per_sample": per_sample, "counted_on": counted}
-        if in_lds and pmc.get("valu_insts_per_sample") and launches:
-            # the scene is LDS resident: what binds is vector issue.  Executed lane-operations = wave instructions x 64 lanes x
-            # the fraction of lanes active in them (both from the committed PMC pass of this workload), at the live sample rate
-            lane_ops = pmc["valu_insts_per_sample"] * 64.0 * pmc["valu_active_lane_fraction"] * avg_samples / (avg_ms * 1e-3) / 1e9
-            roofline = dict(common, bound="valu", achieved=lane_ops, peak=VALU_PEAK_GLANEOPS, unit="Glane-op/s", frac=lane_ops / VALU_PEAK_GLANEOPS,
-                            issue_slot_frac=pmc["valu_insts_per_sample"] * 2.0 * avg_samples / (avg_ms * 1e-3) / (1024 * 2.4e9),
-                            active_lane_fraction=pmc["valu_active_lane_fraction"], valu_insts_per_sample=pmc["valu_insts_per_sample"],
-                            note="scene in LDS: HBM sees the frame only (traffic); frac = issue_slot_frac x active_lane_fraction; "
-                                 "counters from " + pmc.get("pmc_file", "profiles/"))
-        else:
-            roofline = dict(common, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s", frac=min(1.0, achieved / HBM_PEAK_GBPS))
-            if in_lds:
-                roofline["note"] = "scene in LDS and no committed PMC pass for this workload: algorithmic bytes never reach HBM, frac is capped at 1"
-            if traffic and launches:
-                roofline["hbm_gbps_from_traffic"] = traffic / (avg_ms * 1e-3) / 1e9
+        roofline = roofline_of(name, scene, cnt, spp, ssqrt, avg_ms, avg_samples, len(launches), basis, lib_id, device, with_pmc=(world == 1))
         out = {
             "metric": "Msamples/s", "value": total_samples / elapsed / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "width": width, "height": height, "spp": spp,
-                       "triangles": int(scene.d.tri_count), "bvh_nodes": int(scene.d.node_count),
-                       "parallelism": "1 launch" if world == 1 else (
-                           "pixel blocks of %d from a shared counter over %d GPUs (%d streams each) + RCCL reduce" % (block_size, world, args.streams)
-                           if args.dynamic_blocks else
-                           "bands of %d rows, band i to rank i mod %d, one launch per GPU + RCCL reduce" % (max(1, block_size // width), world))},
+            "config": dict(config, parallelism=(
+                "pixel blocks of %d from a shared counter over %d GPUs (%d streams each) + RCCL reduce" % (block_size, world, args.streams)
+                if (args.dynamic_blocks or world == 1) else
+                "bands of %d rows, band i to rank i mod %d, one launch per GPU + RCCL reduce" % (band_rows, world))),
             "roofline": roofline,
             "frame_finite": ok,
+            # what a step's time is made of, per rank: the rank's render call(s), then the reduce; the step ends with the slowest rank
+            "per_rank": per_rank,
+            "backend": backend,
             # host side, untimed: rank 0 builds and flattens the scene; with N > 1 this includes saving it to /dev/shm and
             # the barrier the other ranks wait at before they map it
-            "scene_build_s": t_build,
+            "scene_build_s": t_build, "library": lib_id, "cpu_baseline": None,
         }
         if verified is not None:
             out["frame_equals_single_launch"] = verified
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scene, w, args.cpu_seconds)
-        elif world > 1:
-            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        if rank == 0:
-            try:
-                os.remove(shared)  # /dev/shm is memory
-            except OSError:
-                pass
         dist.destroy_process_group()
 
 

@@ -29,9 +29,23 @@ built = []
 def build():
     built.append(rank)
     return host.cornell(W, H, 1, 2)
-sc = scenefile.build_once(build, sys.argv[1] + ".scene", rank, dist.barrier)
+sc = scenefile.build_once(build, sys.argv[1] + ".scene", rank, dist.barrier, dist.broadcast_object_list)
 assert built == ([0] if rank == 0 else []), built
 assert isinstance(sc, scenefile.FileScene) == (rank != 0)
+assert not os.path.exists(sys.argv[1] + ".scene")      # removed as soon as every rank has mapped it
+# a build that fails on rank 0 raises on EVERY rank instead of leaving the others at a barrier
+def broken():
+    raise ValueError("no such scene")
+try:
+    scenefile.build_once(broken, sys.argv[1] + ".broken", rank, dist.barrier, dist.broadcast_object_list)
+    raise SystemExit("a failed build went unnoticed on rank " + str(rank))
+except RuntimeError as e:
+    assert "no such scene" in str(e), e
+# what bench.py reports per rank for N > 1 (one all_gather)
+stats = blocks.rank_stats(10.0 + rank, 0.5 * (rank + 1), 1000 * (rank + 1))
+assert stats["kernel_ms_per_step"] == {"min": 10.0, "mean": 10.5, "max": 11.0, "all": [10.0, 11.0]}, stats
+assert stats["reduce_ms_per_step"] == {"max": 1.0, "all": [0.5, 1.0]} and len(stats["pixels_per_lane"]) == world
+assert abs(stats["pixels_per_lane"][1] - 2000.0 / blocks.LANES_PER_GPU) < 1e-12
 orc = oracle_loader.load("portable")
 frame = torch.zeros((H, W, 3), dtype=torch.float32)
 store = dist.distributed_c10d._get_default_store()

@@ -258,6 +258,28 @@ def test_import_into_scene_structure_and_material_rules(oracle):
     assert host.import_obj(os.path.join(OBJ_DIR, "nothing_here.obj"), 8, 8, (0, 0, 1), (0, 0, 0)) is None
 
 
+def test_import_with_an_environment_map_file(tmp_path, oracle):
+    """wurblpt-sponza.cpp:46-59: the imported scene under an environment map read from an image file (what bench.py --obj
+    --envmap builds): the texture is the file's texels, importance sampling is set up on request, the frame is lit by it."""
+    rng = np.random.default_rng(3)
+    sky = (rng.random((16, 32, 3)) * 4.0).astype(np.float32)
+    env = str(tmp_path / "sky.pfm")
+    assert host.image_save(env, sky)
+    sc = host.import_obj_env(os.path.join(OBJ_DIR, "scene.obj"), env, 24, 16, (0.0, 1.0, 3.0), (0.0, 1.0, 0.0), 50.0, importance_n=8)
+    assert sc is not None
+    d = sc.d
+    assert d.envmap.type != 0 and d.envmap.N == 8
+    tex = d.textures[d.envmap.tex]
+    assert (tex.width, tex.height, tex.comps) == (32, 16, 3)
+    plain = host.import_obj_env(os.path.join(OBJ_DIR, "scene.obj"), env, 24, 16, (0.0, 1.0, 3.0), (0.0, 1.0, 0.0), 50.0)
+    assert plain.d.envmap.N == 0
+    sc.set_envmap_tables(*oracle.envmap_tables(sc))
+    img, _ = oracle.render(sc, 3)
+    dark, _ = oracle.render(_fixture_scene(), 3)
+    assert np.isfinite(img).all() and img.mean() > dark.mean()
+    assert host.import_obj_env(os.path.join(OBJ_DIR, "scene.obj"), str(tmp_path / "nothing.hdr"), 8, 8, (0, 0, 1), (0, 0, 0)) is None
+
+
 def _png_pixels(path):
     """Independent PNG reader (zlib + the five filters not needed: writers here use filter 0)."""
     import struct

@@ -32,7 +32,7 @@ def counters(suffix):
         if not os.path.exists(f):
             continue
         for r in csv.DictReader(open(f)):
-            if "wpt_pathtrace" in r["Kernel_Name"]:
+            if "wpt_pathtrace" in r["Kernel_Name"] or "wf_trace" in r["Kernel_Name"] or "wf_shade" in r["Kernel_Name"]:
                 k = r["Kernel_Name"].split("(")[0].replace("void ", "")
                 raw[(k, r["Counter_Name"])].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     agg = {}
@@ -53,10 +53,12 @@ for letter, (short, workload) in WORK.items():
     if os.path.exists(st):
         shutil.copy(st, os.path.join(OUT, "%s_kernel_stats_%s.csv" % (prefix, short)))
     log = os.path.join(ROOT, "gpurun_out", "stats_%s_%s.log" % (tag, short))
+    library = None  # the build of the HIP library the profiled command ran (bench.py prints it): what ties the counters to a binary
     if os.path.exists(log):
         lines = [l for l in open(log) if l.startswith("{\"metric\"")]
         if lines:
             open(os.path.join(OUT, "%s_bench_under_rocprof_%s.json" % (prefix, short)), "w").write(lines[-1])
+            library = json.loads(lines[-1]).get("library")
     agg = counters(tag + letter)
     if not agg:
         continue
@@ -75,6 +77,12 @@ for letter, (short, workload) in WORK.items():
             "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_%s.txt); "
                    "FETCH_SIZE x 2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KiB -> bytes" % (prefix, short)}
         mean = lambda c: agg[(k, c)][0] if (k, c) in agg else None
+        if library:
+            traffic[workload].update({"library_sha256": library["sha256"], "library_build": library["build"]})
+        if mean("SQ_WAIT_ANY") and mean("SQ_WAVE_CYCLES"):
+            traffic[workload]["wait_any_share"] = mean("SQ_WAIT_ANY") / mean("SQ_WAVE_CYCLES")
+        if mean("TCC_HIT_sum") and mean("TCC_MISS_sum") is not None:
+            traffic[workload]["l2_hit_rate"] = mean("TCC_HIT_sum") / (mean("TCC_HIT_sum") + mean("TCC_MISS_sum"))
         if mean("SQ_INSTS_VALU") and mean("VALUUtilization") and letter in SAMPLES:
             traffic[workload].update({
                 "valu_insts_per_sample": mean("SQ_INSTS_VALU") / SAMPLES[letter],

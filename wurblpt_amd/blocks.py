@@ -122,3 +122,26 @@ def reduce_frame(frame, dst=0):
         else:
             dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
     return frame
+
+
+LANES_PER_GPU = 256 * 4 * 4 * 64  # lanes an MI355X holds at four waves per SIMD (256 CUs x 4 SIMDs x 4 waves x 64)
+
+
+def rank_stats(kernel_ms_per_step, reduce_ms_per_step, my_pixels, device="cpu"):
+    """What a step's time is made of, rank by rank (one all_gather): each rank's render time per step, its reduce time
+    per step and how many of its pixels there are per lane of its GPU -- a pixel is one serial sequence of samples, so
+    below one pixel per lane a GPU cannot be filled.  Every rank gets the same record; a single process gets its own."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([float(kernel_ms_per_step), float(reduce_ms_per_step), float(my_pixels) / LANES_PER_GPU], dtype=torch.float64, device=device)
+    rows = [mine]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        rows = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, mine)
+    rows = [[float(x) for x in r.cpu().tolist()] for r in rows]
+    kms = [r[0] for r in rows]
+    return {"kernel_ms_per_step": {"min": min(kms), "mean": sum(kms) / len(kms), "max": max(kms), "all": kms},
+            "reduce_ms_per_step": {"max": max(r[1] for r in rows), "all": [r[1] for r in rows]},
+            "pixels_per_lane": [r[2] for r in rows],
+            "note": "pixels_per_lane: a rank's pixels over the %d lanes its GPU holds at four waves per SIMD; a pixel is one serial "
+                    "sequence of samples, so below 1 the GPU cannot be filled" % LANES_PER_GPU}

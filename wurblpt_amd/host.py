@@ -244,6 +244,18 @@ def import_obj(filename, width, height, eye, at, vfov_degrees=45.0, import_bits=
     return HostScene(h, width, height, "import_obj(%s)" % os.path.basename(filename)) if h else None
 
 
+def import_obj_env(filename, envmap, width, height, eye, at, vfov_degrees=45.0, import_bits=0, scale=1.0, rotate_y_degrees=0.0, importance_n=0):
+    """importIntoScene of an OBJ file under an environment map read from an image file, as wurblpt-sponza.cpp:46-59 sets
+    its scene up; importance_n > 0: initializeImportanceSampling(importance_n).  None if a file cannot be read."""
+    L = lib()
+    L.wpt_host_import_obj_env.restype = C.c_void_p
+    L.wpt_host_import_obj_env.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_uint, C.c_uint]
+    e = (C.c_float * 3)(*eye)
+    a = (C.c_float * 3)(*at)
+    h = L.wpt_host_import_obj_env(filename.encode(), envmap.encode(), importance_n, import_bits, scale, rotate_y_degrees, e, a, vfov_degrees, width, height)
+    return HostScene(h, width, height, "import_obj_env(%s, %s)" % (os.path.basename(filename), os.path.basename(envmap))) if h else None
+
+
 def image_load(filename):
     """Decodes an image file with the importer's decoders: numpy array [h, w, comps], row 0 = bottom."""
     L = lib()

@@ -245,3 +245,25 @@ extern "C" wpt_host_scene* wpt_host_import_obj(const char* objFile, unsigned int
     }
     return wptHostFinish(scene, width, height, radians(vfovDegrees), vec3(eye), vec3(at), 0.0f, 1.0f);
 }
+
+/* The same with an environment map from an image file (Radiance HDR, OpenEXR, PFM, ...) as wurblpt-sponza.cpp:46-59 sets
+ * one up, and importance sampling of it where importanceN > 0 (wurblpt-envmap.cpp:76). */
+extern "C" wpt_host_scene* wpt_host_import_obj_env(const char* objFile, const char* envFile, int importanceN, unsigned int importBits, float scale,
+        float rotateYDegrees, const float* eye, const float* at, float vfovDegrees, unsigned int width, unsigned int height)
+{
+    Scene* scene = new Scene;
+    const Transformation T(vec3(0.0f), toQuat(radians(rotateYDegrees), vec3(0.0f, 1.0f, 0.0f)), vec3(scale));
+    if (!importIntoScene(*scene, objFile, T, importBits)) {
+        delete scene;
+        return nullptr;
+    }
+    Texture* tex = createTextureImage(std::string(envFile));
+    if (!tex) {
+        delete scene;
+        return nullptr;
+    }
+    EnvironmentMap* env = scene->take(new EnvironmentMapEquiRect(scene->take(tex)));
+    if (importanceN > 0)
+        env->initializeImportanceSampling(importanceN);
+    return wptHostFinish(scene, width, height, radians(vfovDegrees), vec3(eye), vec3(at), 0.0f, 1.0f);
+}

@@ -130,13 +130,39 @@ def load(path):
     return FileScene(path)
 
 
-def build_once(build, path, rank, barrier):
-    """N ranks, one builder: rank 0 runs build() and saves the scene to `path`, every other rank waits at `barrier`
-    (a callable, e.g. torch.distributed.barrier) and maps the file.  Returns the scene of this rank."""
+def build_once(build, path, rank, barrier, broadcast=None):
+    """N ranks, one builder: rank 0 runs build() and saves the scene to `path`, every other rank waits and maps the
+    file.  Returns the scene of this rank.  `barrier` is a callable (torch.distributed.barrier); with `broadcast`
+    (torch.distributed.broadcast_object_list) rank 0 tells the others whether it succeeded, so that a failed build or a
+    full /dev/shm raises on every rank instead of leaving them at a barrier until the process group times out.  The
+    file is removed as soon as every rank has mapped it (a mapping outlives its name), so nothing stays behind in
+    /dev/shm when a run dies later."""
+    error = None
+    scene = None
     if rank == 0:
-        scene = build()
-        save(scene, path)
+        try:
+            scene = build()
+            save(scene, path)
+        except BaseException as e:  # the other ranks must hear of it whatever it was
+            error = "%s: %s" % (type(e).__name__, e)
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+    if broadcast is not None:
+        box = [error]
+        broadcast(box, src=0)
+        error = box[0]
+    else:
         barrier()
-        return scene
-    barrier()
-    return load(path)
+    if error is not None:
+        raise RuntimeError("rank 0 could not build or save the scene: %s" % error)
+    if rank != 0:
+        scene = load(path)
+    barrier()          # every rank holds its mapping
+    if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return scene
