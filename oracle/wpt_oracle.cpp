@@ -2207,6 +2207,121 @@ void wpt_oracle_camera_rays(const wpt_camera* cam, int n, const float* pq, float
     }
 }
 
+/* Material::scatter / scatterToDirection / emitted of material `mat` of the scene on caller-given rays and hit records
+ * (tests/test_independent_pins.py holds them against float64 evaluations of the published models).
+ * in per record, 18 floats: ray direction(3), hit normal(3), hit tangent(3), texcoords(2), backside, hit distance a,
+ * generator seed (as an integer value), direction to evaluate(3), refractive index of the incoming ray.
+ * out per record, 22 floats: scatter type, direction(3), attenuation(4), pdf, refractive index(4) | scatterToDirection:
+ * attenuation(4), pdf | emitted(4). */
+void wpt_oracle_material_probe(const wpt_scene_desc* scene, uint32_t mat, int n, const float* in, float* out)
+{
+    wpt_params pr;
+    memset(&pr, 0, sizeof(pr));
+    Ctx c;
+    c.sc = scene;
+    c.pr = &pr;
+    memset(&c.cnt, 0, sizeof(c.cnt));
+    for (int i = 0; i < n; i++) {
+        const float* r = in + 18 * i;
+        Ray ray { v3(0.0f), v3(r), 0.0f, v4(r[17]) };
+        HitRecord hr;
+        hr.haveHit = true;
+        hr.normal = v3(r + 3);
+        hr.tangent = v3(r + 6);
+        hr.texcoords = V2 { r[9], r[10] };
+        hr.backside = r[11] != 0.0f;
+        hr.a = r[12];
+        hr.position = ray.at(hr.a);
+        hr.prim = 0;
+        Prng prng((unsigned int)r[13]);
+        const ScatterRecord sr = materialScatter(c, mat, ray, hr, prng);
+        const ScatterRecord ev = materialScatterToDirection(c, mat, ray, hr, v3(r + 14));
+        const V4 em = materialEmitted(c, mat, ray, hr);
+        float* o = out + 22 * i;
+        o[0] = float(sr.type);
+        o[1] = sr.direction.x; o[2] = sr.direction.y; o[3] = sr.direction.z;
+        o[4] = sr.attenuation.x; o[5] = sr.attenuation.y; o[6] = sr.attenuation.z; o[7] = sr.attenuation.w;
+        o[8] = sr.pdf;
+        o[9] = sr.refractiveIndex.x; o[10] = sr.refractiveIndex.y; o[11] = sr.refractiveIndex.z; o[12] = sr.refractiveIndex.w;
+        o[13] = ev.attenuation.x; o[14] = ev.attenuation.y; o[15] = ev.attenuation.z; o[16] = ev.attenuation.w;
+        o[17] = ev.pdf;
+        o[18] = em.x; o[19] = em.y; o[20] = em.z; o[21] = em.w;
+    }
+}
+
+/* The light sampling of tracePath (wurblpt.hpp:179-199) at caller-given points: in per record 7 floats: origin(3),
+ * a direction(3), generator seed; out per record 7 floats: mean pdfValue over all hot spots of that direction
+ * (wurblpt.hpp:181-185), index of the hot spot the generator picks (:187-188), the direction drawn towards it(3)
+ * (Hitable::direction), the mean pdfValue of that direction (:192-195), pdfValue of the FIRST hot spot alone for the
+ * given direction. */
+void wpt_oracle_hotspot_probe(const wpt_scene_desc* scene, int n, const float* in, float* out)
+{
+    wpt_params pr;
+    memset(&pr, 0, sizeof(pr));
+    Ctx c;
+    c.sc = scene;
+    c.pr = &pr;
+    memset(&c.cnt, 0, sizeof(c.cnt));
+    const size_t hotSpotsSize = scene->hotspot_count;
+    const float invHotSpotsSize = hotSpotsSize ? 1.0f / float(hotSpotsSize) : 0.0f;
+    for (int i = 0; i < n; i++) {
+        const float* r = in + 7 * i;
+        float* o = out + 7 * i;
+        memset(o, 0, 7 * sizeof(float));
+        if (hotSpotsSize == 0)
+            continue;
+        const V3 origin = v3(r), direction = v3(r + 3);
+        Prng prng((unsigned int)r[6]);
+        float hotSpotsPdf = 0.0f;
+        for (size_t k = 0; k < hotSpotsSize; k++)
+            hotSpotsPdf += hotSpotPdfValue(c, k, origin, direction);
+        hotSpotsPdf *= invHotSpotsSize;
+        size_t hotSpotIndex = prng.in01() * hotSpotsSize;
+        hotSpotIndex = hotSpotIndex < hotSpotsSize - 1 ? hotSpotIndex : hotSpotsSize - 1;
+        const V3 directDir = hotSpotDirection(c, hotSpotIndex, origin, prng);
+        float directPdf = 0.0f;
+        for (size_t k = 0; k < hotSpotsSize; k++)
+            directPdf += hotSpotPdfValue(c, k, origin, directDir);
+        directPdf *= invHotSpotsSize;
+        o[0] = hotSpotsPdf;
+        o[1] = float(hotSpotIndex);
+        o[2] = directDir.x; o[3] = directDir.y; o[4] = directDir.z;
+        o[5] = directPdf;
+        o[6] = hotSpotPdfValue(c, 0, origin, direction);
+    }
+}
+
+/* EnvironmentMap::L / p / d of the scene's environment map (envmap.hpp:167-210): in per record 4 floats: direction(3),
+ * generator seed; out per record 12 floats: L(direction)(4), p(direction), d(prng)(3), p(d), L(d).rgb sum. */
+void wpt_oracle_envmap_probe(const wpt_scene_desc* scene, int n, const float* in, float* out)
+{
+    wpt_params pr;
+    memset(&pr, 0, sizeof(pr));
+    Ctx c;
+    c.sc = scene;
+    c.pr = &pr;
+    memset(&c.cnt, 0, sizeof(c.cnt));
+    for (int i = 0; i < n; i++) {
+        const float* r = in + 4 * i;
+        float* o = out + 10 * i;
+        const V3 direction = v3(r);
+        Prng prng((unsigned int)r[3]);
+        const V4 L = envL(c, direction);
+        o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = L.w;
+        o[4] = scene->envmap.N > 0 ? envP(c, direction) : 0.0f;
+        V3 d = v3(0.0f);
+        float pd = 0.0f;
+        if (scene->envmap.N > 0) {
+            d = envD(c, prng);
+            pd = envP(c, d);
+        }
+        o[5] = d.x; o[6] = d.y; o[7] = d.z;
+        o[8] = pd;
+        const V4 Ld = envL(c, d);
+        o[9] = Ld.x + Ld.y + Ld.z + Ld.w;
+    }
+}
+
 /* BVH::hit against the scene for n rays (origin, dir, amin, amax = 8 floats).
  * out per ray: haveHit, prim, a, position(3), normal(3), tangent(3), texcoords(2), backside = 15 floats */
 void wpt_oracle_bvh_hits(const wpt_scene_desc* scene, int n, const float* rays, float* out, wpt_counters* counters)
