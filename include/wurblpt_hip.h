@@ -359,8 +359,8 @@ wpt_status wpt_render_block(wpt_scene* scene, const wpt_camera* camera,
         const wpt_params* params, uint32_t width, uint32_t height, uint32_t samples_sqrt,
         uint32_t block_start, uint32_t block_size, float* block_rgb);
 
-/* Waits for the device; WPT_ERR_HIP if a launch on this scene aborted (every wait inside the
- * kernels is bounded, so a protocol failure ends the launch instead of hanging the GPU). */
+/* Waits for the device; WPT_ERR_HIP if a launch since the last call failed (the kernels have no waits that could run
+ * out: every loop of theirs ends with its work). */
 wpt_status wpt_scene_check(wpt_scene* scene);
 
 /* ---- ground truth (GroundTruth / getGroundTruth, wurblpt.hpp:453-769) ----
@@ -421,14 +421,17 @@ wpt_status wpt_postproc_scale_luminance(const float* rgb_device, float* out_devi
  * float), 3 = max luminance (out: one float). */
 wpt_status wpt_postproc_host(int op, const float* rgb_host, void* out_host, uint64_t pixels, float a, float b);
 
-/* Kernel launch geometry knobs (0 = default); for benchmarking only, results do not change.
+/* Kernel launch geometry knobs (0 = default); for benchmarking only, results do not change.  wpt_set_launch_config,
+ * wpt_set_top_nodes and wpt_set_wavefront are PROCESS-GLOBAL hooks for tests and measurements: set them before rendering
+ * starts, not while other threads render (MPICoordinator's worker threads read them).
  * variant, byte 0: 0x01 scene from HBM even if it fits LDS, 0x02 all-features kernel, 0x20 separate SHADE / NEE-END / NEW rounds, 0x10 no pixel pool (every lane renders the one pixel it was launched for), 0x80 material records from HBM even where they fit into LDS next to the scene, 0x40 never two passes over a frame (timed first row of strata, then the rest with the longest tiles first; scenes fetched from HBM), bits 0x0c: a kind of material with few lanes in a long round stands back once (0 = fewer than 6 lanes, 0x04 = never, 0x08 = fewer than 3, 0x0c = fewer than 12; kernels without textures / spheres / environment only); byte 1: leave threshold of the traversal loop in eighths + 1; byte 2: lanes a long round needs + 1; byte 3:
  * leaf bias (DESIGN.md section 4 has what each was measured to do). */
 wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant);
 /* Storage order of the BVH nodes in HBM for scenes uploaded from now on: the first `nodes` nodes of a tree that is
  * larger than an L2 slice are stored level by level in front of the array, the subtrees below them depth-first
- * (0 = the whole tree depth-first, the reference's own array order; default 65536 = 2 MiB).  Visiting order and
- * results do not depend on it. */
+ * (0 = the whole tree depth-first, the reference's own array order; default 65536 = 2 MiB).  Bit 31 set: a tree that
+ * is walked from HBM also keeps every triangle's corners behind its leaf node, so that a leaf test reads on in the line
+ * its node came in (measured: no gain, off by default).  Visiting order and results do not depend on it. */
 wpt_status wpt_set_top_nodes(uint32_t nodes);
 /* Which form of the path tracer renders frames whose scene is fetched from HBM (results do not depend on it):
  * mode 0 = the library decides per launch (default), 1 = the wavefront form wherever it exists (trace and shade as two
@@ -457,9 +460,9 @@ const char* wpt_kernel_name(void);
  * marketing name and architecture of HIP device `device` ("AMD Instinct MI355X (gfx950:...)", or "" if there is none), and
  * the compiler and options the kernels were built with.  The strings live until the next call from the same thread. */
 const char* wpt_device_name(int device);
-/* Launches of the path tracing kernel the last render call of this process took for its pixels: 1, or 2 when the frame
- * was rendered in two passes (timed first row of strata, then the rest with the longest tiles first). Profilers see
- * that many kernel launches per frame; what is rendered does not depend on it. */
+/* Kernel launches the calling thread's last render call took for its pixels: 1, or 2 when the frame was rendered in two
+ * passes (timed first row of strata, then the rest with the longest tiles first), or the hundreds of trace + shade
+ * launches of the wavefront form. Profilers see that many kernel launches per frame; what is rendered does not depend on it. */
 uint32_t wpt_last_render_passes(void);
 const char* wpt_build_info(void);
 

@@ -1084,3 +1084,28 @@ def test_wavefront_is_the_default_only_where_it_was_measured_faster(dev, oracle)
         assert bits_equal(mgot, mref)
     finally:
         _wavefront(dev, 0)
+
+
+def test_leaf_records_never_change_results(dev, oracle):
+    """wpt_set_top_nodes bit 31: a tree that is walked from HBM keeps every triangle's corners behind its leaf node (three slots
+    of the node array per leaf).  Storage only: frames and work counters are the oracle's, for the single kernel, its counting
+    build and the wavefront kernels, with and without the top of the tree stored level by level."""
+    sc = host.sponza_like(64, 48, seed=3, detail=0.05, tex_size=16, env_width=32, importance_n=8)
+    tables = oracle.envmap_tables(sc)
+    try:
+        for word in (0x80000000 | 65536, 0x80000000 | 64, 0x80000000):
+            dev.lib().wpt_set_top_nodes(word)
+            ds = dev.DeviceScene(sc)        # the first upload builds the importance tables on the device, the others are given them
+            sc.set_envmap_tables(*tables)
+            ref, rc = oracle.render(sc, 3)
+            got, _ = ds.render(3)
+            counted, gc = ds.render(3, with_counters=True)
+            assert bits_equal(got, ref) and bits_equal(counted, ref), hex(word)
+            assert gc == rc, (gc, rc)
+            _wavefront(dev, 1, 2, 32, 9 << 16)
+            wf, _ = ds.render(3)
+            _wavefront(dev, 0)
+            assert bits_equal(wf, ref), hex(word)
+    finally:
+        dev.lib().wpt_set_top_nodes(65536)
+        _wavefront(dev, 0)

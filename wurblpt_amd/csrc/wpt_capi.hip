@@ -159,7 +159,6 @@ struct wpt_scene {
     uint32_t nodeCount, triCount;
     uint32_t animationCount;
     std::vector<void*> allocations;
-    uint32_t* status; /* device word: set by a launch that aborted */
     int cuCount;
     std::vector<float> envM, envMcs;
     std::vector<int32_t> envMs;
@@ -172,7 +171,8 @@ uint32_t g_variant = 0;
 uint32_t g_leaveEighths = 0; /* 0 = default: chosen per scene size (single-role kernel) / patience 8 rounds (ray-pool kernel) */
 uint32_t g_heavyMin = 0; /* 0 = chosen per scene size at launch */
 uint32_t g_leafBias = 0;
-uint32_t g_lastPasses = 1; /* path tracing launches the last render call took for its pixels (wpt_last_render_passes) */
+thread_local uint32_t g_lastPasses = 1; /* kernel launches the calling thread's last render call took for its pixels (wpt_last_render_passes) */
+bool g_leafRecords = false; /* wpt_set_top_nodes bit 31: triangle corners also behind their leaf node for trees walked from HBM (measured: no gain) */
 uint32_t g_topNodes = 65536; /* nodes of a large tree that are stored level by level in front (wpt_set_top_nodes) */
 unsigned long long* g_schedStats = nullptr;
 /* wpt_set_wavefront: 0 = the library decides, 1 = wavefront wherever it exists, 2 = never; launch geometry (0 = defaults) */
@@ -467,8 +467,23 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
         std::vector<uint32_t> end(n);
         for (uint32_t i = n; i-- > 0;)
             end[i] = desc->nodes[i].kind == WPT_NODE_INNER ? end[desc->nodes[i].link] : i + 1;
-        std::vector<uint32_t> place(size_t(n) + 1); /* depth-first index -> storage index; place[n] = n ends the walk */
-        place[n] = n;
+        /* Leaf records.  For trees that are walked from HBM / L2 (too large for LDS) a triangle leaf takes three 32-byte
+         * slots of the node array: its node, then the triangle's three corner quadwords (the fourth word of the first is
+         * the triangle's index).  The leaf test then reads on in the line the walk has just fetched instead of asking for a
+         * second, unrelated line of the triangle array.  Links are storage indices already, so the walk does not change;
+         * view.nodeCount counts slots.  Measured (tools/ab_leafrec.py, same process, frames equal bit for bit): 10 M
+         * triangles 61.0 - 61.2 with leaf records against 62.5 Msamples/s without, Sponza-class 131.0 - 131.2 against 131.7:
+         * the second fetch of one visit in nine is not what these walks wait for, and the node array twice as long costs
+         * the caches more than the saved line brings.  Off by default (wpt_set_top_nodes bit 31 switches it on). */
+        const bool leafRecords = size_t(n) * 32 + size_t(desc->tri_count) * 48 > LDS_SCENE_MAX_BYTES && g_leafRecords;
+        auto slotsOf = [&](uint32_t i) -> uint32_t { return leafRecords && desc->nodes[i].kind == WPT_NODE_TRIANGLE ? 3u : 1u; };
+        uint64_t slotCount = 0;
+        for (uint32_t i = 0; i < n; i++)
+            slotCount += slotsOf(i);
+        if (slotCount > NODE_INDEX_MASK)
+            return fail(WPT_ERR_UNSUPPORTED, "more than 2^30 - 1 slots in the device's node array");
+        std::vector<uint32_t> place(size_t(n) + 1); /* depth-first index -> storage index; place[n] ends the walk */
+        place[n] = uint32_t(slotCount);
         uint32_t topNodes = g_topNodes;
         if (n <= topNodes) /* the whole tree is no larger than the part that would go in front: nothing to gain */
             topNodes = 0;
@@ -480,7 +495,8 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
                 while (!level.empty() && cursor + level.size() <= topNodes) {
                     next.clear();
                     for (uint32_t i : level) {
-                        place[i] = cursor++;
+                        place[i] = cursor;
+                        cursor += slotsOf(i);
                         if (desc->nodes[i].kind == WPT_NODE_INNER) {
                             next.push_back(i + 1);
                             next.push_back(desc->nodes[i].link);
@@ -496,15 +512,19 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
              * 10 M triangle scene, no difference on the Sponza-class one; locality of the nodes is not what that scene lacks) */
             std::sort(level.begin(), level.end());
             for (uint32_t root : level)
-                for (uint32_t i = root; i < end[root]; i++)
-                    place[i] = cursor++;
-            if (cursor != n) {
+                for (uint32_t i = root; i < end[root]; i++) {
+                    place[i] = cursor;
+                    cursor += slotsOf(i);
+                }
+            if (cursor != slotCount) {
                 wpt_scene_free(s);
                 return fail(WPT_ERR_INVALID_ARGUMENT, "BVH conversion: the links do not reach every node exactly once");
             }
         }
         /* one node of padding: kernels that fetch aligned pairs of nodes read the whole last pair */
-        std::vector<float4> dev(size_t(n) * 2 + 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        std::vector<float4> dev(size_t(slotCount) * 2 + 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        s->view.leafRecords = leafRecords ? 1u : 0u;
+        s->view.nodeCount = uint32_t(slotCount);
         for (uint32_t i = 0; i < n; i++) {
             const wpt_bvh_node& nd = desc->nodes[i];
             const uint32_t skip = place[end[i]];
@@ -515,6 +535,14 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
             memcpy(&wd, &word, 4);
             dev[2 * size_t(place[i])] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0]);
             dev[2 * size_t(place[i]) + 1] = make_float4(nd.hi[1], nd.hi[2], sk, wd);
+            if (slotsOf(i) == 3) {
+                const wpt_tri_geom& g = desc->tri_geom[nd.link];
+                float index;
+                memcpy(&index, &nd.link, 4);
+                dev[2 * size_t(place[i]) + 2] = make_float4(g.v0[0], g.v0[1], g.v0[2], index);
+                dev[2 * size_t(place[i]) + 3] = make_float4(g.v1[0], g.v1[1], g.v1[2], 0.0f);
+                dev[2 * size_t(place[i]) + 4] = make_float4(g.v2[0], g.v2[1], g.v2[2], 0.0f);
+            }
         }
         UP(uploadArray(s, dev.data(), dev.size(), &nodes));
     }
@@ -581,14 +609,9 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     for (int k = 0; k < 6; k++)
         s->view.envCube[k] = desc->envmap.cube_tex[k];
     {
-        const uint32_t zeros[1] = { 0 };
-        const uint32_t* statusWord = nullptr;
-        UP(uploadArray(s, zeros, 1, &statusWord));
-        s->status = const_cast<uint32_t*>(statusWord);
         hipDeviceProp_t prop;
         s->cuCount = hipGetDeviceProperties(&prop, s->device) == hipSuccess ? prop.multiProcessorCount : 256;
     }
-    s->view.nodeCount = desc->node_count;
     s->view.triCount = desc->tri_count;
     s->view.hotspotCount = desc->hotspot_count;
     s->view.invHotspotCount = desc->hotspot_count ? 1.0f / float(desc->hotspot_count) : 0.0f;
@@ -743,7 +766,6 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     args.blockSize = block_size;
     args.frame = frame_device;
     args.counters = counters_device;
-    args.status = scene->status;
     args.schedStats = g_schedStats;
     args.fuse = (g_variant & 0x20u) ? 0u : 1u; /* variant bit 0x20: separate SHADE / NEE-END / NEW rounds (the older scheduler) */
 
@@ -821,7 +843,7 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     args.pool = pool;
     args.cuCount = uint32_t(scene->cuCount);
     /* the material records join the scene in LDS where a quarter of a compute unit's 160 KiB holds a workgroup with them */
-    args.materialsInLds = (!(g_variant & 0x80u) && COLD_BYTES + ldsBytes + size_t(scene->view.materialCount) * sizeof(wpt_material) <= 40960u) ? 1u : 0u;
+    args.materialsInLds = (!(g_variant & 0x80u) && COLD_BYTES + ldsBytes + size_t(scene->view.materialCount) * sizeof(wpt_material) <= LDS_BYTES_PER_WORKGROUP_AT_FOUR) ? 1u : 0u;
     args.rowStop = samples_sqrt;
     args.carry = nullptr;
     args.cost = nullptr;
@@ -1089,24 +1111,19 @@ wpt_status wpt_set_wavefront(uint32_t mode, uint32_t groups, uint32_t chunk, uin
 
 wpt_status wpt_set_top_nodes(uint32_t nodes)
 {
-    g_topNodes = nodes;
+    g_topNodes = nodes & 0x7fffffffu;
+    g_leafRecords = (nodes & 0x80000000u) != 0; /* bit 31: the triangles' corners also behind their leaf nodes */
     return WPT_OK;
 }
 
-/* Waits for the device and reports whether any launch on this scene had to abort (a bounded
- * wait inside the kernel ran out); clears the flag. */
+/* Waits for the device and reports an error of any launch since the last call (a fault inside a kernel surfaces
+ * here).  The kernels themselves have no bounded waits that could run out: every loop ends with its work. */
 wpt_status wpt_scene_check(wpt_scene* scene)
 {
     if (!scene)
         return fail(WPT_ERR_INVALID_ARGUMENT, "scene is NULL");
     HIP_TRY(hipDeviceSynchronize());
-    uint32_t st = 0;
-    HIP_TRY(hipMemcpy(&st, scene->status, sizeof(st), hipMemcpyDeviceToHost));
-    if (st != 0) {
-        const uint32_t zero = 0;
-        HIP_TRY(hipMemcpy(scene->status, &zero, sizeof(zero), hipMemcpyHostToDevice));
-        return fail(WPT_ERR_HIP, "a path tracing launch aborted: a bounded wait inside the kernel ran out");
-    }
+    HIP_TRY(hipGetLastError());
     return WPT_OK;
 }
 

@@ -462,7 +462,8 @@ struct SceneView {
     const float* envM;
     const int32_t* envMs;
     const float* envMcs;
-    uint32_t nodeCount, triCount;
+    uint32_t nodeCount, triCount; /* nodeCount: 32-byte slots of `nodes` (a triangle leaf takes three where leafRecords is set) */
+    uint32_t leafRecords;         /* 1: a triangle leaf's corners follow its node: nodes[2 * leaf + 2 .. + 4], the first one's w = triangle index */
     uint32_t hotspotCount;
     uint32_t envType, envCompat;
     int32_t envTex, envN;

@@ -59,6 +59,11 @@ constexpr uint32_t TABLE_BYTES = WPT_MATH_TABLE_WORDS * 8;
 constexpr uint32_t COLD_BYTES = TABLE_BYTES + SLOT_COUNT * WG * 16;
 /* with the scene behind them three workgroups still fit into a CU's 160 KiB */
 constexpr uint32_t LDS_SCENE_MAX_BYTES = 20 * 1024;
+/* a quarter of a compute unit's 160 KiB: what a workgroup may use where four of them are to share the unit (the material
+ * records join the scene in LDS where they still fit into it) */
+constexpr uint32_t LDS_BYTES_PER_WORKGROUP_AT_FOUR = 160 * 1024 / 4;
+/* the material records are copied to LDS quadword by quadword and read there through a generic pointer */
+static_assert(sizeof(wpt_material) % 16 == 0 && alignof(wpt_material) <= 16, "wpt_material must be a whole number of quadwords");
 struct KernelArgs {
     SceneView sv;
     wpt_camera cam;
@@ -94,7 +99,6 @@ struct KernelArgs {
     uint32_t materialsInLds; /* scene in LDS: the material records are there too */
     wpt_counters* counters;
     unsigned long long* schedStats; /* COUNT builds: 16 scheduler statistics, or NULL */
-    uint32_t* status;               /* set to 1 by a launch that had to abort (bounded waits) */
 };
 
 /* lane index of the launch -> pixel; false: no pixel behind this index */
@@ -176,6 +180,9 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     /* node prefetch: for scenes in HBM (Sponza-class frame 3 % faster); not from LDS, where the eight registers cost more
      * than the short fetch (Cornell 4 % slower) */
     constexpr bool PREFETCH = !LDSSCENE;
+    /* leaf records (wpt_capi.hip): the walk reads a triangle's corners behind its leaf node; not where the corners are
+     * moved by an animation first (those kernels need the instance and flag words of the triangle array anyway) */
+    constexpr bool LEAFREC = !LDSSCENE && !(F & FEAT_ANIM);
     /* Node steps per look at the lane counts.  The look itself (two ballots, their counts, the leave and leaf decisions:
      * some twenty scalar instructions and two branches in every lane's way) costs a wave as much issue time as half a
      * node step.  From LDS a step is short, and taking up to three in a row before looking again gave 852 against 799
@@ -385,7 +392,19 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                             c.invDet = c.U = c.V = c.W = 0.0f;
                             accepted = sphereTest(sphereNow<F>(sv, ps, sv.spheres[leafPrim & ~PRIM_SPHERE]), ps.o, ps.d, par.min_hit_distance, amax, c.a);
                         } else {
-                            const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
+                            float4 g0, g1, g2;
+                            if (LEAFREC && sv.leafRecords) {
+                                /* the corners lie behind the leaf's node; leafPrim is the leaf's slot until the test is through */
+                                const float4* at = sv.nodes + 2 * (size_t)leafPrim + 2;
+                                g0 = at[0];
+                                g1 = at[1];
+                                g2 = at[2];
+                                leafPrim = __float_as_uint(g0.w);
+                            } else {
+                                g0 = tri4(3 * leafPrim);
+                                g1 = tri4(3 * leafPrim + 1);
+                                g2 = tri4(3 * leafPrim + 2);
+                            }
                             f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
                             if ((F & FEAT_ANIM) && (__float_as_uint(g2.w) & WPT_TRI_ANIMATE)) {
                                 /* the instance moves: its corners at the ray's time (hitable_triangle.hpp:209-218) */
@@ -425,7 +444,9 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         /* select form of: hit & inner -> first child; hit & leaf -> test it, then skip; else -> skip */
                         const bool inner = word >= NODE_CHILD;
                         const bool toLeaf = hit && !inner;
-                        leafPrim = toLeaf ? word : leafPrim;
+                        /* what the leaf test needs: the primitive, or (leaf records) the slot of the triangle's leaf */
+                        const uint32_t leafWord = (LEAFREC && sv.leafRecords && !(word & PRIM_SPHERE)) ? node : word;
+                        leafPrim = toLeaf ? leafWord : leafPrim;
                         node = (hit && inner) ? (word & NODE_INDEX_MASK) : skip;
                         state = toLeaf ? (int)S_LEAF : (int)S_NODE;
                         if (!toLeaf && node >= nodeCount)

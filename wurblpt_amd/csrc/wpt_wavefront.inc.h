@@ -276,8 +276,11 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                         c.invDet = c.U = c.V = c.W = 0.0f;
                         accepted = sphereTest(sv.spheres[leafPrim & ~PRIM_SPHERE], o, d, amin, amax, c.a);
                     } else {
-                        const float4* g = sv.triGeom + 3 * (size_t)leafPrim;
+                        /* leaf records: the corners lie behind the leaf's node, leafPrim is the leaf's slot until here */
+                        const float4* g = sv.leafRecords ? sv.nodes + 2 * (size_t)leafPrim + 2 : sv.triGeom + 3 * (size_t)leafPrim;
                         const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+                        if (sv.leafRecords)
+                            leafPrim = __float_as_uint(g0.w);
                         accepted = triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), o, aux, amin, amax, c);
                     }
                     if (accepted) {
@@ -301,7 +304,8 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                     const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, aux.inv, amin, amax);
                     const bool inner = word >= NODE_CHILD;
                     const bool toLeaf = hit && !inner;
-                    leafPrim = toLeaf ? word : leafPrim;
+                    const uint32_t leafWord = (sv.leafRecords && !(word & PRIM_SPHERE)) ? node : word;
+                    leafPrim = toLeaf ? leafWord : leafPrim;
                     node = (hit && inner) ? (word & NODE_INDEX_MASK) : skip;
                     state = toLeaf ? (int)T_LEAF : (int)T_NODE;
                     if (!toLeaf && node >= nodeCount)
