@@ -352,7 +352,7 @@ template<class PS> WPT_D int advancePath(const wpt_params& par, PS& ps, f4 nextA
 
 /* wurblpt.hpp:348-360 + Camera::getRay (camera.hpp:123-185), pinhole or thin lens */
 template<uint32_t F, class PS>
-WPT_D int blockNew(const FrameArgs& fa, PS& ps, const SceneView* sv = nullptr)
+WPT_D int blockNew(const FrameArgs& fa, PS& ps, const SceneView& sv)
 {
     const uint32_t stratum = ps.getW(SLOT_ACC);
     const uint32_t i = stratum & 0xffffu, j = stratum >> 16; /* sampleIndex % samplesSqrt, sampleIndex / samplesSqrt */
@@ -413,8 +413,11 @@ WPT_D int blockNew(const FrameArgs& fa, PS& ps, const SceneView* sv = nullptr)
         const float t = fa.par.t0 + in01(prng) * (fa.par.t1 - fa.par.t0);
         ps.time = t;
         ps.animCached = -1; /* AnimationCache::init(r.time) */
-        if (fa.cam.animation >= 0 && sv) {
-            const wptanim::Trs T = animationAt(*sv, fa.cam.animation, t);
+        if (fa.cam.animation >= 0) {
+            /* (the scene view comes by reference: a POINTER to it, as this function once took, made the compiler keep a private
+             * copy of all kernel arguments in scratch memory -- 880 bytes per lane in the ground truth kernel, 670 - 930 in the
+             * path tracing kernels for moving scenes) */
+            const wptanim::Trs T = animationAt(sv, fa.cam.animation, t);
             ps.o = add(ld3(T.t), quatRotate(T.q, mul(O, ld3(T.s))));
             ps.d = normalize(quatRotate(T.q, D));
         } else {

@@ -555,6 +555,22 @@ template<uint32_t F> WPT_D wpt_sphere sphereAt(const SceneView& sv, const wpt_sp
         return sphereMoved(sp, animationAt(sv, sp.animation, time));
     return sp;
 }
+/* What the out-of-line sphere code needs of the scene, by value: a reference to the scene view, which lives in the
+ * kernel's arguments, would make the compiler keep a private copy of ALL kernel arguments in scratch memory as soon as
+ * the callee reads more than a field or two of it (the kernels for moving scenes: 670 - 930 bytes per lane). */
+struct SphereScene {
+    const wpt_sphere* spheres;
+    const wpt_animation* animations;
+    const wpt_keyframe* keyframes;
+};
+WPT_D SphereScene sphereScene(const SceneView& sv)
+{
+    SphereScene v;
+    v.spheres = sv.spheres;
+    v.animations = sv.animations;
+    v.keyframes = sv.keyframes;
+    return v;
+}
 /* ... and as pdfValue() places it (:161-166): the whole transformation applied to the centre */
 WPT_D wpt_sphere sphereMovedForPdf(const wpt_sphere& sp, const wptanim::Trs& T)
 {
@@ -570,9 +586,22 @@ WPT_D wpt_sphere sphereMovedForPdf(const wpt_sphere& sp, const wptanim::Trs& T)
 }
 
 /* HitableSphere::constructHitRecord (hitable_sphere.hpp:42-75) */
-template<uint32_t F = 0> static __device__ __attribute__((noinline)) Hit finishSphereHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir, float time = 0.0f)
+/* out of line in the path tracing kernels, where few lanes run it and its registers would be taken from the common path;
+ * a kernel that passes it a scene view living in its arguments defines WPT_SPHERE_HIT_INLINE: a real call would need the
+ * arguments' address, and the compiler then keeps a private copy of ALL kernel arguments in scratch memory (the ground
+ * truth kernel: 880 bytes per lane) */
+#ifdef WPT_SPHERE_HIT_INLINE
+#define WPT_SPHERE_HIT WPT_D
+#else
+#define WPT_SPHERE_HIT static __device__ __attribute__((noinline))
+#endif
+template<uint32_t F = 0> WPT_SPHERE_HIT Hit finishSphereHit(SphereScene sv, Candidate c, f3 org, f3 dir, float time = 0.0f)
 {
-    const wpt_sphere sp = sphereAt<F>(sv, sv.spheres[c.prim & ~PRIM_SPHERE], time);
+    wpt_sphere sp = sv.spheres[c.prim & ~PRIM_SPHERE];
+    if ((F & FEAT_ANIM) && sp.animation >= 0) {
+        const wpt_animation a = sv.animations[sp.animation];
+        sp = sphereMoved(sp, wptanim::at<DeviceAnimMath>(sv.keyframes + a.first_keyframe, a.keyframe_count, time));
+    }
     Hit h;
     h.a = c.a;
     h.prim = c.prim;
@@ -607,7 +636,7 @@ template<uint32_t F = 0, class Tri4 = TriGeomFromScene>
 WPT_D Hit finishHit(const SceneView& sv, const Candidate& c, f3 org, f3 dir, float time, Tri4 tri4)
 {
     if ((F & FEAT_SPHERES) && (c.prim & PRIM_SPHERE))
-        return finishSphereHit<F>(sv, c, org, dir, time);
+        return finishSphereHit<F>(sphereScene(sv), c, org, dir, time);
     Hit h;
     h.a = c.a;
     h.prim = c.prim;

@@ -8,6 +8,7 @@
  * The picture is taken at t0; the flow arrays compare the hit point's place at tPrev / tNext (it moves
  * with an animated instance) as seen by the camera at those times.
  */
+#define WPT_SPHERE_HIT_INLINE /* see wpt_device.h: a real call would pin the kernel arguments to scratch memory */
 #include "wpt_pathtrace.inc.h"
 
 namespace wptk {
@@ -73,7 +74,7 @@ WPT_D void store1(void* array, uint32_t pixel, float v)
 
 constexpr uint32_t GT_FEATURES = FEAT_TEXTURES | FEAT_LENS | FEAT_SPHERES | FEAT_ANIM;
 
-__global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs args)
+__global__ void __launch_bounds__(256) wpt_ground_truth_kernel(const GroundTruthArgs args)
 {
     const uint32_t pixel = blockIdx.x * blockDim.x + threadIdx.x;
     if (pixel >= args.width * args.height)
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(GroundTruthArgs a
     fa.invSamplesSqrt = 1.0f;
     PathRegs ps;
     pathStateInit(ps, pixel, pixel % args.width, pixel / args.width);
-    blockNew<GT_FEATURES>(fa, ps, &sv); /* par.t0 == par.t1: no time draw, ps.time = t0 */
+    blockNew<GT_FEATURES>(fa, ps, sv); /* par.t0 == par.t1: no time draw, ps.time = t0 */
 
     /* BVH::hit (bvh.hpp:270-329): closest candidate, later candidates win ties */
     const RayAux aux = rayAux(ps.d);

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             }
             if (state == S_NEW) { /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
                 const bool passEnds = firstPass && (ps.getW(SLOT_ACC) >> 16) >= args.rowStop;
-                const int next = passEnds ? (int)NEXT_DONE : blockNew<F>(fa, ps, &sv);
+                const int next = passEnds ? (int)NEXT_DONE : blockNew<F>(fa, ps, sv);
                 if (next == NEXT_DONE) {
                     const uint32_t pxy = ps.getW(SLOT_SRDIR);
                     const size_t at = (size_t)(pxy >> 16) * args.width + (pxy & 0xffffu);

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(WG, 4) void wf_shade(const WfArgs a)
                 next = blockNeeEnd<F>(sv, par, tri4, ps, best);            /* the next-event ray's contribution, then the path continues */
         }
         if (next == NEXT_NEW) { /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
-            next = blockNew<F>(fa, ps, &sv);
+            next = blockNew<F>(fa, ps, sv);
             if (next == NEXT_DONE) {
                 /* SensorRGB::finishPixel (sensor_rgb.hpp:82-87) */
                 const uint32_t pxy = ps.getW(SLOT_SRDIR);
