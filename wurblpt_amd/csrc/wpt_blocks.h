@@ -504,7 +504,13 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
         lc.scatters++;
     section(0);
     Prng prng = loadPrng(ps);
-    const Scatter sr = materialScatter<F>(sv, m, ray, h, prng);
+#ifdef WPT_NO_MATERIAL_CACHE /* experiments: every evaluation reads its textures itself */
+    MatCache mcScatter = matCacheEmpty(), mc = matCacheEmpty();
+    const Scatter sr = materialScatter<F>(sv, m, ray, h, prng, mcScatter);
+#else
+    MatCache mc = matCacheEmpty(); /* what scatter reads from the material's textures, kept for the evaluation towards the light */
+    const Scatter sr = materialScatter<F>(sv, m, ray, h, prng, mc);
+#endif
     section(1);
     const f4 att = ps.get4(SLOT_ATT);
     {
@@ -554,7 +560,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
         if (directPdf > 0.0f) {
             float dpdf;
             f4 directAtt;
-            materialEval<F>(sv, m, ray, h, directDir, directAtt, dpdf);
+            materialEval<F>(sv, m, ray, h, directDir, directAtt, dpdf, mc);
             if (dpdf > 0.0f) {
                 const f4 neeFactor = sclr(divs(mul(att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
                 Slot nee;
@@ -579,7 +585,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
         const float directPdf = envP(sv, lightDir);
         float dpdf;
         f4 directAtt;
-        materialEval<F>(sv, m, ray, h, lightDir, directAtt, dpdf);
+        materialEval<F>(sv, m, ray, h, lightDir, directAtt, dpdf, mc);
         if (dpdf > 0.0f) {
             const f4 neeFactor = sclr(divs(mul(att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
             ps.set3(SLOT_NEE, mk3(neeFactor.x, neeFactor.y, neeFactor.z));
