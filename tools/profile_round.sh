@@ -9,7 +9,7 @@ if [[ $PART == *c* ]]; then
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_${TAG}_cornell -o stats --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/stats_${TAG}_cornell.log 2>&1 || exit 1
 bash tools/pmc_sq.sh ${TAG}c || exit 1
 for P in "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace -d gpurun_out/pmc_${TAG}c_$P -o pmc --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/pmc_${TAG}c_$P.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace -d gpurun_out/pmc_${TAG}c_$P -o pmc --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary > gpurun_out/pmc_${TAG}c_$P.log 2>&1 || exit 1
 done
 echo done cornell
 fi
@@ -19,7 +19,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_${TAG}_co
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_${TAG}_sponza -o stats --output-format csv -- python3 bench.py $S --no-cpu-baseline > gpurun_out/stats_${TAG}_sponza.log 2>&1 || exit 1
 bash tools/pmc_sq.sh ${TAG}c || exit 1
 for P in "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace -d gpurun_out/pmc_${TAG}c_$P -o pmc --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/pmc_${TAG}c_$P.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace -d gpurun_out/pmc_${TAG}c_$P -o pmc --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary > gpurun_out/pmc_${TAG}c_$P.log 2>&1 || exit 1
 done
 bash tools/pmc_mem.sh ${TAG}s $S || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_${TAG}s_WRITE_SIZE -o pmc --output-format csv -- python3 bench.py $S --no-cpu-baseline > gpurun_out/pmc_${TAG}s_WRITE_SIZE.log 2>&1 || exit 1
