@@ -504,12 +504,17 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
         lc.scatters++;
     section(0);
     Prng prng = loadPrng(ps);
-#ifdef WPT_NO_MATERIAL_CACHE /* experiments: every evaluation reads its textures itself */
+#ifdef WPT_MATERIAL_CACHE
+    /* what scatter reads from the material's textures is kept for the evaluation towards the light (the wavefront shade
+     * kernels: +2 %) */
+    MatCache mc = matCacheEmpty();
+    const Scatter sr = materialScatter<F>(sv, m, ray, h, prng, mc);
+#else
+    /* The single kernel lets every evaluation read its textures itself: the twelve kept values live across the light sampling,
+     * where that kernel has no register to spare -- its scratch went from 272 to 336 bytes per lane and the frame's HBM writes
+     * from 57 to 636 GB (Sponza-class, profiles/r03_pmc_sponza.txt of that build) for +0.3 % of speed. */
     MatCache mcScatter = matCacheEmpty(), mc = matCacheEmpty();
     const Scatter sr = materialScatter<F>(sv, m, ray, h, prng, mcScatter);
-#else
-    MatCache mc = matCacheEmpty(); /* what scatter reads from the material's textures, kept for the evaluation towards the light */
-    const Scatter sr = materialScatter<F>(sv, m, ray, h, prng, mc);
 #endif
     section(1);
     const f4 att = ps.get4(SLOT_ATT);
