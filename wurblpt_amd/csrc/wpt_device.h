@@ -1003,7 +1003,8 @@ template<uint32_t F> WPT_D f4 texOrConst(const SceneView& sv, int tex, const flo
  * texture coordinates, so the second evaluation can take the first one's values: the same bits, four bilinear look-ups
  * (sixteen texel loads) fewer per ModPhong hit.  Kernels without textures do not use it. */
 struct MatCache {
-    bool haveNormalTexel, haveColours, haveAlbedo, haveRoughness;
+    bool haveNormalTexel, haveColours, haveAlbedo, haveRoughness, haveRgl;
+    wptrgl::RglIncident rgl; /* measured BRDFs: what the model derives from the incident direction alone */
     f4 normalTexel;
     f4 kd, ks;   /* ModPhong: diffuse, specular; Lambertian / GGX: kd = albedo */
     float shininess, rx, ry;
@@ -1011,7 +1012,7 @@ struct MatCache {
 WPT_D MatCache matCacheEmpty()
 {
     MatCache mc;
-    mc.haveNormalTexel = mc.haveColours = mc.haveAlbedo = mc.haveRoughness = false;
+    mc.haveNormalTexel = mc.haveColours = mc.haveAlbedo = mc.haveRoughness = mc.haveRgl = false;
     mc.normalTexel = mc.kd = mc.ks = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     mc.shininess = mc.rx = mc.ry = 0.0f;
     return mc;
@@ -1201,7 +1202,15 @@ template<uint32_t F> WPT_D Scatter materialScatter(const SceneView& sv, const wp
         wwi.x = wi.x;
         wwi.y = wi.y;
         wwi.z = wi.z;
-        const wptrgl::V3 a = wptrgl::rglSample<DeviceRglMath>(sv.rglBrdfs[m.tex[0]], sv.rglData, uu, wwi, pwo, p);
+        wptrgl::V3 a;
+        a.x = a.y = a.z = 0.0f;
+        pwo = a;
+        p = 0.0f;
+        if (wwi.z > 0.0f) { /* BRDF::sample's own first test */
+            wptrgl::rglIncidentCall<DeviceRglMath>(sv.rglBrdfs[m.tex[0]], sv.rglData, wwi, mc.rgl);
+            mc.haveRgl = true;
+            a = wptrgl::rglSampleCall<DeviceRglMath>(sv.rglBrdfs[m.tex[0]], sv.rglData, mc.rgl, uu, wwi, pwo, p);
+        }
         const f3 wo = mk3(pwo.x, pwo.y, pwo.z);
         if (dot(wo, wo) <= 0.0f)
             return scatterNone();
@@ -1416,10 +1425,20 @@ template<uint32_t F> WPT_D void materialEval(const SceneView& sv, const wpt_mate
             wwo.y = wo.y;
             wwo.z = wo.z;
             const wpt_rgl_brdf& b = sv.rglBrdfs[m.tex[0]];
-            const wptrgl::V3 a = wptrgl::rglEval<DeviceRglMath>(b, sv.rglData, wwi, wwo);
+            /* BRDF::eval and BRDF::pdf share the half vector's part; what depends on the incident direction alone comes
+             * from scatter where it has been there (same arguments, same values) */
+            wptrgl::V3 a;
+            a.x = a.y = a.z = 0.0f;
+            p = 0.0f;
+            if (wwi.z > 0.0f && wwo.z > 0.0f) {
+                if (!mc.haveRgl) {
+                    wptrgl::rglIncidentCall<DeviceRglMath>(b, sv.rglData, wwi, mc.rgl);
+                    mc.haveRgl = true;
+                }
+                wptrgl::rglEvalPdfCall<DeviceRglMath>(b, sv.rglData, mc.rgl, wwi, wwo, a, p);
+            }
             const f3 attenuation = mk3(a.x, a.y, a.z);
             att = mk4(attenuation.x, attenuation.y, attenuation.z, average3(attenuation));
-            p = wptrgl::rglPdf<DeviceRglMath>(b, sv.rglData, wwi, wwo);
         }
         break;
     }

@@ -29,9 +29,11 @@
 #if defined(__HIPCC__)
 #define WPT_RGL_HD __host__ __device__ __forceinline__
 #define WPT_RGL_ENTRY __host__ __device__ __attribute__((noinline))
+#define WPT_RGL_UNROLL _Pragma("unroll")
 #else
 #define WPT_RGL_HD inline
 #define WPT_RGL_ENTRY inline
+#define WPT_RGL_UNROLL
 #endif
 
 namespace wptrgl {
@@ -88,36 +90,102 @@ struct Lookup<0> {
     static WPT_RGL_HD float at(const float* data, uint32_t index, uint32_t, const float*, const wpt_rgl_warp&) { return data[index]; }
 };
 
-/* parameter-related indices and weights (the common head of sample / invert / eval) */
-template<int Dim>
-WPT_RGL_HD uint32_t paramWeights(const wpt_rgl_warp& w, const float* pool, const float* param, float* pw)
+/* find_interval over a parameter grid of at most 16 values, read all at once: the bisection then runs over the sixteen
+ * comparison results instead of asking memory for one value per step (each step of the original is a dependent load, and
+ * the grids of the database's files have 8 values).  The same comparisons decide the same steps, so the index is the one
+ * find_interval gives for ANY contents of the grid, sorted or not; the two values around it come from the registers. */
+WPT_RGL_HD uint32_t findIntervalSmall(const float* values, uint32_t size_, float p, float& p0, float& p1)
 {
-    uint32_t sliceOffset = 0;
-    for (int dim = 0; dim < Dim; ++dim) {
-        if (w.param_size[dim] == 1) {
-            pw[2 * dim] = 1.0f;
-            pw[2 * dim + 1] = 0.0f;
-            continue;
-        }
-        const float* values = pool + w.param_values[dim];
-        const float p = param[dim];
-        const uint32_t index = findInterval(w.param_size[dim], [&](uint32_t idx) { return values[idx] <= p; });
-        const float p0 = values[index], p1 = values[index + 1];
-        pw[2 * dim + 1] = rclamp((p - p0) / (p1 - p0), 0.0f, 1.0f);
-        pw[2 * dim] = 1.0f - pw[2 * dim + 1];
-        sliceOffset += w.param_stride[dim] * index;
+    float v[16];
+    uint32_t predMask = 0;
+    WPT_RGL_UNROLL
+    for (uint32_t i = 0; i < 16; i++) {
+        v[i] = i < size_ ? values[i] : 0.0f;
+        predMask |= (v[i] <= p ? 1u : 0u) << i;
     }
-    return sliceOffset;
+    int64_t size = (int64_t)size_ - 2, first = 1;
+    while (size > 0) {
+        const int64_t half = size >> 1, middle = first + half;
+        const bool predResult = ((predMask >> (uint32_t)middle) & 1u) != 0;
+        first = predResult ? middle + 1 : first;
+        size = predResult ? size - (half + 1) : half;
+    }
+    int64_t r = first - 1;
+    const int64_t hi = (int64_t)size_ - 2;
+    r = r < 0 ? 0 : r;
+    r = hi < r ? hi : r;
+    p0 = v[0];
+    p1 = v[1];
+    WPT_RGL_UNROLL
+    for (uint32_t i = 1; i < 15; i++) {
+        if ((uint32_t)r == i) {
+            p0 = v[i];
+            p1 = v[i + 1];
+        }
+    }
+    return (uint32_t)r;
+}
+
+/* one parameter's interpolation weights and its part of the slice offset (the body of the loop at the head of
+ * Marginal2D::sample / invert / eval, powitacq_rgb.inl:330-349) */
+WPT_RGL_HD uint32_t paramWeightsOf(const wpt_rgl_warp& w, const float* pool, int dim, float p, float& w0, float& w1)
+{
+    if (w.param_size[dim] == 1) {
+        w0 = 1.0f;
+        w1 = 0.0f;
+        return 0;
+    }
+    const float* values = pool + w.param_values[dim];
+    uint32_t index;
+    float p0, p1;
+    if (w.param_size[dim] <= 16) {
+        index = findIntervalSmall(values, w.param_size[dim], p, p0, p1);
+    } else {
+        index = findInterval(w.param_size[dim], [&](uint32_t idx) { return values[idx] <= p; });
+        p0 = values[index];
+        p1 = values[index + 1];
+    }
+    w1 = rclamp((p - p0) / (p1 - p0), 0.0f, 1.0f);
+    w0 = 1.0f - w1;
+    return w.param_stride[dim] * index;
+}
+
+/* parameter-related indices and weights (the common head of sample / invert / eval): they depend on the warp and the
+ * parameters alone, so one evaluation serves every look-up into that warp with those parameters */
+template<int Dim>
+struct ParamCtx {
+    float pw[2 * (Dim > 0 ? Dim : 1)];
+    uint32_t sliceOffset;
+};
+template<int Dim>
+WPT_RGL_HD ParamCtx<Dim> paramCtx(const wpt_rgl_warp& w, const float* pool, const float* param)
+{
+    ParamCtx<Dim> c;
+    c.sliceOffset = 0;
+    for (int dim = 0; dim < Dim; ++dim)
+        c.sliceOffset += paramWeightsOf(w, pool, dim, param[dim], c.pw[2 * dim], c.pw[2 * dim + 1]);
+    return c;
+}
+/* a third parameter behind two that are already evaluated (the colour channel of the spectral interpolant) */
+WPT_RGL_HD ParamCtx<3> paramCtxAppend(const ParamCtx<2>& first, const wpt_rgl_warp& w, const float* pool, float third)
+{
+    ParamCtx<3> c;
+    c.pw[0] = first.pw[0];
+    c.pw[1] = first.pw[1];
+    c.pw[2] = first.pw[2];
+    c.pw[3] = first.pw[3];
+    c.sliceOffset = first.sliceOffset + paramWeightsOf(w, pool, 2, third, c.pw[4], c.pw[5]);
+    return c;
 }
 
 /* Marginal2D::sample (powitacq_rgb.inl:322-432) */
 template<int Dim>
-WPT_RGL_HD V2 warpSample(const wpt_rgl_warp& w, const float* pool, V2 sample, const float* param, float& pdf)
+WPT_RGL_HD V2 warpSample(const wpt_rgl_warp& w, const float* pool, V2 sample, const ParamCtx<Dim>& ctx, float& pdf)
 {
     sample.x = rclamp(sample.x, 1.0f - k_oneMinusEpsilon, k_oneMinusEpsilon);
     sample.y = rclamp(sample.y, 1.0f - k_oneMinusEpsilon, k_oneMinusEpsilon);
-    float pw[2 * (Dim > 0 ? Dim : 1)];
-    const uint32_t sliceOffset = paramWeights<Dim>(w, pool, param, pw);
+    const float* pw = ctx.pw;
+    const uint32_t sliceOffset = ctx.sliceOffset;
     const float* marginal = pool + w.marginal_cdf;
     const float* conditional = pool + w.conditional_cdf;
     const float* data = pool + w.data;
@@ -170,10 +238,16 @@ WPT_RGL_HD V2 warpSample(const wpt_rgl_warp& w, const float* pool, V2 sample, co
 
 /* Marginal2D::invert (powitacq_rgb.inl:435-514) */
 template<int Dim>
-WPT_RGL_HD V2 warpInvert(const wpt_rgl_warp& w, const float* pool, V2 sample, const float* param, float& pdfOut)
+WPT_RGL_HD V2 warpSample(const wpt_rgl_warp& w, const float* pool, V2 sample, const float* param, float& pdf)
 {
-    float pw[2 * (Dim > 0 ? Dim : 1)];
-    const uint32_t sliceOffset = paramWeights<Dim>(w, pool, param, pw);
+    return warpSample<Dim>(w, pool, sample, paramCtx<Dim>(w, pool, param), pdf);
+}
+
+template<int Dim>
+WPT_RGL_HD V2 warpInvert(const wpt_rgl_warp& w, const float* pool, V2 sample, const ParamCtx<Dim>& ctx, float& pdfOut)
+{
+    const float* pw = ctx.pw;
+    const uint32_t sliceOffset = ctx.sliceOffset;
     const float* marginal = pool + w.marginal_cdf;
     const float* conditional = pool + w.conditional_cdf;
     const float* data = pool + w.data;
@@ -223,10 +297,16 @@ WPT_RGL_HD V2 warpInvert(const wpt_rgl_warp& w, const float* pool, V2 sample, co
 
 /* Marginal2D::eval (powitacq_rgb.inl:520-560) */
 template<int Dim>
-WPT_RGL_HD float warpEval(const wpt_rgl_warp& w, const float* pool, V2 pos, const float* param)
+WPT_RGL_HD V2 warpInvert(const wpt_rgl_warp& w, const float* pool, V2 sample, const float* param, float& pdfOut)
 {
-    float pw[2 * (Dim > 0 ? Dim : 1)];
-    const uint32_t sliceOffset = paramWeights<Dim>(w, pool, param, pw);
+    return warpInvert<Dim>(w, pool, sample, paramCtx<Dim>(w, pool, param), pdfOut);
+}
+
+template<int Dim>
+WPT_RGL_HD float warpEval(const wpt_rgl_warp& w, const float* pool, V2 pos, const ParamCtx<Dim>& ctx)
+{
+    const float* pw = ctx.pw;
+    const uint32_t sliceOffset = ctx.sliceOffset;
     const float* data = pool + w.data;
     pos.x *= w.inv_patch_size[0];
     pos.y *= w.inv_patch_size[1];
@@ -244,6 +324,11 @@ WPT_RGL_HD float warpEval(const wpt_rgl_warp& w, const float* pool, V2 pos, cons
     const float v11 = Lookup<Dim>::at(data + w.size_x + 1, index, size, pw, w);
     return __builtin_fmaf(w0y, __builtin_fmaf(w0x, v00, w1x * v10), w1y * __builtin_fmaf(w0x, v01, w1x * v11))
         * (w.inv_patch_size[0] * w.inv_patch_size[1]);
+}
+template<int Dim>
+WPT_RGL_HD float warpEval(const wpt_rgl_warp& w, const float* pool, V2 pos, const float* param)
+{
+    return warpEval<Dim>(w, pool, pos, paramCtx<Dim>(w, pool, param));
 }
 
 /* BRDF convenience functions (powitacq_rgb.inl:870-884) */
@@ -276,13 +361,13 @@ WPT_RGL_HD V3 normalize3(V3 v)
     return r;
 }
 
-/* the three colour channels of the spectral interpolant, clipped (POWITACQ_CLIP_RGB) */
-WPT_RGL_HD V3 rglColour(const wpt_rgl_brdf& b, const float* pool, V2 sample, float phi_i, float theta_i)
+/* the three colour channels of the spectral interpolant, clipped (POWITACQ_CLIP_RGB); `first` = the incident direction's
+ * two parameters evaluated on the warp b.rgb */
+WPT_RGL_HD V3 rglColour(const wpt_rgl_brdf& b, const float* pool, V2 sample, const ParamCtx<2>& first)
 {
     float fr[3];
     for (int i = 0; i < 3; ++i) {
-        const float paramsFr[3] = { phi_i, theta_i, (float)i };
-        fr[i] = warpEval<3>(b.rgb, pool, sample, paramsFr);
+        fr[i] = warpEval<3>(b.rgb, pool, sample, paramCtxAppend(first, b.rgb, pool, (float)i));
         fr[i] = rmax(0.0f, fr[i]);
     }
     V3 r;
@@ -292,70 +377,75 @@ WPT_RGL_HD V3 rglColour(const wpt_rgl_brdf& b, const float* pool, V2 sample, flo
     return r;
 }
 
-/* BRDF::pdf (powitacq_rgb.inl:1016-1050) */
+/* Everything BRDF::sample, eval and pdf derive from the INCIDENT direction alone (powitacq_rgb.inl:1016-1183): its
+ * angles, its place in the unit square, the parameter weights of the three warps that are parameterised by it, and the
+ * projected-area term.  A path evaluates the model up to three times at one hit with one incident direction (sample,
+ * then eval and pdf towards the light): this is evaluated once for them. */
+struct RglIncident {
+    float theta_i, phi_i;
+    V2 u_wi;
+    ParamCtx<2> vndf, luminance, rgb;
+    float d; /* 4 * sigma(u_wi) */
+};
 template<class M>
-WPT_RGL_ENTRY float rglPdf(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
+WPT_RGL_HD RglIncident rglIncident(const wpt_rgl_brdf& b, const float* pool, V3 wi)
 {
-    if (wi.z <= 0 || wo.z <= 0)
-        return 0.0f;
-    V3 s;
-    s.x = wi.x + wo.x;
-    s.y = wi.y + wo.y;
-    s.z = wi.z + wo.z;
-    const V3 wm = normalize3(s);
-    const float theta_i = elevation<M>(wi), phi_i = M::atan2(wi.y, wi.x);
-    const float theta_m = elevation<M>(wm), phi_m = M::atan2(wm.y, wm.x);
-    V2 u_wm;
-    u_wm.x = theta2u<M>(theta_m);
-    u_wm.y = phi2u(b.isotropic ? (phi_m - phi_i) : phi_m);
-    u_wm.y = u_wm.y - __builtin_floorf(u_wm.y);
-    float vndfPdf;
-    const float params[2] = { phi_i, theta_i };
-    const V2 sample = warpInvert<2>(b.vndf, pool, u_wm, params, vndfPdf);
-    const float pdf = warpEval<2>(b.luminance, pool, sample, params);
-    const float sinThetaM = __builtin_sqrtf(sqr(wm.x) + sqr(wm.y));
-    const float jacobian = rmax(2.0f * sqr(k_rgl_pi) * u_wm.x * sinThetaM, 1e-6f) * 4.0f * dot3(wi, wm);
-    return vndfPdf * pdf / jacobian;
+    RglIncident inc;
+    inc.theta_i = elevation<M>(wi);
+    inc.phi_i = M::atan2(wi.y, wi.x);
+    inc.u_wi.x = theta2u<M>(inc.theta_i);
+    inc.u_wi.y = phi2u(inc.phi_i);
+    const float params[2] = { inc.phi_i, inc.theta_i };
+    inc.vndf = paramCtx<2>(b.vndf, pool, params);
+    inc.luminance = paramCtx<2>(b.luminance, pool, params);
+    inc.rgb = paramCtx<2>(b.rgb, pool, params);
+    inc.d = 4 * warpEval<0>(b.sigma, pool, inc.u_wi, params);
+    return inc;
 }
 
-/* BRDF::eval (powitacq_rgb.inl:1056-1100): f_r * cos */
+/* BRDF::eval (powitacq_rgb.inl:1056-1100: f_r * cos) and BRDF::pdf (:1016-1050) for one pair of directions: they share
+ * the half vector, its angles and the inverted sample position, which are evaluated once here */
 template<class M>
-WPT_RGL_ENTRY V3 rglEval(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
+WPT_RGL_HD void rglEvalPdfWith(const wpt_rgl_brdf& b, const float* pool, const RglIncident& inc, V3 wi, V3 wo, V3& frOut, float& pdfOut)
 {
     V3 zero;
     zero.x = zero.y = zero.z = 0.0f;
+    frOut = zero;
+    pdfOut = 0.0f;
     if (wi.z <= 0 || wo.z <= 0)
-        return zero;
+        return;
     V3 s;
     s.x = wi.x + wo.x;
     s.y = wi.y + wo.y;
     s.z = wi.z + wo.z;
     const V3 wm = normalize3(s);
-    const float theta_i = elevation<M>(wi), phi_i = M::atan2(wi.y, wi.x);
     const float theta_m = elevation<M>(wm), phi_m = M::atan2(wm.y, wm.x);
-    V2 u_wi;
-    u_wi.x = theta2u<M>(theta_i);
-    u_wi.y = phi2u(phi_i);
     V2 u_wm;
     u_wm.x = theta2u<M>(theta_m);
-    u_wm.y = phi2u(b.isotropic ? (phi_m - phi_i) : phi_m);
+    u_wm.y = phi2u(b.isotropic ? (phi_m - inc.phi_i) : phi_m);
     u_wm.y = u_wm.y - __builtin_floorf(u_wm.y);
     float vndfPdf;
-    const float params[2] = { phi_i, theta_i };
-    const V2 sample = warpInvert<2>(b.vndf, pool, u_wm, params, vndfPdf);
-    V3 fr = rglColour(b, pool, sample, phi_i, theta_i);
+    const V2 sample = warpInvert<2>(b.vndf, pool, u_wm, inc.vndf, vndfPdf);
+    /* eval */
+    V3 fr = rglColour(b, pool, sample, inc.rgb);
+    const float params[2] = { inc.phi_i, inc.theta_i };
     const float n = warpEval<0>(b.ndf, pool, u_wm, params);
-    const float d = 4 * warpEval<0>(b.sigma, pool, u_wi, params);
+    const float d = inc.d;
     fr.x = fr.x * n / d;
     fr.y = fr.y * n / d;
     fr.z = fr.z * n / d;
-    return fr;
+    frOut = fr;
+    /* pdf */
+    const float pdf = warpEval<2>(b.luminance, pool, sample, inc.luminance);
+    const float sinThetaM = __builtin_sqrtf(sqr(wm.x) + sqr(wm.y));
+    const float jacobian = rmax(2.0f * sqr(k_rgl_pi) * u_wm.x * sinThetaM, 1e-6f) * 4.0f * dot3(wi, wm);
+    pdfOut = vndfPdf * pdf / jacobian;
 }
 
 /* BRDF::sample (powitacq_rgb.inl:1106-1183): returns f_r * cos / pdf, the outgoing direction
  * (zero when the sample fails) and the pdf */
 template<class M>
-WPT_RGL_ENTRY V3 rglSample(const wpt_rgl_brdf& b, const float* pool, V2 u, V3 wi, V3& woOut, float& pdfOut)
+WPT_RGL_HD V3 rglSampleWith(const wpt_rgl_brdf& b, const float* pool, const RglIncident& inc, V2 u, V3 wi, V3& woOut, float& pdfOut)
 {
     V3 zero;
     zero.x = zero.y = zero.z = 0.0f;
@@ -363,22 +453,17 @@ WPT_RGL_ENTRY V3 rglSample(const wpt_rgl_brdf& b, const float* pool, V2 u, V3 wi
     pdfOut = 0.0f;
     if (wi.z <= 0)
         return zero;
-    const float theta_i = elevation<M>(wi), phi_i = M::atan2(wi.y, wi.x);
-    const float params[2] = { phi_i, theta_i };
-    V2 u_wi;
-    u_wi.x = theta2u<M>(theta_i);
-    u_wi.y = phi2u(phi_i);
     V2 sample;
     sample.x = u.y;
     sample.y = u.x;
     float lumPdf;
-    sample = warpSample<2>(b.luminance, pool, sample, params, lumPdf);
+    sample = warpSample<2>(b.luminance, pool, sample, inc.luminance, lumPdf);
     float ndfPdf;
-    const V2 u_wm = warpSample<2>(b.vndf, pool, sample, params, ndfPdf);
+    const V2 u_wm = warpSample<2>(b.vndf, pool, sample, inc.vndf, ndfPdf);
     float phi_m = u2phi(u_wm.y);
     const float theta_m = u2theta(u_wm.x);
     if (b.isotropic)
-        phi_m += phi_i;
+        phi_m += inc.phi_i;
     const float sinPhiM = M::sin(phi_m), cosPhiM = M::cos(phi_m), sinThetaM = M::sin(theta_m), cosThetaM = M::cos(theta_m);
     V3 wm;
     wm.x = cosPhiM * sinThetaM;
@@ -391,9 +476,10 @@ WPT_RGL_ENTRY V3 rglSample(const wpt_rgl_brdf& b, const float* pool, V2 u, V3 wi
     wo.z = wm.z * 2.0f * dwm - wi.z;
     if (wo.z <= 0)
         return zero;
-    V3 fr = rglColour(b, pool, sample, phi_i, theta_i);
+    V3 fr = rglColour(b, pool, sample, inc.rgb);
+    const float params[2] = { inc.phi_i, inc.theta_i };
     const float n = warpEval<0>(b.ndf, pool, u_wm, params);
-    const float d = 4 * warpEval<0>(b.sigma, pool, u_wi, params);
+    const float d = inc.d;
     fr.x = fr.x * n / d;
     fr.y = fr.y * n / d;
     fr.z = fr.z * n / d;
@@ -405,6 +491,58 @@ WPT_RGL_ENTRY V3 rglSample(const wpt_rgl_brdf& b, const float* pool, V2 u, V3 wi
     fr.y /= pdf;
     fr.z /= pdf;
     return fr;
+}
+
+/* the reference's three entry points, as its callers use them (the test oracle; ref_probe's golden vectors pin them) */
+template<class M>
+WPT_RGL_ENTRY float rglPdf(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
+{
+    if (wi.z <= 0 || wo.z <= 0)
+        return 0.0f;
+    V3 fr;
+    float pdf;
+    rglEvalPdfWith<M>(b, pool, rglIncident<M>(b, pool, wi), wi, wo, fr, pdf);
+    return pdf;
+}
+template<class M>
+WPT_RGL_ENTRY V3 rglEval(const wpt_rgl_brdf& b, const float* pool, V3 wi, V3 wo)
+{
+    V3 fr;
+    fr.x = fr.y = fr.z = 0.0f;
+    if (wi.z <= 0 || wo.z <= 0)
+        return fr;
+    float pdf;
+    rglEvalPdfWith<M>(b, pool, rglIncident<M>(b, pool, wi), wi, wo, fr, pdf);
+    return fr;
+}
+template<class M>
+WPT_RGL_ENTRY V3 rglSample(const wpt_rgl_brdf& b, const float* pool, V2 u, V3 wi, V3& woOut, float& pdfOut)
+{
+    V3 zero;
+    zero.x = zero.y = zero.z = 0.0f;
+    woOut = zero;
+    pdfOut = 0.0f;
+    if (wi.z <= 0)
+        return zero;
+    return rglSampleWith<M>(b, pool, rglIncident<M>(b, pool, wi), u, wi, woOut, pdfOut);
+}
+
+/* the same for the kernels: out of line (few lanes run them, and they are long), the incident direction's context by
+ * reference so that scatter and the evaluation towards the light share one */
+template<class M>
+WPT_RGL_ENTRY void rglIncidentCall(const wpt_rgl_brdf& b, const float* pool, V3 wi, RglIncident& inc)
+{
+    inc = rglIncident<M>(b, pool, wi);
+}
+template<class M>
+WPT_RGL_ENTRY V3 rglSampleCall(const wpt_rgl_brdf& b, const float* pool, const RglIncident& inc, V2 u, V3 wi, V3& woOut, float& pdfOut)
+{
+    return rglSampleWith<M>(b, pool, inc, u, wi, woOut, pdfOut);
+}
+template<class M>
+WPT_RGL_ENTRY void rglEvalPdfCall(const wpt_rgl_brdf& b, const float* pool, const RglIncident& inc, V3 wi, V3 wo, V3& frOut, float& pdfOut)
+{
+    rglEvalPdfWith<M>(b, pool, inc, wi, wo, frOut, pdfOut);
 }
 
 } /* namespace wptrgl */

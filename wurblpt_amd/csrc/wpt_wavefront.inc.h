@@ -49,6 +49,9 @@ constexpr uint32_t WF_SLOTS = 16; /* quadwords per lane record */
 #ifndef WF_TRACE_WAVES
 #define WF_TRACE_WAVES 4
 #endif
+#ifndef WF_TRACE_UNIFIED
+#define WF_TRACE_UNIFIED 0 /* 1: every lane keeps one fetch in flight and an iteration runs leaf tests AND node steps (measured slower) */
+#endif
 enum { WF_RAY_O = 8, WF_RAY_D = 9, WF_HIT0 = 10, WF_HIT1 = 11, WF_WALK = 12 };
 constexpr uint32_t WF_RESUME = 0x100u; /* in the kind-of-ray word: the record holds a suspended walk */
 
@@ -88,6 +91,7 @@ struct WfArgs {
     uint32_t leafBias;
     uint32_t stepBudget; /* node steps a ray may take per launch of the trace (0: no limit) */
     uint32_t topNodes;   /* the first topNodes nodes of the array (the top of a large tree, stored level by level) are walked from LDS */
+    uint32_t kindMask;   /* shade: the kinds this launch serves (measurements launch one per kind; normally all) */
 };
 
 WPT_D uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -261,6 +265,77 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
         const bool canRefill = chunkNext != chunkEnd || !dry;
         int leaveBelow = canRefill ? 65 - (int)a.refillIdle : 1;
         leaveBelow = leaveBelow < 1 ? 1 : leaveBelow;
+#if WF_TRACE_UNIFIED
+        /* Unified steps.  Every walking lane has ONE fetch in flight, issued at the end of the iteration before: its next
+         * node's two quadwords, or -- when the step before found a leaf -- the triangle's three.  An iteration waits for
+         * them once and then runs the leaf test for the lanes that came for one and the node step for the others, each
+         * under its mask.  With separate rounds for nodes and leaves (the single kernel's scheduler, and this kernel's first
+         * form) a wave has one memory round trip in flight at a time and a lane stands still through every round of the
+         * other kind.  Measured, bit-exact: Sponza-class 366 against 315 ms, measured BRDFs 1406 against 1262, 10 M triangles
+         * 540 against 510 -- running both stretches of code in every iteration costs more issue time than the shorter wait
+         * gives back.  Not the default (WF_TRACE_UNIFIED). */
+        float4 q2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        auto fetchLeaf = [&](uint32_t prim) {
+            if (!(SPHERES && (prim & PRIM_SPHERE))) {
+                /* leaf records: the corners lie behind the leaf's node, leafPrim is the leaf's slot until the test */
+                const float4* g = sv.leafRecords ? sv.nodes + 2 * (size_t)prim + 2 : sv.triGeom + 3 * (size_t)prim;
+                pn0 = g[0];
+                pn1 = g[1];
+                q2 = g[2];
+            }
+        };
+        if (state == T_LEAF) /* (a lane never enters the loop in this state; kept for symmetry with the refill) */
+            fetchLeaf(leafPrim);
+        for (;;) {
+            const unsigned long long mNode = __ballot(state == T_NODE), mLeaf = __ballot(state == T_LEAF);
+            if (__popcll(mNode) + __popcll(mLeaf) < leaveBelow)
+                break;
+            const bool wasLeaf = state == T_LEAF, wasNode = state == T_NODE;
+            if (mLeaf != 0 && wasLeaf) {
+                /* HitableTriangle::hit / HitableSphere::hit, candidate part; `node` already is the node to go on with */
+                Candidate c;
+                bool accepted;
+                if (SPHERES && (leafPrim & PRIM_SPHERE)) {
+                    c.invDet = c.U = c.V = c.W = 0.0f;
+                    accepted = sphereTest(sv.spheres[leafPrim & ~PRIM_SPHERE], o, d, amin, amax, c.a);
+                } else {
+                    if (sv.leafRecords)
+                        leafPrim = __float_as_uint(pn0.w);
+                    accepted = triangleTest(mk3(pn0.x, pn0.y, pn0.z), mk3(pn1.x, pn1.y, pn1.z), mk3(q2.x, q2.y, q2.z), o, aux, amin, amax, c);
+                }
+                if (accepted) {
+                    c.prim = leafPrim;
+                    best = c;
+                    amax = c.a;
+                }
+                state = node >= nodeCount ? (int)T_DONE : (int)T_NODE;
+                if (state == T_NODE && stepsLeft == 0)
+                    state = T_SUSPEND; /* between two nodes: nothing pending but (node, bound, candidate) */
+            }
+            if (mNode != 0 && wasNode) {
+                /* AABB::mayHit + the stackless form of BVH::hit's walk (wpt_pathtrace.inc.h) */
+                const float4 n0 = pn0, n1 = pn1;
+                const uint32_t skip = __float_as_uint(n1.z);
+                const uint32_t word = __float_as_uint(n1.w);
+                const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, aux.inv, amin, amax);
+                const bool inner = word >= NODE_CHILD;
+                const bool toLeaf = hit && !inner;
+                const uint32_t leafWord = (sv.leafRecords && !(word & PRIM_SPHERE)) ? node : word;
+                leafPrim = toLeaf ? leafWord : leafPrim;
+                node = (hit && inner) ? (word & NODE_INDEX_MASK) : skip;
+                state = toLeaf ? (int)T_LEAF : (int)T_NODE;
+                if (!toLeaf && node >= nodeCount)
+                    state = T_DONE;
+                stepsLeft = stepsLeft ? stepsLeft - 1 : 0;
+                if (state == T_NODE && stepsLeft == 0)
+                    state = T_SUSPEND;
+            }
+            /* what each lane tests next is asked for now */
+            fetchNode(node, state == T_NODE, pn0, pn1);
+            if (state == T_LEAF)
+                fetchLeaf(leafPrim);
+        }
+#else
         for (;;) {
             const int nNode = __popcll(__ballot(state == T_NODE));
             const int nLeaf = __popcll(__ballot(state == T_LEAF));
@@ -318,6 +393,7 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                 fetchNode(node, wantNode, pn0, pn1);
             }
         }
+#endif
         /* ---- finished rays: the candidate goes to the pixel's record, the pixel to the queue of its kind; rays out of
          * steps are written back as they stand and queued for the next trace ---- */
         if (__ballot(state == T_DONE || state == T_SUSPEND) != 0) {
@@ -387,11 +463,11 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
 
 /* Workgroup -> (kind, first entry) over the kinds' queues laid end to end, each kind rounded up to whole workgroups.
  * false: nothing for this workgroup. */
-WPT_D bool shadeSlice(const WfIter* cur, uint32_t group, uint32_t& kind, uint32_t& first, uint32_t& count)
+WPT_D bool shadeSlice(const WfIter* cur, uint32_t kindMask, uint32_t group, uint32_t& kind, uint32_t& first, uint32_t& count)
 {
     uint32_t at = 0;
     for (uint32_t kd = 0; kd < WF_BUCKETS; kd++) {
-        const uint32_t n = cur->bucketCount[kd];
+        const uint32_t n = ((kindMask >> kd) & 1u) ? cur->bucketCount[kd] : 0u;
         const uint32_t groups = (n + WG - 1) / WG;
         if (group < at + groups) {
             kind = kd;
@@ -406,8 +482,11 @@ WPT_D bool shadeSlice(const WfIter* cur, uint32_t group, uint32_t& kind, uint32_
 
 /* INIT: the first launch of a group -- every lane takes its pixel, seeds the generator and starts the first sample.
  * Otherwise one path component per queued pixel. */
+#ifndef WF_SHADE_WAVES
+#define WF_SHADE_WAVES 4 /* waves per SIMD the shade kernels are built for (their LDS allows four workgroups per compute unit) */
+#endif
 template<uint32_t F, bool INIT>
-__global__ __launch_bounds__(WG, 4) void wf_shade(const WfArgs a)
+__global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
 {
     /* [ math tables ][ cold path words: SLOT_COUNT x WG float4 ][ 8 words: compaction ] */
     extern __shared__ float4 lds[];
@@ -428,7 +507,7 @@ __global__ __launch_bounds__(WG, 4) void wf_shade(const WfArgs a)
     if (INIT) {
         count = a.laneCount;
     } else if (a.buckets) {
-        if (shadeSlice(cur, blockIdx.x, kind, first, count))
+        if (shadeSlice(cur, a.kindMask, blockIdx.x, kind, first, count))
             queueIn = a.bucketQueue + (size_t)kind * a.laneCount;
         else
             return; /* uniform for the workgroup */

@@ -89,6 +89,7 @@ hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, c
     if (const char* e = getenv("WPT_WF_TRACE_PER_CU")) /* experiments: workgroups of the trace per compute unit */
         perCu = std::max(1, std::min(perCu, atoi(e)));
     const uint32_t traceResident = uint32_t(perCu) * std::max(1u, args.cuCount);
+    const bool perKind = getenv("WPT_WF_SHADE_PER_KIND") != nullptr;
 
     float4* state = nullptr;
     uint32_t* queues = nullptr;
@@ -118,6 +119,7 @@ hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, c
         gr.args.chunk = chunk;
         gr.args.refillIdle = cfg.refillIdle ? cfg.refillIdle : 16u;
         gr.args.leafBias = cfg.leafBias ? cfg.leafBias : 32u;
+        gr.args.kindMask = (1u << WF_BUCKETS) - 1u;
         gr.args.stepBudget = cfg.stepBudget == 0xffffffffu ? 0u : (cfg.stepBudget ? cfg.stepBudget : 512u);
         /* the top of the tree in LDS: with the 8 KiB of staging, four workgroups per compute unit hold 32 KiB each */
         gr.args.topNodes = cfg.topNodes == 0xffffffffu ? 0u : std::min(std::min(cfg.topNodes ? cfg.topNodes : 768u, 768u), args.sv.nodeCount);
@@ -153,7 +155,17 @@ hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, c
             for (uint32_t i = 0; i < BATCH; i++) {
                 gr.args.iteration = gr.iteration + i;
                 kernels.trace(gr.args, dim3(traceGroups), s);
-                kernels.shade(gr.args, dim3(shadeGroups), s);
+                if (perKind && gr.args.buckets) {
+                    /* measurements: one shade launch per kind, so that a kernel trace tells what each kind costs */
+                    for (uint32_t kd = 0; kd < WF_BUCKETS; kd++) {
+                        gr.args.kindMask = 1u << kd;
+                        kernels.shade(gr.args, dim3(shadeGroups), s);
+                    }
+                    gr.args.kindMask = (1u << WF_BUCKETS) - 1u;
+                    launched += WF_BUCKETS - 1;
+                } else {
+                    kernels.shade(gr.args, dim3(shadeGroups), s);
+                }
             }
             launched += 2 * BATCH;
             gr.iteration += BATCH;
