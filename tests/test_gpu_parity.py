@@ -997,11 +997,11 @@ def _wavefront(dev, mode, groups=0, chunk=0, flags=0):
 
 
 @pytest.mark.parametrize("groups,chunk,flags", [(1, 0, 0), (2, 64, 1 | (7 << 16)), (3, 32, 0x800 | (1 << 16)), (2, 0, 0x2000 | (0xffff << 16)),
-                                                (2, 0, (33 << 16) | 0xfe), (1, 16, (2 << 1) | (5 << 16))])
+                                                (2, 0, (33 << 16) | 0xfe), (1, 16, (2 << 1) | (5 << 16)), (2, 32, 0x5000), (1, 0, 0x4000 | (9 << 16))])
 def test_wavefront_kernels_bit_exact(dev, oracle, groups, chunk, flags):
     """The wavefront form (wpt_wavefront.inc.h: trace and shade as two kernels that hand every ray through HBM, pixels filed by
     kind of material, walks suspended after a budget of node steps and taken up again by the next launch, the top of the tree in
-    LDS, groups of lanes on streams of their own) against the oracle, for every family of scene it exists for and over its launch
+    LDS, groups of lanes on streams of their own, rays dealt lane by lane or in whole batches whose stragglers are parked) against the oracle, for every family of scene it exists for and over its launch
     geometry: whole frames, a ragged block, interleaved bands.  wpt_kernel_name() tells which kernels rendered."""
     import torch
     p = host.default_params()

@@ -209,7 +209,11 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
     for (;;) {
         /* ---- deal rays to the lanes that have none ---- */
         const unsigned long long idle = __ballot(state == T_IDLE);
-        if (idle != 0) {
+        /* batches (refillIdle >= 64): rays are dealt to an EMPTY wave only, so that its lanes start at the root together
+         * and walk the top of the tree over the same lines; what still walks when fewer than refillIdle - 64 lanes are left
+         * is suspended and queued for the next launch */
+        const bool batches = a.refillIdle >= 64u;
+        if (idle != 0 && (!batches || idle == ~0ull)) {
             if (chunkNext == chunkEnd && !dry) {
                 uint32_t first = 0;
                 if (lane == 0)
@@ -264,6 +268,13 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
         /* walk until refillIdle lanes have finished (while there is something to deal them), or to the end */
         const bool canRefill = chunkNext != chunkEnd || !dry;
         int leaveBelow = canRefill ? 65 - (int)a.refillIdle : 1;
+        if (batches) {
+            /* never more than a quarter of the batch: a small batch (the end of a frame has few rays left) parked before it
+             * has walked would come back the same, launch after launch, without end */
+            const int walking = __popcll(__ballot(state != T_IDLE));
+            const int quarter = walking >> 2;
+            leaveBelow = canRefill ? ((int)a.refillIdle - 64 < quarter ? (int)a.refillIdle - 64 : quarter) : 1;
+        }
         leaveBelow = leaveBelow < 1 ? 1 : leaveBelow;
 #if WF_TRACE_UNIFIED
         /* Unified steps.  Every walking lane has ONE fetch in flight, issued at the end of the iteration before: its next
@@ -394,6 +405,32 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
             }
         }
 #endif
+        if (batches && canRefill && __ballot(state == T_NODE || state == T_LEAF) != 0) {
+            /* the few that still walk make room for a full batch: a pending leaf test first (a walk is suspended between
+             * two nodes), then they are written back as they stand */
+            if (state == T_LEAF) {
+                Candidate c;
+                bool accepted;
+                if (SPHERES && (leafPrim & PRIM_SPHERE)) {
+                    c.invDet = c.U = c.V = c.W = 0.0f;
+                    accepted = sphereTest(sv.spheres[leafPrim & ~PRIM_SPHERE], o, d, amin, amax, c.a);
+                } else {
+                    const float4* g = sv.leafRecords ? sv.nodes + 2 * (size_t)leafPrim + 2 : sv.triGeom + 3 * (size_t)leafPrim;
+                    const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+                    if (sv.leafRecords)
+                        leafPrim = __float_as_uint(g0.w);
+                    accepted = triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), o, aux, amin, amax, c);
+                }
+                if (accepted) {
+                    c.prim = leafPrim;
+                    best = c;
+                    amax = c.a;
+                }
+                state = node >= nodeCount ? (int)T_DONE : (int)T_NODE;
+            }
+            if (state == T_NODE)
+                state = T_SUSPEND;
+        }
         /* ---- finished rays: the candidate goes to the pixel's record, the pixel to the queue of its kind; rays out of
          * steps are written back as they stand and queued for the next trace ---- */
         if (__ballot(state == T_DONE || state == T_SUSPEND) != 0) {
