@@ -26,7 +26,7 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_${
 echo done cornell+sponza
 fi
 if [[ $PART == *2* ]]; then
-Y="--workload courtyard_like_10M_1920x1080_121spp --steps 1 --warmup 1"
+Y="--workload courtyard_like_10M_1920x1080_121spp --steps 1 --warmup 1 --no-secondary"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_${TAG}_courtyard -o stats --output-format csv -- python3 bench.py $Y --no-cpu-baseline > gpurun_out/stats_${TAG}_courtyard.log 2>&1 || exit 1
 for P in "FETCH_SIZE" "WRITE_SIZE" "VALUBusy VALUUtilization" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   N=$(echo $P | tr " " "_" | cut -c1-40)
