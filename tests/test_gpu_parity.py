@@ -1109,3 +1109,18 @@ def test_leaf_records_never_change_results(dev, oracle):
     finally:
         dev.lib().wpt_set_top_nodes(65536)
         _wavefront(dev, 0)
+
+
+def test_wavefront_render_calls_from_several_threads(dev, oracle):
+    """mcpt() with an MPICoordinator of three workers (one device named three times): each worker thread renders its bands with a
+    render call of its own, here in wavefront form -- buffers, streams and queue counters are per call, so concurrent calls on one
+    scene do not meet; the frame is the oracle's."""
+    sc = host.cornell(64, 48, 1, 2)
+    ref, _ = oracle.render(sc, 3)
+    try:
+        _wavefront(dev, 1, 2, 32, 11 << 16)
+        for _ in range(2):          # the second round takes its streams and events from the free list the first one filled
+            got = host.mcpt(sc, 3, workers=3)
+            assert bits_equal(got, ref)
+    finally:
+        _wavefront(dev, 0)

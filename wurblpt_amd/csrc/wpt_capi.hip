@@ -827,11 +827,16 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
         const wptk::WfLaunchers& kernels = rgl ? wptk::wfFullRgl() : (basic ? wptk::wfBasic() : wptk::wfFull());
         uint32_t launches = 0;
         const hipError_t e = wptk::renderWavefront(args, kernels, g_wfConfig, stream, &launches);
-        g_lastPasses = launches;
-        g_kernelName = "wf";
-        if (e != hipSuccess)
-            return fail(WPT_ERR_HIP, std::string("wavefront render: ") + hipGetErrorString(e));
-        return WPT_OK;
+        if (e == hipSuccess) {
+            g_lastPasses = launches;
+            g_kernelName = "wf";
+            return WPT_OK;
+        }
+        /* The library's own choice must not fail where the single kernel would not: without the memory for the records
+         * (256 B per lane) the frame is rendered by the single kernel below.  A forced wavefront render reports the error. */
+        if (g_wfMode == 1u || e != hipErrorOutOfMemory)
+            return fail(e == hipErrorOutOfMemory ? WPT_ERR_OUT_OF_MEMORY : WPT_ERR_HIP, std::string("wavefront render: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
     }
     g_kernelName = nullptr;
     uint32_t* pool = nullptr;

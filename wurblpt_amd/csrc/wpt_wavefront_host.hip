@@ -9,7 +9,7 @@
 
 #include <algorithm>
 #include <cstdlib>
-#include <map>
+#include <mutex>
 #include <vector>
 
 #include "wpt_wavefront.inc.h"
@@ -21,34 +21,57 @@ namespace {
 constexpr uint32_t BATCH = 32;        /* iterations between two looks at a group's queue length; divides WF_RING */
 constexpr uint32_t MAX_GROUPS = 8;
 
-/* per host thread and device: the groups' streams, events, and the pinned words the queue lengths are copied to */
-struct ThreadResources {
+/* what one render call needs besides its buffers: the groups' streams, events, and the pinned words the queue lengths are
+ * copied to.  A call takes a set from the device's free list (or makes one) and gives it back: as many sets exist as
+ * calls have ever run at once on the device, whatever threads made them (MPICoordinator starts its workers anew for every
+ * frame), and none is destroyed -- at process exit the runtime may be gone before a destructor of ours would run. */
+struct CallResources {
     hipStream_t stream[MAX_GROUPS];
     hipEvent_t batchDone[MAX_GROUPS][2];
     hipEvent_t fork, join[MAX_GROUPS];
     uint32_t* pinned; /* [MAX_GROUPS][2] */
-    bool ok;
+    int device;
 };
 
-ThreadResources* threadResources(int device)
+std::mutex g_resourcesLock;
+std::vector<CallResources*> g_freeResources;
+
+CallResources* acquireResources(int device)
 {
-    thread_local std::map<int, ThreadResources> perDevice;
-    auto it = perDevice.find(device);
-    if (it != perDevice.end())
-        return it->second.ok ? &it->second : nullptr;
-    ThreadResources r;
-    r.ok = true;
-    r.pinned = nullptr;
-    for (uint32_t g = 0; g < MAX_GROUPS && r.ok; g++) {
-        r.ok = r.ok && hipStreamCreateWithFlags(&r.stream[g], hipStreamNonBlocking) == hipSuccess;
-        r.ok = r.ok && hipEventCreateWithFlags(&r.batchDone[g][0], hipEventDisableTiming) == hipSuccess;
-        r.ok = r.ok && hipEventCreateWithFlags(&r.batchDone[g][1], hipEventDisableTiming) == hipSuccess;
-        r.ok = r.ok && hipEventCreateWithFlags(&r.join[g], hipEventDisableTiming) == hipSuccess;
+    {
+        std::lock_guard<std::mutex> lock(g_resourcesLock);
+        for (size_t i = 0; i < g_freeResources.size(); i++) {
+            if (g_freeResources[i]->device == device) {
+                CallResources* r = g_freeResources[i];
+                g_freeResources.erase(g_freeResources.begin() + long(i));
+                return r;
+            }
+        }
     }
-    r.ok = r.ok && hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess;
-    r.ok = r.ok && hipHostMalloc(reinterpret_cast<void**>(&r.pinned), MAX_GROUPS * 2 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
-    auto& stored = perDevice[device] = r;
-    return stored.ok ? &stored : nullptr;
+    CallResources* r = new CallResources;
+    r->device = device;
+    r->pinned = nullptr;
+    bool ok = true;
+    for (uint32_t g = 0; g < MAX_GROUPS && ok; g++) {
+        ok = ok && hipStreamCreateWithFlags(&r->stream[g], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&r->batchDone[g][0], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&r->batchDone[g][1], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&r->join[g], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&r->pinned), MAX_GROUPS * 2 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    if (!ok) { /* whatever was made stays unused: this path means the device is out of resources anyway */
+        (void)hipGetLastError();
+        delete r;
+        return nullptr;
+    }
+    return r;
+}
+
+void releaseResources(CallResources* r)
+{
+    std::lock_guard<std::mutex> lock(g_resourcesLock);
+    g_freeResources.push_back(r);
 }
 
 struct Group {
@@ -72,7 +95,7 @@ hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, c
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess)
         return hipErrorInvalidDevice;
-    ThreadResources* tr = threadResources(device);
+    CallResources* tr = acquireResources(device);
     if (!tr)
         return hipErrorOutOfMemory;
     const uint32_t lanes = args.blockSize;
@@ -215,6 +238,10 @@ hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, c
             (void)hipFreeAsync(p, stream);
     if (launches)
         *launches = launched;
+    /* everything of this call on the groups' streams is done or (after an error) waited for: the set may serve another call */
+    for (uint32_t g = 0; g < groupCount && g < MAX_GROUPS; g++)
+        (void)hipStreamSynchronize(tr->stream[g]);
+    releaseResources(tr);
     return status;
 #undef WF_TRY
 }
