@@ -2,6 +2,9 @@
 #define WPT_MATH_TABLES_IN_LDS /* this unit's kernels keep the tables of expf / powf in LDS (wpt_math.h) */
 #include "wpt_pathtrace.inc.h"
 
+#ifndef WPT_FULL_FEATURES
+#define WPT_FULL_FEATURES FEAT_ALL /* experiments: a narrower set for scenes that need no more */
+#endif
 #ifndef WPT_FULL_OCC
 #define WPT_FULL_OCC 4 /* experiments: 3 = 168 registers, no spills, three workgroups per compute unit */
 #endif
@@ -10,7 +13,7 @@ namespace wptk {
 
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    launchMaybePooled(wpt_pathtrace<FEAT_ALL, false, false, WPT_FULL_OCC>, args, grid, COLD_BYTES, stream);
+    launchMaybePooled(wpt_pathtrace<WPT_FULL_FEATURES, false, false, WPT_FULL_OCC>, args, grid, COLD_BYTES, stream);
 }
 
 }
