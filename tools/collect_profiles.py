@@ -13,10 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "profiles")
 WORK = {"c": ("cornell", "cornell_1024x1024_1024spp_ggx_glass"),
         "s": ("sponza", "sponza_like_1920x1080_256spp_envmap_is"),
-        "y": ("courtyard", "courtyard_like_10M_1920x1080_121spp")}
+        "y": ("courtyard", "courtyard_like_10M_1920x1080_121spp"),
+        "m": ("measured", "measured_like_3840x2160_529spp_rgl")}
 
 
-SAMPLES = {"c": 1024 * 1024 * 1024, "s": 1920 * 1080 * 256, "y": 1920 * 1080 * 121}  # samples per launch of the product kernel
+SAMPLES = {"c": 1024 * 1024 * 1024, "s": 1920 * 1080 * 256, "y": 1920 * 1080 * 121, "m": 3840 * 2160 * 529}  # samples per launch of the product kernel
 
 
 RATIOS = ("Busy", "Utilization", "Occupancy", "Stalled", "_avr")   # averaged over a launch, not summed
@@ -62,11 +63,26 @@ for letter, (short, workload) in WORK.items():
     agg = counters(tag + letter)
     if not agg:
         continue
+    wf = [(k, c) for (k, c) in agg if "wf_trace" in k or "wf_shade" in k]
+    if wf and library is not None:
+        # The wavefront form: a frame is hundreds of launches of two kernels.  Per frame = all their launches of the run over the
+        # render calls the bench line says it made (warm-up + steps); ratios are weighted by the kernels' total durations.
+        line = json.loads([l for l in open(log) if l.startswith("{\"metric\"")][-1])
+        calls = int(line["steps"]) + int(line["warmup"])
+        combined = {}
+        for c in sorted(set(c for _, c in wf)):
+            if any(x in c for x in RATIOS):
+                continue   # busy / utilisation figures stay per kernel
+            # agg holds per-frame values by the single kernel's idea of a frame: value x frames = the run's total
+            combined[c] = sum(agg[(k, cc)][0] * agg[(k, cc)][1] for (k, cc) in wf if cc == c) / calls
+        for c, v in combined.items():
+            agg[("wf_trace + wf_shade (all launches of a frame)", c)] = (v, calls, sum(agg[(k, cc)][2] for (k, cc) in wf if cc == c))
     with open(os.path.join(OUT, "%s_pmc_%s.txt" % (prefix, short)), "w") as f:
         f.write("# rocprofv3 --pmc passes (one counter group per run, tools/profile_round.sh) of\n# python3 bench.py --workload %s --no-cpu-baseline; per frame: counters summed over a frame's launches (two passes = two\n# launches of one kernel), busy / utilisation / occupancy weighted by the launches' durations\n" % workload)
         for (k, c), (v, frames, launches) in sorted(agg.items()):
             f.write("%-58s %-30s frames=%d launches=%d per_frame=%.6g\n" % (k, c, frames, launches, v))
     prod = [k for (k, c) in agg if c == "FETCH_SIZE" and "u, true, " not in k]  # not the counting build
+    prod.sort(key=lambda k: 0 if k.startswith("wf_trace + wf_shade") else (2 if "wf_" in k else 1))   # the frame's sum where the wavefront form rendered
     if prod:
         k = prod[0]
         fetch = agg[(k, "FETCH_SIZE")][0]

@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/profile_round.sh <tag> [1|2|c]
 # kernel-trace statistics of the default bench command, then PMC passes (each its own run);
-# part 1 = Cornell + Sponza-class, part 2 = the 10 M triangle scene (default: both); c = Cornell alone
+# part 1 = Cornell + Sponza-class, part 2 = the 10 M triangle scene (default: both); c = Cornell alone; m = the Bistro-class frame
+# with measured BRDFs (wavefront kernels; one frame per pass)
 export TMPDIR=/tmp
 TAG=$1
 PART=${2:-12}
@@ -33,4 +34,14 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "VALUBusy VALUUtilization" "TCC_HIT_sum TCC_M
   timeout -k 10 500 rocprofv3 --pmc $P --kernel-trace -d gpurun_out/pmc_${TAG}y_$N -o pmc --output-format csv -- python3 bench.py $Y --no-cpu-baseline > gpurun_out/pmc_${TAG}y_$N.log 2>&1 || exit 1
 done
 echo done courtyard
+fi
+if [[ $PART == *m* ]]; then
+M="--workload measured_like_3840x2160_529spp_rgl --steps 1 --warmup 0 --no-secondary"
+timeout -k 10 700 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_${TAG}_measured -o stats --output-format csv -- python3 bench.py $M --no-cpu-baseline > gpurun_out/stats_${TAG}_measured.log 2>&1 || exit 1
+for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "VALUBusy VALUUtilization"; do
+  N=$(echo $P | tr " " "_" | cut -c1-40)
+  timeout -k 10 700 rocprofv3 --pmc $P --kernel-trace -d gpurun_out/pmc_${TAG}m_$N -o pmc --output-format csv -- python3 bench.py $M --no-cpu-baseline > gpurun_out/pmc_${TAG}m_$N.log 2>&1 || exit 1
+  echo pass $N done
+done
+echo done measured
 fi
