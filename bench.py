@@ -291,7 +291,8 @@ def main():
     ap.add_argument("--dynamic-blocks", action="store_true",
                     help="N > 1: hand blocks out from a shared counter as MPICoordinator does (default: block i to rank i mod N)")
     ap.add_argument("--verify", action="store_true",
-                    help="after the timed steps rank 0 renders the frame once more in a single launch and compares (bit for bit)")
+                    help="after the timed steps rank 0 renders the frame once more in a single launch and compares (bit for bit); on by default when N > 1")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip that comparison and the oracle rows")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant / scheduler tuning word for wpt_set_launch_config (experiments)")
     ap.add_argument("--wavefront", type=int, default=0, help="wpt_set_wavefront mode: 0 = the library decides, 1 = wavefront kernels wherever they exist, 2 = never")
     ap.add_argument("--top-nodes", type=int, default=-1, help="BVH nodes stored level by level in front of the array (wpt_set_top_nodes; experiments)")
@@ -484,12 +485,19 @@ def main():
 
     ok = bool(torch.isfinite(frame).all().item()) if rank == 0 else True
     verified = None
-    if args.verify and rank == 0:
+    parity = None
+    if (args.verify or (world > 1 and not args.no_verify)) and rank == 0:
         # the sharded frame (rank 0 holds the sum of all ranks' bands) against one launch over all pixels
         whole = torch.zeros_like(frame)
         dscene.render_block_into(whole, ssqrt, None, params, None, main_stream)
         torch.cuda.synchronize()
         verified = bool(torch.equal(whole.view(torch.int32), frame.view(torch.int32)))
+        del whole
+        if cpu_seconds > 0:
+            # and rows around the middle of it against the oracle (a few seconds of the host cores; several ranks' bands
+            # where the bands are narrow); untimed, and not a cpu_baseline: that is measured at N = 1 only
+            _, oframe, ostart, opixels = cpu_baseline(scene, w, min(cpu_seconds, 4.0))
+            parity = parity_of(frame.cpu().numpy(), oframe, ostart, opixels, width)
     if rank == 0:
         total_samples = float(pixels) * spp * args.steps
         avg_ms = sum(m for m, _ in launches) / max(1, len(launches))
@@ -522,6 +530,8 @@ def main():
         }
         if verified is not None:
             out["frame_equals_single_launch"] = verified
+        if parity is not None:
+            out["parity"] = parity
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1111,6 +1111,31 @@ def test_leaf_records_never_change_results(dev, oracle):
         _wavefront(dev, 0)
 
 
+@pytest.mark.parametrize("every", [1, 3])
+def test_redealing_kernel_bit_exact(dev, oracle, every):
+    """WPT_REDEAL=n (a measurement hook): the kernel with the scene in LDS whose workgroups deal their 256
+    paths to their lanes anew at every n-th look at the lane counts, sorted by what the paths need next.  Which lane a path
+    sits in never shows: a small frame and a frame of more pixels than the device
+    holds lanes (finished paths take the next pixels from the pool, in whichever wave they have come to rest) are the oracle's."""
+    import os
+    small = host.cornell(96, 64, 1, 2)
+    large = host.cornell(640, 512, 1, 2)
+    try:
+        os.environ["WPT_REDEAL"] = str(every)
+        for sc, ssqrt in ((small, 4), (large, 2)):
+            ref, _ = oracle.render(sc, ssqrt)
+            ds = dev.DeviceScene(sc)
+            got, _ = ds.render(ssqrt)
+            assert dev.lib().wpt_kernel_name() == b"wpt_pathtrace, paths re-dealt"
+            assert bits_equal(got, ref), (sc.width, sc.height)
+        os.environ["WPT_REDEAL_IDENTITY"] = "1"
+        got, _ = dev.DeviceScene(small).render(4)
+        assert bits_equal(got, oracle.render(small, 4)[0])
+    finally:
+        os.environ.pop("WPT_REDEAL", None)
+        os.environ.pop("WPT_REDEAL_IDENTITY", None)
+
+
 def test_wavefront_render_calls_from_several_threads(dev, oracle):
     """mcpt() with an MPICoordinator of three workers (one device named three times): each worker thread renders its bands with a
     render call of its own, here in wavefront form -- buffers, streams and queue counters are per call, so concurrent calls on one

@@ -829,7 +829,7 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
         const hipError_t e = wptk::renderWavefront(args, kernels, g_wfConfig, stream, &launches);
         if (e == hipSuccess) {
             g_lastPasses = launches;
-            g_kernelName = "wf";
+            g_kernelName = "wf_trace + wf_shade";
             return WPT_OK;
         }
         /* The library's own choice must not fail where the single kernel would not: without the memory for the records
@@ -854,6 +854,14 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     args.cost = nullptr;
     args.order = nullptr;
     args.orderCount = nullptr;
+    /* Measurements (a kept negative): the kernel whose workgroups deal their paths to their lanes anew,
+     * sorted by what they need next, at every n-th look at the lane counts (WPT_REDEAL=n; with WPT_REDEAL_IDENTITY every
+     * path stays in its lane at the full price of a deal).  Scenes in LDS, as long as the staging area fits with them into
+     * the 64 KiB a workgroup may ask for.  Read per launch: tools/redeal_cost.py changes it within a process. */
+    const char* const redealWord = getenv("WPT_REDEAL");
+    const bool redeal = redealWord != nullptr && atoi(redealWord) > 0
+            && COLD_BYTES + ldsBytes + size_t(scene->view.materialCount) * sizeof(wpt_material) + wptk::REDEAL_BYTES <= 64u * 1024u;
+    args.redealEvery = redeal ? (uint32_t(atoi(redealWord)) & 0xffffu) | (getenv("WPT_REDEAL_IDENTITY") ? 0x80000000u : 0u) : 1u;
     auto launch = [&](const wptk::KernelArgs& a) {
         if (anim) {
             /* its own instantiation, like the measured BRDFs */
@@ -877,7 +885,11 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
         } else if (rgl) {
             launchFullRgl(a, grid, stream);
         } else {
-            if (basic && lds)
+            if (basic && lds && redeal)
+                g_kernelName = "wpt_pathtrace, paths re-dealt";
+            if (basic && lds && redeal)
+                launchBasicLdsRedeal(a, grid, ldsBytes + (a.materialsInLds ? size_t(scene->view.materialCount) * sizeof(wpt_material) : 0), stream);
+            else if (basic && lds)
                 launchBasicLds(a, grid, ldsBytes + (a.materialsInLds ? size_t(scene->view.materialCount) * sizeof(wpt_material) : 0), stream);
             else if (basic)
                 launchBasic(a, grid, stream);
@@ -1236,7 +1248,7 @@ wpt_status wpt_set_scheduler_stats(unsigned long long* stats_device)
 const char* wpt_kernel_name(void)
 {
     /* the kernel family of the calling thread's last render call */
-    return g_kernelName ? "wf_trace + wf_shade" : "wpt_pathtrace";
+    return g_kernelName ? g_kernelName : "wpt_pathtrace";
 }
 
 const char* wpt_device_name(int device)

@@ -81,6 +81,7 @@ struct KernelArgs {
     uint32_t leafBias;     /* scheduler: leaf tests run when waiting lanes * leafBias >= walking lanes * 8 */
     uint32_t waitBelow;    /* scheduler: a kind of material with fewer lanes than this in a long round stands back once (0 = never) */
     uint32_t fuse;         /* scheduler: 1 = one long round serves SHADE, NEE-END and NEW lanes together */
+    uint32_t redealEvery;  /* re-dealing kernel: the workgroup deals its paths anew at every n-th look at the lane counts */
     float* frame;
     /* Pixel pool (or NULL): lanes whose pixel is finished take the next lane index of the launch from this counter, which
      * starts at the number of lanes launched.  A launch then is as many workgroups as the GPU holds at once, and a wave
@@ -174,9 +175,18 @@ WPT_D void fetchNodePaired(const float4* nodes, uint32_t node, bool need, float4
 /* lane states, in scheduling priority order for ties */
 enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5, S_START = 6 /* within a long round: has a ray to start */ };
 
-template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC>
+/* REDEAL (scene in LDS only): at every look at the lane counts the workgroup deals its 256 paths to its lanes anew, sorted by
+ * what they need next -- traversal, shading by kind of material, the end of a light ray, a new sample, nothing.  A path's cold
+ * words stay where they are in LDS (ps.base is the path's slot, not the lane's); its 22 hot words change lanes through a
+ * staging area of three quadwords per lane, in two rounds.  What a path computes does not depend on the lane it sits in. */
+constexpr uint32_t REDEAL_CLASSES = 8;
+constexpr uint32_t REDEAL_STAGE_QUADS = 3;
+constexpr uint32_t REDEAL_BYTES = (WG / 64) * REDEAL_CLASSES * 4 + REDEAL_STAGE_QUADS * WG * 16;
+
+template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, bool REDEAL = false>
 __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 {
+    static_assert(!REDEAL || (LDSSCENE && !COUNT && !(F & (FEAT_ANIM | FEAT_SPHERES))), "re-dealing: the plain kernel with the scene in LDS");
     /* node prefetch: for scenes in HBM (Sponza-class frame 3 % faster); not from LDS, where the eight registers cost more
      * than the short fetch (Cornell 4 % slower) */
     constexpr bool PREFETCH = !LDSSCENE;
@@ -208,9 +218,11 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     const wpt_params& par = args.par;
     const uint32_t nodeCount = sv.nodeCount;
 
+    uint32_t ldsSceneQuads = 0; /* REDEAL: its words lie behind the scene */
     if (LDSSCENE) {
         /* nodes (2 x float4 each) followed by the triangle positions (3 x float4 each) */
         const uint32_t n4 = 2 * nodeCount, t4 = 3 * sv.triCount;
+        ldsSceneQuads = n4 + t4 + (args.materialsInLds ? sv.materialCount * (uint32_t)(sizeof(wpt_material) / 16) : 0u);
         for (uint32_t i = threadIdx.x; i < n4; i += WG)
             ldsScene[i] = sv.nodes[i];
         for (uint32_t i = threadIdx.x; i < t4; i += WG)
@@ -315,18 +327,137 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             state = next == NEXT_NEW ? (int)S_NEW : (int)S_DONE;
     };
 
+    /* idle lanes take the next pixels of the launch: one atomic per wave */
+    auto fromPool = [&]() {
+        if (!COUNT && args.pool && !poolDry) {
+            const unsigned long long idle = __ballot(state == S_DONE);
+            if (idle != 0) {
+                const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                const uint32_t want = (uint32_t)__popcll(idle);
+                const int leader = __ffsll((long long)idle) - 1;
+                uint32_t first = 0;
+                if ((int)lane == leader)
+                    first = atomicAdd(args.pool, want);
+                first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+                poolDry = first + want >= laneLimit; /* the counter only grows: nothing behind it for this wave */
+                if (state == S_DONE) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    if (startPixel(first + rank))
+                        state = S_NEW;
+                }
+            }
+        }
+    };
+
+    uint32_t looks = 0;
     for (;;) {
         /* ---- the wave's scheduler ----
          * Traversal (NODE steps and LEAF tests) is one block with its own inner policy; the long
          * blocks (SHADE, NEE-END, NEW) run when they are well filled, or when no traversal work
          * is left in the wave.  Waiting lanes lose nothing but time: every lane still executes
          * its own operations in order. */
+        if (REDEAL && (looks++ % (args.redealEvery & 0xffffu)) == 0) { /* the waves of a workgroup count their looks alike */
+            uint32_t* const ldsCounts = reinterpret_cast<uint32_t*>(ldsScene + ldsSceneQuads); /* [wave][class] */
+            float4* const ldsStage = ldsScene + ldsSceneQuads + (WG / 64) * REDEAL_CLASSES / 4;  /* [quad][lane] */
+            const uint32_t wave = threadIdx.x >> 6;
+            const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            /* what the path needs next: 0 traversal, 1 - 4 shading (no hit or a light, Lambertian, GGX, the rest), 5 the end
+             * of a light ray, 6 a new sample, 7 nothing */
+            uint32_t cls = 7;
+            if (state == S_NODE || state == S_LEAF) {
+                cls = 0;
+            } else if (state == S_SHADE) {
+                cls = 1;
+                if (best.prim != NO_HIT) {
+                    const wpt_material* m = sv.materials + __float_as_uint(tri4(3 * best.prim + 1).w);
+                    for (int guard = 0; guard < 4 && m->type == WPT_MAT_TWOSIDED; guard++)
+                        m = sv.materials + (best.invDet < 0.0f ? m->tex[1] : m->tex[0]);
+                    const uint32_t type = m->type;
+                    cls = type == WPT_MAT_LIGHT_DIFFUSE ? 1u : type == WPT_MAT_LAMBERTIAN ? 2u : type == WPT_MAT_GGX ? 3u : 4u;
+                }
+            } else if (state == S_NEEEND) {
+                cls = 5;
+            } else if (state == S_NEW) {
+                cls = 6;
+            }
+            uint32_t inWave[REDEAL_CLASSES];
+            uint32_t rank = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < REDEAL_CLASSES; c++) {
+                const unsigned long long of = __ballot(cls == c);
+                inWave[c] = (uint32_t)__popcll(of);
+                if (cls == c)
+                    rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(of >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)of, 0u));
+            }
+            if (lane == 0) {
+                uint4* const mine = reinterpret_cast<uint4*>(ldsCounts + wave * REDEAL_CLASSES);
+                mine[0] = make_uint4(inWave[0], inWave[1], inWave[2], inWave[3]);
+                mine[1] = make_uint4(inWave[4], inWave[5], inWave[6], inWave[7]);
+            }
+            __syncthreads();
+            /* place of the path in the workgroup's order: classes one after the other, within a class wave by wave */
+            uint32_t dest = 0, before = 0, idle = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < REDEAL_CLASSES; c++) {
+                uint32_t mineAt = before;
+#pragma unroll
+                for (uint32_t w = 0; w < WG / 64; w++) {
+                    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)ldsCounts[w * REDEAL_CLASSES + c]);
+                    if (w < wave)
+                        mineAt += n;
+                    before += n;
+                    if (c == REDEAL_CLASSES - 1)
+                        idle += n;
+                }
+                if (cls == c)
+                    dest = mineAt + rank;
+            }
+            if (idle == WG)
+                break; /* the whole workgroup at once: nothing left for any of its paths */
+            if (args.redealEvery & 0x80000000u)
+                dest = threadIdx.x; /* measurements: every path stays where it is, at the full price of a deal */
+            const uint32_t path = (uint32_t)(ps.base - ldsCold);
+            ldsStage[dest] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+            ldsStage[WG + dest] = make_float4(ps.d.y, ps.d.z, aux.inv.x, aux.inv.y);
+            ldsStage[2 * WG + dest] = make_float4(aux.inv.z, __int_as_float(aux.k), aux.Sx, aux.Sy);
+            __syncthreads();
+            {
+                const float4 q0 = ldsStage[threadIdx.x], q1 = ldsStage[WG + threadIdx.x], q2 = ldsStage[2 * WG + threadIdx.x];
+                ps.o = mk3(q0.x, q0.y, q0.z);
+                ps.d = mk3(q0.w, q1.x, q1.y);
+                aux.inv = mk3(q1.z, q1.w, q2.x);
+                aux.k = __float_as_int(q2.y);
+                aux.Sx = q2.z;
+                aux.Sy = q2.w;
+            }
+            __syncthreads();
+            ldsStage[dest] = make_float4(__uint_as_float(node), __uint_as_float(leafPrim), amax, __uint_as_float(best.prim));
+            ldsStage[WG + dest] = make_float4(best.a, best.invDet, best.U, best.V);
+            ldsStage[2 * WG + dest] = make_float4(best.W, __uint_as_float((uint32_t)state | ((uint32_t)ps.rayKind << 4) | (path << 8)), 0.0f, 0.0f);
+            __syncthreads();
+            {
+                const float4 q0 = ldsStage[threadIdx.x], q1 = ldsStage[WG + threadIdx.x], q2 = ldsStage[2 * WG + threadIdx.x];
+                node = __float_as_uint(q0.x);
+                leafPrim = __float_as_uint(q0.y);
+                amax = q0.z;
+                best.prim = __float_as_uint(q0.w);
+                best.a = q1.x;
+                best.invDet = q1.y;
+                best.U = q1.z;
+                best.V = q1.w;
+                best.W = q2.x;
+                const uint32_t word = __float_as_uint(q2.y);
+                state = (int)(word & 15u);
+                ps.rayKind = (int)((word >> 4) & 15u);
+                ps.base = ldsCold + (word >> 8);
+            }
+        }
         const int cTrav = __popcll(__ballot(state == S_NODE || state == S_LEAF));
         const int cShade = __popcll(__ballot(state == S_SHADE));
         const int cNee = __popcll(__ballot(state == S_NEEEND));
         const int cNew = __popcll(__ballot(state == S_NEW));
-        if ((cTrav | cShade | cNee | cNew) == 0)
-            break;
+        if (!REDEAL && (cTrav | cShade | cNee | cNew) == 0)
+            break; /* re-dealing: a wave without work stays for the workgroup's barriers, and its idle lanes for the pool */
         int pick;
         const bool fused = args.fuse != 0;
         {
@@ -511,30 +642,15 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 }
                 afterBlock(next);
             }
-            if (!COUNT && args.pool && !poolDry) {
-                /* idle lanes take the next pixels of the launch: one atomic per wave */
-                const unsigned long long idle = __ballot(state == S_DONE);
-                if (idle != 0) {
-                    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-                    const uint32_t want = (uint32_t)__popcll(idle);
-                    const int leader = __ffsll((long long)idle) - 1;
-                    uint32_t first = 0;
-                    if ((int)lane == leader)
-                        first = atomicAdd(args.pool, want);
-                    first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
-                    poolDry = first + want >= laneLimit; /* the counter only grows: nothing behind it for this wave */
-                    if (state == S_DONE) {
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                        if (startPixel(first + rank))
-                            state = S_NEW;
-                    }
-                }
-            }
+            if (!REDEAL)
+                fromPool();
             if (COUNT) /* shader clock spent per kind of block: [11] traversal [12] shade [13] nee-end [14] new */
                 sched[14] += (unsigned long long)(clock64() - tBlock);
         }
         if (pick != S_NODE && state == S_START)
             beginRay();
+        if (REDEAL) /* whichever wave a finished path has come to rest in */
+            fromPool();
     }
 
     if (COUNT && args.counters && inBlock) {
@@ -596,6 +712,7 @@ void launchGroundTruth(const GroundTruthArgs& args, hipStream_t stream);
 constexpr uint32_t ORDER_BUCKETS = 128;
 void launchOrderBuild(const KernelArgs& args, uint32_t* order, uint32_t* work, hipStream_t stream);
 void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
+void launchBasicLdsRedeal(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream);
