@@ -165,4 +165,5 @@ def build_once(build, path, rank, barrier, broadcast=None):
             os.remove(path)
         except OSError:
             pass
+    barrier()          # the name is gone when any rank returns
     return scene
