@@ -187,9 +187,13 @@ template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, bool REDEAL = false>
 __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 {
     static_assert(!REDEAL || (LDSSCENE && !COUNT && !(F & (FEAT_ANIM | FEAT_SPHERES))), "re-dealing: the plain kernel with the scene in LDS");
-    /* node prefetch: for scenes in HBM (Sponza-class frame 3 % faster); not from LDS, where the eight registers cost more
-     * than the short fetch (Cornell 4 % slower) */
-    constexpr bool PREFETCH = !LDSSCENE;
+    /* node prefetch: for scenes in HBM (Sponza-class frame 3 % faster); not from LDS, where the fetch is short and the
+     * registers that hold the node ahead lengthen every step (Cornell 4 % slower in round 2; again with round 3's kernel,
+     * 117 registers either way: 966 against 1017 Msamples/s, -DWPT_LDS_PREFETCH=1) */
+#ifndef WPT_LDS_PREFETCH
+#define WPT_LDS_PREFETCH 0 /* experiments: 1 = the kernel with the scene in LDS requests its next node ahead as well */
+#endif
+    constexpr bool PREFETCH = !LDSSCENE || WPT_LDS_PREFETCH;
     /* leaf records (wpt_capi.hip): the walk reads a triangle's corners behind its leaf node; not where the corners are
      * moved by an animation first (those kernels need the instance and flag words of the triangle array anyway) */
     constexpr bool LEAFREC = !LDSSCENE && !(F & FEAT_ANIM);
