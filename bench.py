@@ -185,8 +185,10 @@ def roofline_of(name, scene, cnt, spp, count_sqrt, avg_ms, avg_samples, n_launch
     width, height = scene.width, scene.height
     bps, _ = bytes_per_sample(cnt, scene, spp)
     achieved = bps * avg_samples / (avg_ms * 1e-3) / 1e9 if n_launches else 0.0
+    # with_pmc "per_sample": a rank's share of the frame (N > 1) -- what the committed pass says per SAMPLE still describes
+    # it (instructions, active lanes), what it says per launch of the whole frame (HBM bytes) does not
     pmc = load_pmc(name) if with_pmc else {}
-    traffic = pmc.get("hbm_bytes_per_launch")
+    traffic = pmc.get("hbm_bytes_per_launch") if with_pmc is True else None
     in_lds = int(scene.d.node_count) * 32 + int(scene.d.tri_count) * 48 <= LDS_SCENE_MAX_BYTES
     per_sample = {k: cnt[k] / float(cnt["samples"]) for k in ("rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")}
     common = {"traffic": traffic, "basis": basis, "kernel": device.lib().wpt_kernel_name().decode(), "avg_launch_ms": avg_ms,
@@ -509,7 +511,10 @@ def main():
             avg_ms = elapsed * 1e3
             avg_samples = sum(s for _, s in launches)
             basis = "algorithmic bytes of rank 0's %d overlapping launches / the timed region" % len(launches)
-        roofline = roofline_of(name, scene, cnt, spp, ssqrt, avg_ms, avg_samples, len(launches), basis, lib_id, device, with_pmc=(world == 1))
+        roofline = roofline_of(name, scene, cnt, spp, ssqrt, avg_ms, avg_samples, len(launches), basis, lib_id, device,
+                               with_pmc=(True if world == 1 else "per_sample"))
+        if world > 1:
+            roofline["note"] = roofline.get("note", "") + "; rank 0's launch over its share of the frame, per-sample counters from the one-GPU PMC pass of the whole frame"
         out = {
             "metric": "Msamples/s", "value": total_samples / elapsed / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
