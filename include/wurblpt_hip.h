@@ -444,6 +444,13 @@ wpt_status wpt_set_top_nodes(uint32_t nodes);
  * Process-global like wpt_set_launch_config and wpt_set_top_nodes: a hook for tests and measurements, set it before
  * rendering starts, not while other threads render. */
 wpt_status wpt_set_wavefront(uint32_t mode, uint32_t groups, uint32_t chunk, uint32_t flags);
+/* Environment variables the library reads -- all of them measurement hooks behind kept negatives of DESIGN.md sections 4
+ * and 7; none changes a result, none is needed to use the library:
+ *   WPT_REDEAL=n            scenes in LDS: the kernel whose workgroups deal their paths to their lanes anew at every n-th look
+ *                           at the lane counts (WPT_REDEAL_IDENTITY: every path stays in its lane, the price of a deal alone)
+ *   WPT_EXTRA_LDS=bytes     scenes in LDS: idle LDS per workgroup (what fewer workgroups per compute unit cost)
+ *   WPT_WF_TRACE_PER_CU=n   wavefront form: workgroups of the trace kernel per compute unit
+ *   WPT_WF_SHADE_PER_KIND   wavefront form: one shade launch per kind of material, so that a kernel trace tells them apart */
 
 /* Profiling hook: `stats_device` (device pointer to 24 uint64, or NULL to switch off) receives
  * the wave scheduler's statistics of launches that also count work (counters_device != NULL):
