@@ -181,7 +181,7 @@ def load_pmc(name):
         return {}
 
 
-def roofline_of(name, scene, cnt, spp, count_sqrt, avg_ms, avg_samples, n_launches, basis, lib_id, device, with_pmc=True):
+def roofline_of(name, scene, cnt, spp, count_sqrt, avg_ms, avg_samples, n_launches, basis, lib_id, device, with_pmc=True, walked=None):
     width, height = scene.width, scene.height
     bps, _ = bytes_per_sample(cnt, scene, spp)
     achieved = bps * avg_samples / (avg_ms * 1e-3) / 1e9 if n_launches else 0.0
@@ -221,6 +221,14 @@ def roofline_of(name, scene, cnt, spp, count_sqrt, avg_ms, avg_samples, n_launch
         for k in ("wait_any_share", "l2_hit_rate", "valu_active_lane_fraction", "valu_busy_percent"):
             if pmc.get(k) is not None:
                 roofline[k] = pmc[k]
+    if walked is not None and n_launches:
+        wbps, _ = bytes_per_sample(walked, scene, spp)
+        roofline["walked"] = {
+            "per_sample": {k: walked[k] / float(walked["samples"]) for k in ("rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")},
+            "bytes_per_sample": wbps, "gbps": wbps * avg_samples / (avg_ms * 1e-3) / 1e9,
+            "frac": min(1.0, wbps * avg_samples / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS),
+            "note": "what the product kernel walks: walks of light rays towards the environment end at their first accepted hit "
+                    "(same answer, same frame); bytes_per_sample / achieved / frac above price the reference's full walks, as SURVEY 8(d) defines them"}
     return roofline
 
 
@@ -237,7 +245,22 @@ def measure_one_gpu(name, w, scene, dscene, steps, warmup, cpu_seconds, lib_id, 
     counters = torch.zeros(6, dtype=torch.int64, device="cuda")
     dscene.render_block_into(frame, ssqrt, None, params, counters, stream)
     torch.cuda.synchronize()
-    cnt = dict(zip(("samples", "rays", "node_visits", "leaf_tests", "pdf_tests", "scatters"), [int(x) for x in counters.cpu().tolist()]))
+    names = ("samples", "rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")
+    cnt = dict(zip(names, [int(x) for x in counters.cpu().tolist()]))
+    walked = None
+    if int(scene.d.envmap.type) != 0:
+        # What the product kernel walks: the walk of a light ray towards the environment ends at its first accepted hit (the
+        # answer it is traced for is known there), the reference's goes on.  The counted pass above counts the reference's walk
+        # (its numbers are the oracle's, and the algorithmic bytes are the reference's by definition); this one counts the
+        # product's, so that the line says both.
+        os.environ["WPT_COUNT_PRODUCT_WALKS"] = "1"
+        try:
+            counters.zero_()
+            dscene.render_block_into(frame, ssqrt, None, params, counters, stream)
+            torch.cuda.synchronize()
+            walked = dict(zip(names, [int(x) for x in counters.cpu().tolist()]))
+        finally:
+            os.environ.pop("WPT_COUNT_PRODUCT_WALKS", None)
     frame.zero_()
     events = []
 
@@ -264,7 +287,7 @@ def measure_one_gpu(name, w, scene, dscene, steps, warmup, cpu_seconds, lib_id, 
              "kernel_launches_per_launch launches of the kernel(s), whose durations add up to it")
     out = {
         "value": float(pixels) * spp * steps / elapsed / 1e6, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
-        "roofline": roofline_of(name, scene, cnt, spp, ssqrt, avg_ms, float(pixels) * spp, len(ms), basis, lib_id, device),
+        "roofline": roofline_of(name, scene, cnt, spp, ssqrt, avg_ms, float(pixels) * spp, len(ms), basis, lib_id, device, walked=walked),
         "frame_finite": bool(torch.isfinite(frame).all().item()),
     }
     if cpu_seconds > 0:

@@ -444,10 +444,14 @@ wpt_status wpt_set_top_nodes(uint32_t nodes);
  * Process-global like wpt_set_launch_config and wpt_set_top_nodes: a hook for tests and measurements, set it before
  * rendering starts, not while other threads render. */
 wpt_status wpt_set_wavefront(uint32_t mode, uint32_t groups, uint32_t chunk, uint32_t flags);
-/* Environment variables the library reads -- all of them measurement hooks behind kept negatives of DESIGN.md sections 4
- * and 7; none changes a result, none is needed to use the library:
+/* Environment variables the library reads -- all of them measurement hooks (DESIGN.md sections 4
+ * and 7); none changes a result, none is needed to use the library:
  *   WPT_REDEAL=n            scenes in LDS: the kernel whose workgroups deal their paths to their lanes anew at every n-th look
  *                           at the lane counts (WPT_REDEAL_IDENTITY: every path stays in its lane, the price of a deal alone)
+ *   WPT_FULL_SHADOW_WALKS   light rays towards the environment walk the tree to the end like the reference's (product launches
+ *                           end such a walk at its first accepted hit: the answer the ray is traced for is known there)
+ *   WPT_COUNT_PRODUCT_WALKS counting launches, which otherwise walk like the reference so that their counters are its
+ *                           counters, count the product's shortened walks instead
  *   WPT_EXTRA_LDS=bytes     scenes in LDS: idle LDS per workgroup (what fewer workgroups per compute unit cost)
  *   WPT_WF_TRACE_PER_CU=n   wavefront form: workgroups of the trace kernel per compute unit
  *   WPT_WF_SHADE_PER_KIND   wavefront form: one shade launch per kind of material, so that a kernel trace tells them apart */

@@ -1111,6 +1111,38 @@ def test_leaf_records_never_change_results(dev, oracle):
         _wavefront(dev, 0)
 
 
+def test_environment_light_rays_end_their_walk_at_the_first_hit(dev, oracle):
+    """A light ray towards the environment is traced for one answer -- is anything in the way (wurblpt.hpp:240-250) -- and up to a
+    walk's first accepted hit every decision is the reference's, so the product kernels end the walk there.  The frame is the
+    oracle's either way; counting launches walk on like the reference (their counters are the oracle's) unless
+    WPT_COUNT_PRODUCT_WALKS asks them for the product's walk: fewer node visits and leaf tests, everything else the same."""
+    import os
+    sc = host.sponza_like(64, 48, seed=5, detail=0.05, tex_size=16, env_width=32, importance_n=8)
+    tables = oracle.envmap_tables(sc)
+    ds = dev.DeviceScene(sc)
+    sc.set_envmap_tables(*tables)
+    ref, rc = oracle.render(sc, 3)
+    got, _ = ds.render(3)
+    counted, gc = ds.render(3, with_counters=True)
+    assert bits_equal(got, ref) and bits_equal(counted, ref) and gc == rc
+    try:
+        os.environ["WPT_COUNT_PRODUCT_WALKS"] = "1"
+        product, pc = ds.render(3, with_counters=True)
+        assert bits_equal(product, ref)
+        assert all(pc[k] == rc[k] for k in ("samples", "rays", "pdf_tests", "scatters")), (pc, rc)
+        assert pc["node_visits"] < rc["node_visits"] and pc["leaf_tests"] < rc["leaf_tests"], (pc, rc)
+        os.environ.pop("WPT_COUNT_PRODUCT_WALKS")
+        os.environ["WPT_FULL_SHADOW_WALKS"] = "1"
+        full, _ = ds.render(3)
+        _wavefront(dev, 1, 2, 32, 9 << 16)
+        wf, _ = ds.render(3)
+        assert bits_equal(full, ref) and bits_equal(wf, ref)
+    finally:
+        os.environ.pop("WPT_COUNT_PRODUCT_WALKS", None)
+        os.environ.pop("WPT_FULL_SHADOW_WALKS", None)
+        _wavefront(dev, 0)
+
+
 @pytest.mark.parametrize("every", [1, 3])
 def test_redealing_kernel_bit_exact(dev, oracle, every):
     """WPT_REDEAL=n (a measurement hook): the kernel with the scene in LDS whose workgroups deal their 256

@@ -787,6 +787,11 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     dim3 grid((block_size + WG - 1) / WG);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const bool count = counters_device != nullptr;
+    /* The walk of a light ray towards the environment ends at its first accepted hit (wpt_pathtrace.inc.h: the answer it is
+     * traced for is known there).  Counting launches walk on as the reference does, so that their counters are the
+     * reference's; measurements: WPT_COUNT_PRODUCT_WALKS makes them count what the product kernel walks,
+     * WPT_FULL_SHADOW_WALKS switches the short cut off everywhere. */
+    args.shadowWalksEnd = getenv("WPT_FULL_SHADOW_WALKS") ? 0u : (count ? (getenv("WPT_COUNT_PRODUCT_WALKS") ? 1u : 0u) : 1u);
     const size_t ldsBytes = size_t(scene->nodeCount) * 32 + size_t(scene->triCount) * 48;
     /* scheduler defaults from sweeps on the Cornell box (scene in LDS, short walks) and on the
      * Sponza-class scene (deep tree in HBM: traversal dominates, so long blocks may run with fewer

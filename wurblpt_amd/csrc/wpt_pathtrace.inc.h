@@ -81,6 +81,7 @@ struct KernelArgs {
     uint32_t leafBias;     /* scheduler: leaf tests run when waiting lanes * leafBias >= walking lanes * 8 */
     uint32_t waitBelow;    /* scheduler: a kind of material with fewer lanes than this in a long round stands back once (0 = never) */
     uint32_t fuse;         /* scheduler: 1 = one long round serves SHADE, NEE-END and NEW lanes together */
+    uint32_t shadowWalksEnd; /* 1: the walk of a light ray towards the environment ends at its first accepted hit (not in counting launches) */
     uint32_t redealEvery;  /* re-dealing kernel: the workgroup deals its paths anew at every n-th look at the lane counts */
     float* frame;
     /* Pixel pool (or NULL): lanes whose pixel is finished take the next lane index of the launch from this counter, which
@@ -556,6 +557,12 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                             amax = c.a;
                         }
                         state = node >= nodeCount ? endOfRayState() : (int)S_NODE;
+                        /* A light ray towards the environment asks one thing: is anything in the way (blockNeeEnd,
+                         * wurblpt.hpp:240-250).  Up to a walk's first accepted hit the bound is the ray's own, so every box
+                         * and leaf decision is the reference's, and the answer is known there: the walk ends.  (Counting
+                         * launches are given shadowWalksEnd = 0 and walk on, as the reference does: their numbers are its numbers.) */
+                        if ((F & FEAT_ENVMAP) && args.shadowWalksEnd && accepted && ps.rayKind == RAY_NEE_ENV)
+                            state = S_NEEEND;
                         if (PREFETCH && state == S_NODE) {
                             pn0 = node4(2 * node);
                             pn1 = node4(2 * node + 1);

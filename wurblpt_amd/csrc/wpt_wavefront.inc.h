@@ -200,6 +200,7 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
     aux.k = 0;
     aux.Sx = aux.Sy = 0.0f;
     uint32_t node = 0, leafPrim = 0, gid = 0, stepsLeft = 0;
+    bool shadowRay = false;
     float amax = k_maxval;
     Candidate best;
     best.prim = NO_HIT;
@@ -255,6 +256,8 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                     }
                     stepsLeft = a.stepBudget ? a.stepBudget : 0xffffffffu;
                     state = T_NODE;
+                    /* a light ray towards the environment: its walk ends at the first accepted hit (wpt_pathtrace.inc.h) */
+                    shadowRay = a.k.shadowWalksEnd != 0 && (__float_as_uint(rd.w) & ~WF_RESUME) == (uint32_t)RAY_NEE_ENV;
                 }
                 fetchNode(node, dealt, pn0, pn1);
                 chunkNext += take;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                     best = c;
                     amax = c.a;
                 }
-                state = node >= nodeCount ? (int)T_DONE : (int)T_NODE;
+                state = (node >= nodeCount || (accepted && shadowRay)) ? (int)T_DONE : (int)T_NODE;
                 if (state == T_NODE && stepsLeft == 0)
                     state = T_SUSPEND; /* between two nodes: nothing pending but (node, bound, candidate) */
             }
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                         best = c;
                         amax = c.a;
                     }
-                    state = node >= nodeCount ? (int)T_DONE : (int)T_NODE;
+                    state = (node >= nodeCount || (accepted && shadowRay)) ? (int)T_DONE : (int)T_NODE;
                     if (state == T_NODE && stepsLeft == 0)
                         state = T_SUSPEND; /* between two nodes: nothing pending but (node, bound, candidate) */
                     wantNode = state == T_NODE;
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                     best = c;
                     amax = c.a;
                 }
-                state = node >= nodeCount ? (int)T_DONE : (int)T_NODE;
+                state = (node >= nodeCount || (accepted && shadowRay)) ? (int)T_DONE : (int)T_NODE;
             }
             if (state == T_NODE)
                 state = T_SUSPEND;
