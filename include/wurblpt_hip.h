@@ -452,6 +452,7 @@ wpt_status wpt_set_wavefront(uint32_t mode, uint32_t groups, uint32_t chunk, uin
  *                           end such a walk at its first accepted hit: the answer the ray is traced for is known there)
  *   WPT_COUNT_PRODUCT_WALKS counting launches, which otherwise walk like the reference so that their counters are its
  *                           counters, count the product's shortened walks instead
+ *   WPT_XCD_BANDS=1         the workgroups that share an XCD render one contiguous eighth of a launch's pixels between them
  *   WPT_EXTRA_LDS=bytes     scenes in LDS: idle LDS per workgroup (what fewer workgroups per compute unit cost)
  *   WPT_WF_TRACE_PER_CU=n   wavefront form: workgroups of the trace kernel per compute unit
  *   WPT_WF_SHADE_PER_KIND   wavefront form: one shade launch per kind of material, so that a kernel trace tells them apart */

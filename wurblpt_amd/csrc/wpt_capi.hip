@@ -791,6 +791,7 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
      * traced for is known there).  Counting launches walk on as the reference does, so that their counters are the
      * reference's; measurements: WPT_COUNT_PRODUCT_WALKS makes them count what the product kernel walks,
      * WPT_FULL_SHADOW_WALKS switches the short cut off everywhere. */
+    args.xcdBands = getenv("WPT_XCD_BANDS") ? uint32_t(atoi(getenv("WPT_XCD_BANDS"))) : 0u;
     args.shadowWalksEnd = getenv("WPT_FULL_SHADOW_WALKS") ? 0u : (count ? (getenv("WPT_COUNT_PRODUCT_WALKS") ? 1u : 0u) : 1u);
     const size_t ldsBytes = size_t(scene->nodeCount) * 32 + size_t(scene->triCount) * 48;
     /* scheduler defaults from sweeps on the Cornell box (scene in LDS, short walks) and on the

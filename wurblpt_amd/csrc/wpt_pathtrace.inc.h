@@ -82,6 +82,7 @@ struct KernelArgs {
     uint32_t waitBelow;    /* scheduler: a kind of material with fewer lanes than this in a long round stands back once (0 = never) */
     uint32_t fuse;         /* scheduler: 1 = one long round serves SHADE, NEE-END and NEW lanes together */
     uint32_t shadowWalksEnd; /* 1: the walk of a light ray towards the environment ends at its first accepted hit (not in counting launches) */
+    uint32_t xcdBands;     /* measurements: 1 = the workgroups of an XCD share a contiguous eighth of the launch's pixels */
     uint32_t redealEvery;  /* re-dealing kernel: the workgroup deals its paths anew at every n-th look at the lane counts */
     float* frame;
     /* Pixel pool (or NULL): lanes whose pixel is finished take the next lane index of the launch from this counter, which
@@ -292,7 +293,11 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             args.cost[pixel] = (uint32_t)clock64();
         return have;
     };
-    const bool inBlock = startPixel(blockIdx.x * WG + threadIdx.x);
+    /* Workgroups b, b + 8, b + 16, ... share an XCD and its L2 (round-robin placement; observed, not promised).  With
+     * xcdBands they render one contiguous eighth of the launch's pixels between them, so that an L2 holds the nodes behind one
+     * part of the picture instead of a share of everything (measurements; the launch must be a multiple of eight workgroups). */
+    const uint32_t logicalBlock = (args.xcdBands && (gridDim.x & 7u) == 0) ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const bool inBlock = startPixel(logicalBlock * WG + threadIdx.x);
     LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
     /* wave-level scheduler statistics (COUNT builds): rounds and lane counts per state */
     unsigned long long sched[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
