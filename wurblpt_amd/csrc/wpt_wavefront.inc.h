@@ -201,6 +201,9 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
     aux.Sx = aux.Sy = 0.0f;
     uint32_t node = 0, leafPrim = 0, gid = 0, stepsLeft = 0;
     bool shadowRay = false;
+#ifdef WPT_EVAL_BEHIND_RAY
+    bool pendingEnd = false;
+#endif
     float amax = k_maxval;
     Candidate best;
     best.prim = NO_HIT;
@@ -257,7 +260,11 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                     stepsLeft = a.stepBudget ? a.stepBudget : 0xffffffffu;
                     state = T_NODE;
                     /* a light ray towards the environment: its walk ends at the first accepted hit (wpt_pathtrace.inc.h) */
-                    shadowRay = a.k.shadowWalksEnd != 0 && (__float_as_uint(rd.w) & ~WF_RESUME) == (uint32_t)RAY_NEE_ENV;
+                    shadowRay = a.k.shadowWalksEnd != 0 && ((__float_as_uint(rd.w) & ~WF_RESUME) == (uint32_t)RAY_NEE_ENV
+#ifdef WPT_EVAL_BEHIND_RAY
+                            || (__float_as_uint(rd.w) & ~WF_RESUME) == (uint32_t)RAY_NEE_ENV_PENDING
+#endif
+                            );
                 }
                 fetchNode(node, dealt, pn0, pn1);
                 chunkNext += take;
@@ -454,9 +461,32 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                         *kindWord = kw & ~WF_RESUME; /* through: the record holds a result again */
                     if (a.buckets)
                         kind = shadeKind<SPHERES>(sv, kw & ~WF_RESUME, best.prim, best.invDet);
+#ifdef WPT_EVAL_BEHIND_RAY
+                    /* a light ray with its material's evaluation pending that nothing was in the way of: a queue of its own,
+                     * filled from the far end of the measured BRDFs' (a pixel is in one queue per iteration, so the two never
+                     * meet); shadowed ones end like any other light ray */
+                    if (a.buckets && (kw & ~WF_RESUME) == (uint32_t)RAY_NEE_ENV_PENDING && best.prim == NO_HIT) {
+                        kind = WF_BUCKETS;
+                        pendingEnd = true;
+                    }
+#endif
                 }
                 state = T_IDLE;
             }
+#ifdef WPT_EVAL_BEHIND_RAY
+            {
+                const unsigned long long pend = __ballot(pendingEnd);
+                if (pend != 0) {
+                    uint32_t base = 0;
+                    if (lane == 0)
+                        base = atomicAdd(&cur->pad[0], (uint32_t)__popcll(pend));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (pendingEnd)
+                        a.bucketQueue[(size_t)WF_B_RGL * a.laneCount + (a.laneCount - 1u - (base + rankIn(pend)))] = gid;
+                    pendingEnd = false;
+                }
+            }
+#endif
             const unsigned long long suspended = __ballot(suspend);
             if (suspended != 0) {
                 uint32_t base = 0;
@@ -517,6 +547,18 @@ WPT_D bool shadeSlice(const WfIter* cur, uint32_t kindMask, uint32_t group, uint
         }
         at += groups;
     }
+#ifdef WPT_EVAL_BEHIND_RAY
+    if ((kindMask >> WF_B_RGL) & 1u) { /* ends of light rays with an evaluation pending: kind WF_BUCKETS, the far end of the measured BRDFs' queue */
+        const uint32_t n = cur->pad[0];
+        const uint32_t groups = (n + WG - 1) / WG;
+        if (group < at + groups) {
+            kind = WF_BUCKETS;
+            first = (group - at) * WG;
+            count = n;
+            return true;
+        }
+    }
+#endif
     return false;
 }
 
@@ -548,7 +590,11 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
         count = a.laneCount;
     } else if (a.buckets) {
         if (shadeSlice(cur, a.kindMask, blockIdx.x, kind, first, count))
+#ifdef WPT_EVAL_BEHIND_RAY
+            queueIn = a.bucketQueue + (size_t)(kind < WF_BUCKETS ? kind : (uint32_t)WF_B_RGL) * a.laneCount;
+#else
             queueIn = a.bucketQueue + (size_t)kind * a.laneCount;
+#endif
         else
             return; /* uniform for the workgroup */
     } else {
@@ -595,7 +641,11 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
         ps.rayKind = RAY_PATH;
         ps.o = ps.d = mk3(0.0f, 0.0f, 1.0f);
         if (have) {
+#ifdef WPT_EVAL_BEHIND_RAY
+            gid = queueIn[kind == WF_BUCKETS && a.buckets ? a.laneCount - 1u - entry : entry];
+#else
             gid = queueIn[entry];
+#endif
             rec = a.state + (size_t)gid * WF_SLOTS;
 #pragma unroll
             for (int k = 0; k < SLOT_COUNT; k++)
@@ -618,10 +668,36 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
     if (have) {
         LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
         if (!INIT) {
+#ifdef WPT_EVAL_BEHIND_RAY
+            if (ps.rayKind == RAY_PATH) {
+                next = blockShade<F, false>(sv, par, tri4, ps, best, lc, 0, true);
+                if (next == NEXT_TRACE && ps.rayKind == RAY_NEE_ENV_PENDING) {
+                    /* what the evaluation behind the light ray will need of the path ray: candidate, direction, origin -- the
+                     * record still holds them (the new ray is written below), they move to its three free quadwords */
+                    const float4 ro = rec[WF_RAY_O], rd = rec[WF_RAY_D], h0 = rec[WF_HIT0], h1 = rec[WF_HIT1];
+                    rec[13] = h0;
+                    rec[14] = make_float4(h1.x, h1.y, rd.x, rd.y);
+                    rec[15] = make_float4(rd.z, ro.x, ro.y, ro.z);
+                }
+            } else if (ps.rayKind == RAY_NEE_ENV_PENDING && best.prim == NO_HIT) {
+                const float4 q0 = rec[13], q1 = rec[14], q2 = rec[15];
+                Candidate pathBest;
+                pathBest.prim = __float_as_uint(q0.x);
+                pathBest.a = q0.y;
+                pathBest.invDet = q0.z;
+                pathBest.U = q0.w;
+                pathBest.V = q1.x;
+                pathBest.W = q1.y;
+                next = blockNeeEndPending<F>(sv, par, tri4, ps, pathBest, mk3(q2.y, q2.z, q2.w), mk3(q1.z, q1.w, q2.x));
+            } else {
+                next = blockNeeEnd<F>(sv, par, tri4, ps, best); /* (a shadowed pending ray ends like any light ray towards the environment: nothing to add) */
+            }
+#else
             if (ps.rayKind == RAY_PATH)
                 next = blockShade<F, false>(sv, par, tri4, ps, best, lc, 0); /* tracePath, one path component (wurblpt.hpp:131-252) */
             else
                 next = blockNeeEnd<F>(sv, par, tri4, ps, best);            /* the next-event ray's contribution, then the path continues */
+#endif
         }
         if (next == NEXT_NEW) { /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
             next = blockNew<F>(fa, ps, sv);

@@ -174,7 +174,11 @@ hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, c
                     return e;
             }
             const uint32_t traceGroups = std::max(1u, std::min(traceResident, (gr.known + chunk * (WG / 64) - 1) / (chunk * (WG / 64))));
+#ifdef WPT_EVAL_BEHIND_RAY
+            const uint32_t shadeGroups = (gr.known + WG - 1) / WG + (gr.args.buckets ? WF_BUCKETS + 1u : 0u); /* a ninth queue's rounding */
+#else
             const uint32_t shadeGroups = (gr.known + WG - 1) / WG + (gr.args.buckets ? WF_BUCKETS : 0u);
+#endif
             for (uint32_t i = 0; i < BATCH; i++) {
                 gr.args.iteration = gr.iteration + i;
                 kernels.trace(gr.args, dim3(traceGroups), s);
