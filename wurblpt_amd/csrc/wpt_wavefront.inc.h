@@ -27,6 +27,11 @@
  *   8      ray origin, time          9   ray direction, kind of ray
  *   10     candidate: primitive, distance, 1 / det, U        11   V, W
  *   12     a suspended walk: next node, bound
+ *   13..15 free (the variant build -DWPT_EVAL_BEHIND_RAY keeps a path ray's candidate, direction and origin there while the
+ *          light ray whose end will evaluate a measured BRDF is traced: DESIGN.md section 7)
+ *
+ * The walk of a light ray towards the environment ends at its first accepted hit, as in the single kernel (the answer it is
+ * traced for -- anything in the way? -- is known there).
  *
  * A launch of the trace walks a ray for at most WfArgs::stepBudget node steps.  The walk has no stack: what it needs to
  * go on is the next node, the bound and the candidate, eight words.  A ray that is not through by then is written
