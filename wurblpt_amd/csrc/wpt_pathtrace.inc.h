@@ -243,12 +243,30 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         }
     }
     __syncthreads();
+#ifdef WPT_TOP_IN_LDS_HERE /* defined by the one translation unit whose launcher adds the LDS (wpt_k_full.hip) */
+    /* Variant build: the first WPT_TOP_IN_LDS nodes of the array -- the tree's upper levels, stored level
+     * by level in front (wpt_set_top_nodes) -- are walked from LDS by the kernels that fetch the scene from HBM, so that the
+     * vector L1 serves the levels below them.  The launchers add WPT_TOP_IN_LDS * 32 bytes of LDS. */
+    const uint32_t topQuads = LDSSCENE ? 0u : 2u * (nodeCount < (uint32_t)WPT_TOP_IN_LDS_HERE ? nodeCount : (uint32_t)WPT_TOP_IN_LDS_HERE);
+    if (!LDSSCENE) {
+        for (uint32_t i = threadIdx.x; i < topQuads; i += WG)
+            ldsScene[i] = sv.nodes[i];
+        __syncthreads();
+    }
+    auto node4 = [&](uint32_t i) -> float4 {
+        if constexpr (LDSSCENE)
+            return ldsScene[i];
+        else
+            return i < topQuads ? ldsScene[i] : sv.nodes[i];
+    };
+#else
     auto node4 = [&](uint32_t i) -> float4 {
         if constexpr (LDSSCENE)
             return ldsScene[i];
         else
             return sv.nodes[i];
     };
+#endif
     auto tri4 = [&](uint32_t i) -> float4 {
         if constexpr (LDSSCENE)
             return ldsScene[2 * nodeCount + i];
