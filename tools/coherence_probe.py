@@ -1,4 +1,4 @@
-"""usage (GPU box): python tools/coherence_probe.py [samples_sqrt]
+"""usage (GPU box): python tools/coherence_probe.py [samples_sqrt [cornell]]
 How fast do walks run when the rays of a wave belong together?  The Sponza-class frame with paths cut after 2, 3, 4, ... components
 (Parameters::maxPathComponents): with 2 there are camera rays and the light rays from their hits only -- neighbouring pixels,
 neighbouring origins --, every further component adds rays that have been scattered once more.  Node visits per second
@@ -12,7 +12,8 @@ import torch
 from wurblpt_amd import device, host
 
 ssqrt = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-sc = host.sponza_like(1920, 1080, seed=1)
+# "cornell": the same question where no memory is in the way (scene in LDS): what is lost to lanes that part ways
+sc = host.cornell(1024, 1024, 1, 2) if len(sys.argv) > 2 and sys.argv[2] == "cornell" else host.sponza_like(1920, 1080, seed=1)
 ds = device.DeviceScene(sc)
 frame = torch.zeros((sc.height, sc.width, 3), dtype=torch.float32, device="cuda")
 stream = torch.cuda.current_stream()
