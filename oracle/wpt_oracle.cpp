@@ -22,6 +22,8 @@
  * std:: functions as the reference uses (gvm.hpp:118-146).
  */
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stddef.h>
 #include <string.h>
 #include <math.h>
@@ -2320,6 +2322,190 @@ void wpt_oracle_envmap_probe(const wpt_scene_desc* scene, int n, const float* in
         const V4 Ld = envL(c, d);
         o[9] = Ld.x + Ld.y + Ld.z + Ld.w;
     }
+}
+
+} /* extern "C" (the walk below has templates) */
+
+/* ---- A walk that is NOT the reference's, held against it: DESIGN.md section 7.1 proposes a step that tests the boxes of a
+ * node's four grandchildren together (the binary tree collapsed by one level) and claims every result stays the same.  This
+ * is that walk on the CPU, leaf test for leaf test next to bvhTraverse: test infrastructure for a design decision, not the
+ * oracle's path (wpt_oracle_render never comes here).
+ *
+ * A step at inner node X tests the boxes of X's grandchildren WITHOUT the bound (a child that is a leaf
+ * stands for itself), in the order the reference's walk would come to them, and keeps those that pass with their entry
+ * distance M = max(amin, near slabs).  The reference tests a later one under whatever bound the earlier subtrees have left;
+ * since the far side of the test had already held, that test is `M <= bound`, which is what a kept child is admitted by when
+ * its turn comes.  The inner nodes that disappear decide nothing of their own: a child's box lies within its parent's, the
+ * slab arithmetic is monotone, so a child that passes implies the parent the reference tested before it.  Both arguments
+ * need slab distances that are numbers: with a NaN among them (0 * inf: origin on a slab plane, direction parallel to it)
+ * the comparison chains of gvm.hpp depend on operand order, and the step falls back to the reference's own two tests. */
+struct WideWalkStats {
+    uint64_t rays, binaryVisits, wideSteps, wideBoxTests, leafTests, nanFallbacks, revalidationsFailed, maxPending;
+    uint64_t admissionDisagrees, parentDisagrees; /* self-checks of the two arguments, counted where they fail */
+};
+
+inline bool slabsOf(const float* lo, const float* hi, const Ray& ray, V3 invDir, float amin, float amax, float& entry, bool& pass)
+{
+    const V3 t0 = (v3(lo) - ray.origin) * invDir;
+    const V3 t1 = (v3(hi) - ray.origin) * invDir;
+    const bool number = t0.x == t0.x && t0.y == t0.y && t0.z == t0.z && t1.x == t1.x && t1.y == t1.y && t1.z == t1.z;
+    const V4 tmin = V4 { amin, fmin_(t0.x, t1.x), fmin_(t0.y, t1.y), fmin_(t0.z, t1.z) };
+    const V4 tmax = V4 { amax, fmax_(t0.x, t1.x), fmax_(t0.y, t1.y), fmax_(t0.z, t1.z) };
+    entry = max4(tmin);
+    pass = entry <= min4(tmax);
+    return number;
+}
+
+template<typename LeafHit>
+inline HitRecord bvhTraverseWide(const wpt_bvh_node* nodes, const Ray& ray, const RayHelper& rh, float amin, float amax,
+        LeafHit&& leafHit, std::vector<uint32_t>& leafOrder, WideWalkStats& st)
+{
+    struct Pending {
+        uint32_t node;
+        bool tested; /* kept by a wide step with entry distance `entry`; false: the reference's own test is still to be made */
+        float entry;
+    };
+    HitRecord hr;
+    std::vector<Pending> pending;
+    pending.push_back(Pending { 0u, false, 0.0f });
+    while (!pending.empty()) {
+        if (pending.size() > st.maxPending)
+            st.maxPending = pending.size();
+        const Pending e = pending.back();
+        pending.pop_back();
+        const wpt_bvh_node& node = nodes[e.node];
+        if (e.tested) {
+            /* self-check: the admission by entry distance is the reference's test under the bound of this moment */
+            if ((e.entry <= amax) != aabbMayHit(node.lo, node.hi, ray, amin, amax, rh.invDirection))
+                st.admissionDisagrees++;
+            if (!(e.entry <= amax)) {
+                st.revalidationsFailed++;
+                continue;
+            }
+        } else {
+            st.wideBoxTests++;
+            if (!aabbMayHit(node.lo, node.hi, ray, amin, amax, rh.invDirection))
+                continue;
+        }
+        if (node.kind != WPT_NODE_INNER) {
+            if (node.kind != WPT_NODE_EMPTY) {
+                st.leafTests++;
+                leafOrder.push_back(node.kind == WPT_NODE_SPHERE ? (0x80000000u | node.link) : node.link);
+                HitRecord cur = leafHit(node.kind, node.link, amin, amax);
+                if (cur.haveHit) {
+                    hr = cur;
+                    amax = hr.a;
+                }
+            }
+            continue;
+        }
+        /* one step: the grandchildren in the reference's order (first child = index + 1, second = link) */
+        st.wideSteps++;
+        const uint32_t child[2] = { e.node + 1u, node.link };
+        uint32_t grand[4];
+        int count = 0;
+        for (int k = 0; k < 2; k++) {
+            const wpt_bvh_node& ch = nodes[child[k]];
+            if (ch.kind == WPT_NODE_INNER) {
+                grand[count++] = child[k] + 1u;
+                grand[count++] = ch.link;
+            } else {
+                grand[count++] = child[k];
+            }
+        }
+        float entry[4];
+        bool pass[4];
+        bool numbers = true;
+        for (int k = 0; k < count; k++) {
+            st.wideBoxTests++;
+            /* Without the bound: a hit is accepted by one comparison and its distance stored by another (hitable_triangle.hpp:
+             * 283-296), so the bound can GROW by an ulp at a hit, and a box that is beyond it now may be within it when its
+             * turn comes (found by this check: one ray in 200 000 on the Sponza-class scene).  The bound is applied at the
+             * child's turn only, where it is the reference's. */
+            numbers = slabsOf(nodes[grand[k]].lo, nodes[grand[k]].hi, ray, rh.invDirection, amin, k_maxval, entry[k], pass[k]) && numbers;
+        }
+        /* the children that disappear must be numbers too for the implication child => parent to hold */
+        for (int k = 0; k < 2 && numbers; k++) {
+            float en;
+            bool pa;
+            numbers = slabsOf(nodes[child[k]].lo, nodes[child[k]].hi, ray, rh.invDirection, amin, amax, en, pa);
+        }
+        if (!numbers) {
+            st.nanFallbacks++;
+            pending.push_back(Pending { child[1], false, 0.0f });
+            pending.push_back(Pending { child[0], false, 0.0f });
+            continue;
+        }
+        /* self-check: a grandchild that passes implies its parent (the child the reference tests first) */
+        {
+            int k = 0;
+            for (int c2 = 0; c2 < 2; c2++) {
+                const wpt_bvh_node& ch = nodes[child[c2]];
+                const int members = ch.kind == WPT_NODE_INNER ? 2 : 1;
+                const bool parentPasses = aabbMayHit(ch.lo, ch.hi, ray, amin, k_maxval, rh.invDirection);
+                for (int m = 0; m < members; m++, k++)
+                    if (pass[k] && !parentPasses)
+                        st.parentDisagrees++;
+            }
+        }
+        for (int k = count - 1; k >= 0; k--)
+            if (pass[k])
+                pending.push_back(Pending { grand[k], true, entry[k] });
+    }
+    return hr;
+}
+
+extern "C" {
+
+/* n rays (origin, dir, amin, amax = 8 floats) through both walks: returns the number of rays whose sequence of leaf tests or
+ * whose result (hit, primitive, distance bits) differs; stats: 8 x uint64 (WideWalkStats). */
+int wpt_oracle_wide_walk_check(const wpt_scene_desc* scene, int n, const float* rays, uint64_t* stats)
+{
+    wpt_params pr;
+    memset(&pr, 0, sizeof(pr));
+    WideWalkStats st;
+    memset(&st, 0, sizeof(st));
+    int differ = 0;
+    Ctx c;
+    c.sc = scene;
+    c.pr = &pr;
+    memset(&c.cnt, 0, sizeof(c.cnt));
+    std::vector<uint32_t> orderBinary, orderWide;
+    for (int i = 0; i < n; i++) {
+        Ray r { v3(rays + 8 * i), v3(rays + 8 * i + 3), 0.0f, v4(1.0f) };
+        const RayHelper rh(r);
+        auto leaf = [&](std::vector<uint32_t>* order) {
+            return [&c, &r, &rh, order](uint32_t kind, uint32_t index, float lo, float hi) {
+                if (order)
+                    order->push_back(kind == WPT_NODE_SPHERE ? (0x80000000u | index) : index);
+                if (kind == WPT_NODE_SPHERE)
+                    return sphereHit(c, c.sc->spheres[index], index, r, lo, hi);
+                return triangleHit(c, index, r, rh, lo, hi, true, nullptr, nullptr);
+            };
+        };
+        orderBinary.clear();
+        orderWide.clear();
+        const uint64_t visitsBefore = c.cnt.node_visits;
+        const HitRecord a = bvhTraverse(c.sc->nodes, c.cnt, r, rh, rays[8 * i + 6], rays[8 * i + 7], leaf(&orderBinary));
+        st.binaryVisits += c.cnt.node_visits - visitsBefore;
+        const HitRecord b = bvhTraverseWide(c.sc->nodes, r, rh, rays[8 * i + 6], rays[8 * i + 7], leaf(nullptr), orderWide, st);
+        st.rays++;
+        uint32_t abits, bbits;
+        memcpy(&abits, &a.a, 4);
+        memcpy(&bbits, &b.a, 4);
+        if (orderBinary != orderWide || a.haveHit != b.haveHit || (a.haveHit && (a.prim != b.prim || abits != bbits))) {
+            differ++;
+            if (getenv("WPT_ORACLE_WIDE_DEBUG")) {
+                fprintf(stderr, "ray %d: binary hit %d prim %u a %.9g | wide hit %d prim %u a %.9g\n binary leaves:", i, a.haveHit, a.prim, a.a, b.haveHit, b.prim, b.a);
+                for (uint32_t x : orderBinary) fprintf(stderr, " %u", x);
+                fprintf(stderr, "\n wide leaves:  ");
+                for (uint32_t x : orderWide) fprintf(stderr, " %u", x);
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+    memcpy(stats, &st, sizeof(st));
+    return differ;
 }
 
 /* BVH::hit against the scene for n rays (origin, dir, amin, amax = 8 floats).

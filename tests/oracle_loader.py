@@ -131,6 +131,16 @@ class Oracle:
         self.L.wpt_oracle_bvh_hits(scene.desc, C.c_int(n), C.c_void_p(rays8.ctypes.data), C.c_void_p(out.ctypes.data), C.byref(cnt))
         return out, cnt.as_dict()
 
+    def wide_walk_check(self, scene, rays8):
+        """The collapsed four-wide walk of DESIGN.md section 7.1 next to BVH::hit: (rays that differ, statistics)."""
+        rays8 = np.ascontiguousarray(rays8, np.float32)
+        n = rays8.size // 8
+        stats = (C.c_uint64 * 10)()
+        self.L.wpt_oracle_wide_walk_check.restype = C.c_int
+        differ = self.L.wpt_oracle_wide_walk_check(scene.desc, C.c_int(n), C.c_void_p(rays8.ctypes.data), stats)
+        names = ("rays", "binary_visits", "wide_steps", "wide_box_tests", "leaf_tests", "nan_fallbacks", "revalidations_failed", "max_pending", "admission_disagrees", "parent_disagrees")
+        return int(differ), dict(zip(names, [int(x) for x in stats]))
+
     def math(self, op, a, b=None):
         a = np.ascontiguousarray(a, np.float32)
         b = np.ascontiguousarray(b if b is not None else a, np.float32)
