@@ -545,6 +545,64 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
             }
         }
         UP(uploadArray(s, dev.data(), dev.size(), &nodes));
+#ifdef WPT_WIDE_WALK
+        {
+            /* the binary tree collapsed by one level (wpt_device.h, SceneView::wideNodes): wide nodes are made for the root and
+             * for every inner node that is an entry of a wide node, depth first */
+            std::vector<float4> wide;
+            std::vector<uint32_t> todo(1, 0u);        /* binary nodes to make a wide node for */
+            std::vector<uint32_t> wideOf(n, 0xffffffffu);
+            if (n > 0)
+                wideOf[0] = 0;
+            uint32_t made = n > 0 ? 1u : 0u;
+            for (size_t t = 0; t < todo.size(); t++) {
+                const uint32_t x = todo[t];
+                uint32_t entry[4];
+                int count = 0;
+                if (desc->nodes[x].kind == WPT_NODE_INNER) {
+                    const uint32_t child[2] = { x + 1, desc->nodes[x].link };
+                    for (int k = 0; k < 2; k++) {
+                        if (desc->nodes[child[k]].kind == WPT_NODE_INNER) {
+                            entry[count++] = child[k] + 1;
+                            entry[count++] = desc->nodes[child[k]].link;
+                        } else {
+                            entry[count++] = child[k];
+                        }
+                    }
+                } else {
+                    entry[count++] = x; /* a tree of one leaf */
+                }
+                float q[8][4];
+                uint32_t ref[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+                for (int r = 0; r < 8; r++)
+                    for (int k = 0; k < 4; k++)
+                        q[r][k] = 0.0f;
+                for (int k = 0; k < count; k++) {
+                    const wpt_bvh_node& nd = desc->nodes[entry[k]];
+                    for (int a = 0; a < 3; a++) {
+                        q[a][k] = nd.lo[a];
+                        q[3 + a][k] = nd.hi[a];
+                    }
+                    if (nd.kind == WPT_NODE_INNER) {
+                        wideOf[entry[k]] = made++;
+                        todo.push_back(entry[k]);
+                        ref[k] = NODE_CHILD | wideOf[entry[k]];
+                    } else if (nd.kind == WPT_NODE_TRIANGLE) {
+                        ref[k] = nd.link;
+                    } else if (nd.kind == WPT_NODE_SPHERE) {
+                        ref[k] = PRIM_SPHERE | nd.link;
+                    }
+                }
+                memcpy(q[6], ref, 16);
+                for (int r = 0; r < 8; r++)
+                    wide.push_back(make_float4(q[r][0], q[r][1], q[r][2], q[r][3]));
+            }
+            if (made > NODE_INDEX_MASK)
+                return fail(WPT_ERR_UNSUPPORTED, "more than 2^30 - 1 wide nodes");
+            /* todo[] is in order of creation, which is the order of the wide indices handed out above */
+            UP(uploadArray(s, wide.data(), wide.size(), &s->view.wideNodes));
+        }
+#endif
     }
     UP(uploadArray(s, reinterpret_cast<const float4*>(desc->tri_geom), size_t(desc->tri_count) * 3, &geom));
     UP(uploadArray(s, reinterpret_cast<const float4*>(desc->tri_attr), size_t(desc->tri_count) * 6, &attr));

@@ -474,6 +474,13 @@ struct SceneView {
     uint32_t sphereCount;
     const wpt_animation* animations; /* key frame animations of instances and camera */
     const wpt_keyframe* keyframes;
+#ifdef WPT_WIDE_WALK
+    /* Variant build (oracle/wpt_oracle.cpp::bvhTraverseWide): the binary tree collapsed by one level.
+     * 8 quadwords per wide node: lo.x, lo.y, lo.z, hi.x, hi.y, hi.z of up to four entries (the node's grandchildren, a child
+     * that is a leaf standing for itself, in the reference's order), their references (NODE_CHILD | wide node, a triangle
+     * index, PRIM_SPHERE | sphere index, 0xffffffff = no entry), one spare.  Wide node 0 is the root's. */
+    const float4* wideNodes;
+#endif
 };
 
 /* ---- animations at a ray's time (wpt_anim.h) ---- */

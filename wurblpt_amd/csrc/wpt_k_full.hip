@@ -3,6 +3,9 @@
 #ifdef WPT_TOP_IN_LDS
 #define WPT_TOP_IN_LDS_HERE WPT_TOP_IN_LDS /* variant build: this unit's kernel walks the top of the tree from LDS */
 #endif
+#ifdef WPT_WIDE_WALK
+#define WPT_WIDE_WALK_HERE /* variant build: this unit's kernel walks the tree collapsed by one level */
+#endif
 #include "wpt_pathtrace.inc.h"
 
 #ifndef WPT_FULL_FEATURES

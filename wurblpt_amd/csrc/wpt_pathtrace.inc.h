@@ -195,7 +195,15 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 #ifndef WPT_LDS_PREFETCH
 #define WPT_LDS_PREFETCH 0 /* experiments: 1 = the kernel with the scene in LDS requests its next node ahead as well */
 #endif
-    constexpr bool PREFETCH = !LDSSCENE || WPT_LDS_PREFETCH;
+#ifdef WPT_WIDE_WALK_HERE
+    /* Variant build: this unit's rendering kernel walks the tree collapsed by one level (SceneView::wideNodes; the walk is
+     * oracle/wpt_oracle.cpp::bvhTraverseWide, checked there against BVH::hit).  A prototype for measuring: lanes with a NaN
+     * slab distance are not given the reference's own tests yet. */
+    constexpr bool WIDE = !LDSSCENE && !COUNT;
+#else
+    constexpr bool WIDE = false;
+#endif
+    constexpr bool PREFETCH = (!LDSSCENE || WPT_LDS_PREFETCH) && !WIDE;
     /* leaf records (wpt_capi.hip): the walk reads a triangle's corners behind its leaf node; not where the corners are
      * moved by an animation first (those kernels need the instance and flag words of the triangle array anyway) */
     constexpr bool LEAFREC = !LDSSCENE && !(F & FEAT_ANIM);
@@ -324,6 +332,12 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     RayAux aux = rayAux(ps.d);
     uint32_t node = 0, leafPrim = 0;
     float amax = k_maxval;
+#ifdef WPT_WIDE_WALK_HERE
+    /* children that wait for their turn: reference and entry distance (bits), the walk's own stack in scratch memory */
+    constexpr uint32_t WIDE_PENDING = 40;
+    uint2 pend[WIDE_PENDING];
+    uint32_t sp = 0;
+#endif
     Candidate best;
     best.prim = NO_HIT;
     best.a = best.invDet = best.U = best.V = best.W = 0.0f;
@@ -335,6 +349,12 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         amax = k_maxval;
         best.prim = NO_HIT;
         state = S_NODE;
+#ifdef WPT_WIDE_WALK_HERE
+        if (WIDE) { /* the root's wide node, admitted under any bound (the root's own box decides nothing its children do not) */
+            pend[0] = make_uint2(NODE_CHILD | 0u, __float_as_uint(0.0f));
+            sp = 1;
+        }
+#endif
         if (COUNT)
             lc.rays++;
     };
@@ -579,6 +599,11 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                             best = c;
                             amax = c.a;
                         }
+#ifdef WPT_WIDE_WALK_HERE
+                        if (WIDE)
+                            state = sp == 0 ? endOfRayState() : (int)S_NODE;
+                        else
+#endif
                         state = node >= nodeCount ? endOfRayState() : (int)S_NODE;
                         /* A light ray towards the environment asks one thing: is anything in the way (blockNeeEnd,
                          * wurblpt.hpp:240-250).  Up to a walk's first accepted hit the bound is the ray's own, so every box
@@ -596,6 +621,42 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         sched[1]++;
                         sched[2] += nNode;
                     }
+#ifdef WPT_WIDE_WALK_HERE
+                    if (WIDE && state == S_NODE) {
+                        /* one child that has waited: admitted if its entry distance is within the bound of this moment (the
+                         * reference's test at its turn); a leaf goes to its test, an inner node's four entries are tested
+                         * WITHOUT the bound and those the ray passes through wait in the reference's order */
+                        const uint2 e = pend[--sp];
+                        const uint32_t ref = e.x;
+                        if (__uint_as_float(e.y) <= amax) {
+                            if (ref < NODE_CHILD) {
+                                leafPrim = ref;
+                                state = S_LEAF;
+                            } else {
+                                const float4* w = sv.wideNodes + 8 * (size_t)(ref & NODE_INDEX_MASK);
+                                const float4 lx = w[0], ly = w[1], lz = w[2], hx = w[3], hy = w[4], hz = w[5], rf = w[6];
+                                const float amin = par.min_hit_distance;
+                                auto entryOf = [&](float lox, float loy, float loz, float hix, float hiy, float hiz, uint32_t r) {
+                                    const float t0x = (lox - ps.o.x) * aux.inv.x, t0y = (loy - ps.o.y) * aux.inv.y, t0z = (loz - ps.o.z) * aux.inv.z;
+                                    const float t1x = (hix - ps.o.x) * aux.inv.x, t1y = (hiy - ps.o.y) * aux.inv.y, t1z = (hiz - ps.o.z) * aux.inv.z;
+                                    const float near = __builtin_fmaxf(__builtin_fmaxf(amin, __builtin_fminf(t0x, t1x)),
+                                            __builtin_fmaxf(__builtin_fminf(t0y, t1y), __builtin_fminf(t0z, t1z)));
+                                    const float far = __builtin_fminf(__builtin_fminf(k_maxval, __builtin_fmaxf(t0x, t1x)),
+                                            __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
+                                    if (r != 0xffffffffu && near <= far && sp < WIDE_PENDING)
+                                        pend[sp++] = make_uint2(r, __float_as_uint(near));
+                                };
+                                entryOf(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, __float_as_uint(rf.w));
+                                entryOf(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, __float_as_uint(rf.z));
+                                entryOf(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, __float_as_uint(rf.y));
+                                entryOf(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, __float_as_uint(rf.x));
+                            }
+                        }
+                        if (state == S_NODE && sp == 0)
+                            state = endOfRayState();
+                    }
+                    if (!WIDE)
+#endif
 #pragma unroll
                     for (int step = 0; step < STEPS; step++)
                     if (state == S_NODE) {
