@@ -2339,6 +2339,9 @@ void wpt_oracle_envmap_probe(const wpt_scene_desc* scene, int n, const float* in
  * slab arithmetic is monotone, so a child that passes implies the parent the reference tested before it.  Both arguments
  * need slab distances that are numbers: with a NaN among them (0 * inf: origin on a slab plane, direction parallel to it)
  * the comparison chains of gvm.hpp depend on operand order, and the step falls back to the reference's own two tests. */
+/* what a kernel prototype leaves out, to see what each omission costs: 1 = no fall-back for NaN slabs, 2 = IEEE minimum / maximum
+ * instead of the reference's comparison chains, 4 = the root's own box is not tested */
+static int g_wideMode = 0;
 struct WideWalkStats {
     uint64_t rays, binaryVisits, wideSteps, wideBoxTests, leafTests, nanFallbacks, revalidationsFailed, maxPending;
     uint64_t admissionDisagrees, parentDisagrees; /* self-checks of the two arguments, counted where they fail */
@@ -2349,11 +2352,17 @@ inline bool slabsOf(const float* lo, const float* hi, const Ray& ray, V3 invDir,
     const V3 t0 = (v3(lo) - ray.origin) * invDir;
     const V3 t1 = (v3(hi) - ray.origin) * invDir;
     const bool number = t0.x == t0.x && t0.y == t0.y && t0.z == t0.z && t1.x == t1.x && t1.y == t1.y && t1.z == t1.z;
+    if (g_wideMode & 2) {
+        entry = std::fmax(std::fmax(amin, std::fmin(t0.x, t1.x)), std::fmax(std::fmin(t0.y, t1.y), std::fmin(t0.z, t1.z)));
+        const float far = std::fmin(std::fmin(amax, std::fmax(t0.x, t1.x)), std::fmin(std::fmax(t0.y, t1.y), std::fmax(t0.z, t1.z)));
+        pass = entry <= far;
+        return number || (g_wideMode & 1);
+    }
     const V4 tmin = V4 { amin, fmin_(t0.x, t1.x), fmin_(t0.y, t1.y), fmin_(t0.z, t1.z) };
     const V4 tmax = V4 { amax, fmax_(t0.x, t1.x), fmax_(t0.y, t1.y), fmax_(t0.z, t1.z) };
     entry = max4(tmin);
     pass = entry <= min4(tmax);
-    return number;
+    return number || (g_wideMode & 1);
 }
 
 template<typename LeafHit>
@@ -2367,7 +2376,7 @@ inline HitRecord bvhTraverseWide(const wpt_bvh_node* nodes, const Ray& ray, cons
     };
     HitRecord hr;
     std::vector<Pending> pending;
-    pending.push_back(Pending { 0u, false, 0.0f });
+    pending.push_back(Pending { 0u, (g_wideMode & 4) != 0, 0.0f });
     while (!pending.empty()) {
         if (pending.size() > st.maxPending)
             st.maxPending = pending.size();
@@ -2459,6 +2468,8 @@ extern "C" {
 
 /* n rays (origin, dir, amin, amax = 8 floats) through both walks: returns the number of rays whose sequence of leaf tests or
  * whose result (hit, primitive, distance bits) differs; stats: 8 x uint64 (WideWalkStats). */
+void wpt_oracle_wide_walk_mode(int mode) { g_wideMode = mode; }
+
 int wpt_oracle_wide_walk_check(const wpt_scene_desc* scene, int n, const float* rays, uint64_t* stats)
 {
     wpt_params pr;
