@@ -22,6 +22,16 @@ t_start = time.time()
 
 def check(label, sc, s, p=None, tables=False):
     global bad, done
+    if os.environ.get("WPT_FUZZ_LIST"):
+        # no rendering (runs without a GPU): the same draws from the generator, and what each scene was rendered with
+        w_, h_ = sc.width, sc.height
+        start = int(rng.integers(0, w_ * h_))
+        rng.integers(1, w_ * h_ - start + 1)
+        rng.integers(1, 20), rng.integers(1, 6)
+        print("%s: %dx%d, samples_sqrt %d, max_path_components %s, rr_threshold %s, randomize_ray_over_pixel %s" % (
+            label, w_, h_, s, getattr(p, "max_path_components", None), getattr(p, "rr_threshold", None), getattr(p, "randomize_ray_over_pixel", None)), flush=True)
+        done += 1
+        return
     if tables and sc.d.envmap.N > 0:
         t = orc.envmap_tables(sc)
         ds = device.DeviceScene(sc)       # the device builds its own tables at upload
