@@ -232,7 +232,7 @@ def roofline_of(name, scene, cnt, spp, count_sqrt, avg_ms, avg_samples, n_launch
     return roofline
 
 
-def measure_one_gpu(name, w, scene, dscene, steps, warmup, cpu_seconds, lib_id, torch, device, host, barrier=None):
+def measure_one_gpu(name, w, scene, dscene, steps, warmup, cpu_seconds, lib_id, torch, device, host, barrier=None, walk_flags=0):
     """W untimed + K timed renders of the workload's frame on this GPU (one render call each), the counted pass for the
     roofline, the CPU baseline on a block of the same frame and the parity of that block."""
     width, height, ssqrt = w["width"], w["height"], w["samples_sqrt"]
@@ -253,14 +253,14 @@ def measure_one_gpu(name, w, scene, dscene, steps, warmup, cpu_seconds, lib_id, 
         # answer it is traced for is known there), the reference's goes on.  The counted pass above counts the reference's walk
         # (its numbers are the oracle's, and the algorithmic bytes are the reference's by definition); this one counts the
         # product's, so that the line says both.
-        os.environ["WPT_COUNT_PRODUCT_WALKS"] = "1"
+        device.lib().wpt_set_walk(walk_flags | device.WALK_COUNT_PRODUCT)
         try:
             counters.zero_()
             dscene.render_block_into(frame, ssqrt, None, params, counters, stream)
             torch.cuda.synchronize()
             walked = dict(zip(names, [int(x) for x in counters.cpu().tolist()]))
         finally:
-            os.environ.pop("WPT_COUNT_PRODUCT_WALKS", None)
+            device.lib().wpt_set_walk(walk_flags)
     frame.zero_()
     events = []
 
@@ -320,6 +320,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip that comparison and the oracle rows")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant / scheduler tuning word for wpt_set_launch_config (experiments)")
     ap.add_argument("--wavefront", type=int, default=0, help="wpt_set_wavefront mode: 0 = the library decides, 1 = wavefront kernels wherever they exist, 2 = never")
+    ap.add_argument("--wide-walk", action="store_true", help="wpt_set_walk(WPT_WALK_WIDE): scenes fetched from HBM are walked over the tree collapsed by one level (experiments)")
     ap.add_argument("--top-nodes", type=int, default=-1, help="BVH nodes stored level by level in front of the array (wpt_set_top_nodes; experiments)")
     args = ap.parse_args()
 
@@ -392,6 +393,8 @@ def main():
         device.lib().wpt_set_wavefront(args.wavefront, 0, 0, 0)
     if args.top_nodes >= 0:
         device.lib().wpt_set_top_nodes(args.top_nodes)
+    walk_flags = device.WALK_WIDE if args.wide_walk else 0
+    device.lib().wpt_set_walk(walk_flags)  # before the upload: the wide form of a tree is built there
     lib_id = library_identity()
     dscene = device.DeviceScene(scene)
     params = host.default_params()
@@ -406,7 +409,7 @@ def main():
     sharded = world > 1 or args.force_blocks > 0
     if not sharded:
         # ---- N = 1: one render call per step ----
-        m, frame = measure_one_gpu(name, w, scene, dscene, args.steps, args.warmup, cpu_seconds, lib_id, torch, device, host, barrier)
+        m, frame = measure_one_gpu(name, w, scene, dscene, args.steps, args.warmup, cpu_seconds, lib_id, torch, device, host, barrier, walk_flags)
         verified = None
         out = {
             "metric": "Msamples/s", "value": m["value"], "unit": "Msamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -425,7 +428,7 @@ def main():
             sscene = build_scene(sw)
             t2 = time.perf_counter() - t2
             sd = device.DeviceScene(sscene)
-            sm, _ = measure_one_gpu(sname, sw, sscene, sd, args.secondary_steps, 1, min(cpu_seconds, 8.0), lib_id, torch, device, host)
+            sm, _ = measure_one_gpu(sname, sw, sscene, sd, args.secondary_steps, 1, min(cpu_seconds, 8.0), lib_id, torch, device, host, walk_flags=walk_flags)
             sm.update(workload=sname, unit="Msamples/s", scene_build_s=t2,
                       config={"workload": sname, "width": sw["width"], "height": sw["height"], "spp": sw["samples_sqrt"] ** 2,
                               "triangles": int(sscene.d.tri_count), "bvh_nodes": int(sscene.d.node_count), "parallelism": "1 launch"})

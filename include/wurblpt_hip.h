@@ -429,33 +429,39 @@ wpt_status wpt_postproc_host(int op, const float* rgb_host, void* out_host, uint
 wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant);
 /* Storage order of the BVH nodes in HBM for scenes uploaded from now on: the first `nodes` nodes of a tree that is
  * larger than an L2 slice are stored level by level in front of the array, the subtrees below them depth-first
- * (0 = the whole tree depth-first, the reference's own array order; default 65536 = 2 MiB).  Bit 31 set: a tree that
- * is walked from HBM also keeps every triangle's corners behind its leaf node, so that a leaf test reads on in the line
- * its node came in (measured: no gain, off by default).  Visiting order and results do not depend on it. */
+ * (0 = the whole tree depth-first, the reference's own array order; default 65536 = 2 MiB).  Visiting order and results do
+ * not depend on it. */
 wpt_status wpt_set_top_nodes(uint32_t nodes);
+/* How rays walk the tree (results do not depend on it; process-global like the hooks above, set it before uploading and
+ * rendering, not while other threads render):
+ *   WPT_WALK_WIDE           scenes uploaded from now on whose tree is fetched from HBM also get the tree collapsed by one level
+ *                           (128-byte nodes that hold the boxes of a node's four grandchildren), and product launches walk that:
+ *                           four box tests per fetch, leaf tests in BVH::hit's order (bvh.hpp:277-311), the same hits bit for bit
+ *                           (wpt_pathtrace.inc.h says why; rays for which the argument does not hold walk the binary tree).
+ *                           Trees with a non-finite box, a child's box outside its parent's, or a worst case of more than 64
+ *                           waiting entries have no wide form and are walked as before.
+ *   WPT_WALK_FULL_SHADOW    light rays towards the environment walk the tree to the end like the reference's (product launches
+ *                           end such a walk at its first accepted hit: the answer the ray is traced for is known there)
+ *   WPT_WALK_COUNT_PRODUCT  counting launches, which otherwise walk like the reference so that their counters are its
+ *                           counters, count the product's shortened walks instead */
+#define WPT_WALK_WIDE 1u
+#define WPT_WALK_FULL_SHADOW 2u
+#define WPT_WALK_COUNT_PRODUCT 4u
+wpt_status wpt_set_walk(uint32_t flags);
 /* Which form of the path tracer renders frames whose scene is fetched from HBM (results do not depend on it):
  * mode 0 = the library decides per launch (default), 1 = the wavefront form wherever it exists (trace and shade as two
  * kernels that hand rays through HBM, wpt_wavefront.inc.h: everything but counting launches and moving scenes), 2 = never.
- * groups: groups of lanes that iterate on streams of their own (0 = default); chunk: queue entries a wave of the trace
+ * groups, bits 0-7: groups of lanes that iterate on streams of their own (0 = default), bits 8-15 (measurements): workgroups
+ * of the trace kernel per compute unit (0 = what fits), bit 16 (measurements): one shade launch per kind of material, so that a
+ * kernel trace tells the kinds apart; chunk: queue entries a wave of the trace
  * takes per atomic (0 = default); flags bit 0: the shade walks the ray queue in its own order instead of by kind of
  * material, bits 1-7: nodes in front of the node array that the trace walks from LDS, in units of 128 (0 = default, 0x7f =
- * none), bits 8-15: lanes of a wave that must have finished before the trace deals it new rays (0 = default), bits 16-31: node
+ * none), bits 8-13: lanes of a wave that must have finished before the trace deals it new rays (0 = default), bits 16-31: node
  * steps a ray takes per launch of the trace before its walk is suspended until the next (0 = default, 0xffff = no limit).
  * Process-global like wpt_set_launch_config and wpt_set_top_nodes: a hook for tests and measurements, set it before
  * rendering starts, not while other threads render. */
 wpt_status wpt_set_wavefront(uint32_t mode, uint32_t groups, uint32_t chunk, uint32_t flags);
-/* Environment variables the library reads -- all of them measurement hooks (DESIGN.md sections 4
- * and 7); none changes a result, none is needed to use the library:
- *   WPT_REDEAL=n            scenes in LDS: the kernel whose workgroups deal their paths to their lanes anew at every n-th look
- *                           at the lane counts (WPT_REDEAL_IDENTITY: every path stays in its lane, the price of a deal alone)
- *   WPT_FULL_SHADOW_WALKS   light rays towards the environment walk the tree to the end like the reference's (product launches
- *                           end such a walk at its first accepted hit: the answer the ray is traced for is known there)
- *   WPT_COUNT_PRODUCT_WALKS counting launches, which otherwise walk like the reference so that their counters are its
- *                           counters, count the product's shortened walks instead
- *   WPT_XCD_BANDS=1         the workgroups that share an XCD render one contiguous eighth of a launch's pixels between them
- *   WPT_EXTRA_LDS=bytes     scenes in LDS: idle LDS per workgroup (what fewer workgroups per compute unit cost)
- *   WPT_WF_TRACE_PER_CU=n   wavefront form: workgroups of the trace kernel per compute unit
- *   WPT_WF_SHADE_PER_KIND   wavefront form: one shade launch per kind of material, so that a kernel trace tells them apart */
+/* The library reads no environment variable. */
 
 /* Profiling hook: `stats_device` (device pointer to 24 uint64, or NULL to switch off) receives
  * the wave scheduler's statistics of launches that also count work (counters_device != NULL):
@@ -466,13 +472,13 @@ wpt_status wpt_set_wavefront(uint32_t mode, uint32_t groups, uint32_t chunk, uin
  * light pdf 2, evaluation towards the light, environment sampling / continuation). */
 wpt_status wpt_set_scheduler_stats(unsigned long long* stats_device);
 
-/* Name of the GPU kernel that wpt_render_block_device launches (for profile matching). */
+/* Kernel family of the process's most recent render call (for profile matching). */
 const char* wpt_kernel_name(void);
 /* What the reference records about a run for the CPU (wurblpt.hpp:393-400,425-435: COMPILER, CPU_MODEL), for the device:
  * marketing name and architecture of HIP device `device` ("AMD Instinct MI355X (gfx950:...)", or "" if there is none), and
  * the compiler and options the kernels were built with.  The strings live until the next call from the same thread. */
 const char* wpt_device_name(int device);
-/* Kernel launches the calling thread's last render call took for its pixels: 1, or 2 when the frame was rendered in two
+/* Kernel launches the process's most recent render call took for its pixels: 1, or 2 when the frame was rendered in two
  * passes (timed first row of strata, then the rest with the longest tiles first), or the hundreds of trace + shade
  * launches of the wavefront form. Profilers see that many kernel launches per frame; what is rendered does not depend on it. */
 uint32_t wpt_last_render_passes(void);

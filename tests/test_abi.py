@@ -160,6 +160,20 @@ def test_product_does_not_touch_the_oracle():
             assert "liboracle" not in open(os.path.join(dirpath, f)).read()
 
 
+def test_product_library_reads_no_environment_variable():
+    """One product, separate experiments: nothing an inherited environment variable could switch lives in the library that ships
+    (measurement settings are arguments of the wpt_set_* hooks)."""
+    path = os.path.join(ROOT, "wurblpt_amd", "lib", "libwurblpt_hip.so")
+    symbols = subprocess.check_output(["nm", "-D", path]).decode()
+    assert "getenv" not in symbols, [l for l in symbols.splitlines() if "getenv" in l]
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "wurblpt_amd", "csrc")):
+        if os.path.basename(dirpath).startswith("build"):
+            continue
+        for f in files:
+            if f.endswith((".h", ".hip")):
+                assert "getenv" not in open(os.path.join(dirpath, f)).read(), f
+
+
 def test_header_is_plain_c(tmp_path):
     """include/wurblpt_hip.h is the boundary for any language with a C FFI: it compiles as C99 with -pedantic."""
     src = tmp_path / "cabi.c"

@@ -2,7 +2,7 @@
 How fast do walks run when the rays of a wave belong together?  The Sponza-class frame with paths cut after 2, 3, 4, ... components
 (Parameters::maxPathComponents): with 2 there are camera rays and the light rays from their hits only -- neighbouring pixels,
 neighbouring origins --, every further component adds rays that have been scattered once more.  Node visits per second
-(visits from a counting launch with the product's walks, WPT_COUNT_PRODUCT_WALKS; time from the rendering launch) per depth
+(visits from a counting launch with the product's walks, wpt_set_walk(WPT_WALK_COUNT_PRODUCT); time from the rendering launch) per depth
 says what sorting rays could at best recover of the difference between the first and the last line."""
 import os
 import sys
@@ -24,10 +24,10 @@ for depth in (2, 3, 4, 6, 10, 0):
     if depth:
         params.max_path_components = depth
     counters = torch.zeros(6, dtype=torch.int64, device="cuda")
-    os.environ["WPT_COUNT_PRODUCT_WALKS"] = "1"
+    device.lib().wpt_set_walk(device.WALK_COUNT_PRODUCT)
     ds.render_block_into(frame, ssqrt, None, params, counters, stream)
     torch.cuda.synchronize()
-    os.environ.pop("WPT_COUNT_PRODUCT_WALKS")
+    device.lib().wpt_set_walk(0)
     cnt = dict(zip(names, [int(x) for x in counters.cpu().tolist()]))
     best = 1e30
     for _ in range(3):

@@ -1,6 +1,7 @@
-"""usage (GPU box): python tools/fuzz_parity.py [rounds [seed [scale]]]
+"""usage (GPU box): python tools/fuzz_parity.py [rounds [seed [scale]]] [--wide]
 Seeded random scenes of every family through the GPU and the CPU restatement: frames, work counters and the ground truth
 arrays must agree bit for bit; a random pixel block and a random split into interleaved bands must give the same frame.
+--wide: scenes are uploaded with the wide form of their tree (wpt_set_walk) and product launches walk that.
 Prints one line per mismatch and a summary; exit code 1 if anything differed."""
 import os
 import sys
@@ -11,6 +12,8 @@ import numpy as np
 from wurblpt_amd import device, host
 from tests import oracle_loader
 
+wide = "--wide" in sys.argv
+sys.argv = [a for a in sys.argv if a != "--wide"]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 orc = oracle_loader.load("portable")
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
@@ -18,6 +21,8 @@ scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # frames `scale` times
 bad = 0
 done = 0
 t_start = time.time()
+if wide and not os.environ.get("WPT_FUZZ_LIST"):
+    device.lib().wpt_set_walk(device.WALK_WIDE)
 
 
 def check(label, sc, s, p=None, tables=False):

@@ -33,8 +33,7 @@ using namespace wptd;
 
 constexpr uint32_t NO_HIT = 0xffffffffu;
 
-enum { RAY_PATH = 0, RAY_NEE_LIGHT = 1, RAY_NEE_ENV = 2, RAY_PATH_WAITED = 3 /* a path ray's hit that has stood back once */,
-       RAY_NEE_ENV_PENDING = 4 /* WPT_EVAL_BEHIND_RAY: a light ray towards the environment whose material evaluation waits for its end */ };
+enum { RAY_PATH = 0, RAY_NEE_LIGHT = 1, RAY_NEE_ENV = 2, RAY_PATH_WAITED = 3 /* a path ray's hit that has stood back once */ };
 enum { NEXT_TRACE = 0, NEXT_NEW = 1, NEXT_DONE = 2, NEXT_WAIT = 3 };
 
 struct LaneCounters {
@@ -449,11 +448,7 @@ WPT_D int blockNew(const FrameArgs& fa, PS& ps, const SceneView& sv)
 
 /* tracePath, one path component (wurblpt.hpp:131-252); `best` is the path ray's result */
 template<uint32_t F, bool COUNT, class Tri4, class PS>
-WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& ps, const Candidate& best, LaneCounters& lc, int waitBelow = 0
-#ifdef WPT_EVAL_BEHIND_RAY
-        , bool evalBehindRay = false /* measured BRDFs: the evaluation towards the environment waits for the light ray's end (blockNeeEndPending) */
-#endif
-        )
+WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& ps, const Candidate& best, LaneCounters& lc, int waitBelow = 0)
 {
     const bool haveEnv = (F & FEAT_ENVMAP) && sv.envType != WPT_ENV_NONE;
     if (best.prim == NO_HIT) {
@@ -592,26 +587,6 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
         const float lightsP = envP(sv, sr.dir);
         nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, lightsP));
         const f3 lightDir = envD(sv, prng);
-#ifdef WPT_EVAL_BEHIND_RAY
-        if (evalBehindRay && (F & FEAT_RGL) && m.type == WPT_MAT_RGL) {
-            /* The evaluation draws no random number and feeds the light ray's contribution alone: it can run behind the
-             * ray, and not at all where the ray is shadowed.  What is decided here is whether a ray is traced: the cheap
-             * part of the evaluation's own answer (material_rgl.hpp:82-98 -- the direction's side of the surface); where
-             * it says no the evaluation's pdf is 0 and the reference traces no ray either, where it says yes and the
-             * tables still give 0 the ray's end adds nothing. */
-            const Frame ts = tangentSpaceAt<F>(sv, m, h, mc);
-            if (dot(ts.n, lightDir) > 0.0f && toTangent(ts, neg(ray.d)).z > 0.0f && toTangent(ts, lightDir).z > 0.0f) {
-                ps.set4(SLOT_NEXTATT, nextAtt);
-                ps.set3(SLOT_SRDIR, sr.dir);
-                storePrng(ps, prng);
-                ps.o = h.p;
-                ps.d = lightDir;
-                ps.rayKind = RAY_NEE_ENV_PENDING;
-                section(7);
-                return NEXT_TRACE;
-            }
-        } else {
-#endif
         const float directPdf = envP(sv, lightDir);
         float dpdf;
         f4 directAtt;
@@ -628,9 +603,6 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
             section(7);
             return NEXT_TRACE;
         }
-#ifdef WPT_EVAL_BEHIND_RAY
-        }
-#endif
     }
     /* No next-event ray.  The scattered ray's refractive index: every ScatterRandom record
      * carries the incoming ray's index unchanged (material_lambertian.hpp:83, material_ggx.hpp:224,
@@ -681,45 +653,6 @@ WPT_D int blockNeeEnd(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS&
         storePrng(ps, prng);
     return next;
 }
-
-#ifdef WPT_EVAL_BEHIND_RAY
-/* The end of a light ray towards the environment that nothing was in the way of, with the material's evaluation still to do
- * (blockShade, evalBehindRay): the path ray's hit record is made again from its candidate, origin and direction -- the same
- * arguments, the same values --, then wurblpt.hpp:229-250 as blockShade and blockNeeEnd have them, and the path continues. */
-template<uint32_t F, class Tri4, class PS>
-WPT_D int blockNeeEndPending(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& ps, const Candidate& pathBest, f3 pathO, f3 pathD)
-{
-    Ray ray;
-    ray.o = pathO;
-    ray.d = pathD;
-    ray.ri = ps.get4(SLOT_RI);
-    Hit h = finishHit<F>(sv, pathBest, ray.o, ray.d, ps.time, tri4);
-    const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
-    MatCache mc = matCacheEmpty();
-    float dpdf;
-    f4 directAtt;
-    materialEval<F>(sv, m, ray, h, ps.d, directAtt, dpdf, mc);
-    if (dpdf > 0.0f) {
-        const float directPdf = envP(sv, ps.d);
-        const f4 att = ps.get4(SLOT_ATT);
-        const f4 neeFactor = sclr(divs(mul(att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
-        f4 rad = mul(mk4(neeFactor.x, neeFactor.y, neeFactor.z, 0.0f), envL(sv, ps.d));
-        accumulateRadiance(par, mk3(k_maxval, k_maxval, k_maxval), k_maxval, rad, ps);
-    }
-    const Slot oplSlot = ps.get(SLOT_OPL);
-    const f4 nextAtt = ps.get4(SLOT_NEXTATT);
-    const Slot sd = ps.get(SLOT_SRDIR);
-    const bool roulette = max4(nextAtt) < par.rr_threshold && oplSlot.w >= 5;
-    Prng prng;
-    prng.s0 = prng.s1 = prng.s2 = prng.s3 = 0;
-    if (roulette)
-        prng = loadPrng(ps);
-    const int next = advancePath(par, ps, nextAtt, mk3(sd.x, sd.y, sd.z), oplSlot.w, prng);
-    if (roulette)
-        storePrng(ps, prng);
-    return next;
-}
-#endif
 
 } /* namespace wptk */
 

@@ -6,9 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
-#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -171,14 +171,18 @@ uint32_t g_variant = 0;
 uint32_t g_leaveEighths = 0; /* 0 = default: chosen per scene size (single-role kernel) / patience 8 rounds (ray-pool kernel) */
 uint32_t g_heavyMin = 0; /* 0 = chosen per scene size at launch */
 uint32_t g_leafBias = 0;
-thread_local uint32_t g_lastPasses = 1; /* kernel launches the calling thread's last render call took for its pixels (wpt_last_render_passes) */
-bool g_leafRecords = false; /* wpt_set_top_nodes bit 31: triangle corners also behind their leaf node for trees walked from HBM (measured: no gain) */
+/* what the process's most recent render call ran: kernel launches it took for its pixels (wpt_last_render_passes) and which
+ * kernel family (wpt_kernel_name).  Process-wide, so that a caller whose worker threads render (MPICoordinator, bench.py's
+ * block queue) reads on its main thread what the workers ran. */
+std::atomic<uint32_t> g_lastPasses{1};
+std::atomic<const char*> g_kernelName{nullptr};
 uint32_t g_topNodes = 65536; /* nodes of a large tree that are stored level by level in front (wpt_set_top_nodes) */
 unsigned long long* g_schedStats = nullptr;
 /* wpt_set_wavefront: 0 = the library decides, 1 = wavefront wherever it exists, 2 = never; launch geometry (0 = defaults) */
 uint32_t g_wfMode = 0;
-wptk::WfConfig g_wfConfig = { 0, 0, 0, 1, 0, 0, 0 };
-thread_local const char* g_kernelName = nullptr; /* the calling thread's last render: which kernel family ran */
+wptk::WfConfig g_wfConfig = { 0, 0, 0, 1, 0, 0, 0, 0, 0 };
+/* wpt_set_walk: WPT_WALK_* bits */
+uint32_t g_walk = 0;
 
 template<typename T> wpt_status uploadArray(wpt_scene* s, const T* src, size_t count, const T** dst)
 {
@@ -467,23 +471,9 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
         std::vector<uint32_t> end(n);
         for (uint32_t i = n; i-- > 0;)
             end[i] = desc->nodes[i].kind == WPT_NODE_INNER ? end[desc->nodes[i].link] : i + 1;
-        /* Leaf records.  For trees that are walked from HBM / L2 (too large for LDS) a triangle leaf takes three 32-byte
-         * slots of the node array: its node, then the triangle's three corner quadwords (the fourth word of the first is
-         * the triangle's index).  The leaf test then reads on in the line the walk has just fetched instead of asking for a
-         * second, unrelated line of the triangle array.  Links are storage indices already, so the walk does not change;
-         * view.nodeCount counts slots.  Measured (tools/ab_leafrec.py, same process, frames equal bit for bit): 10 M
-         * triangles 61.0 - 61.2 with leaf records against 62.5 Msamples/s without, Sponza-class 131.0 - 131.2 against 131.7:
-         * the second fetch of one visit in nine is not what these walks wait for, and the node array twice as long costs
-         * the caches more than the saved line brings.  Off by default (wpt_set_top_nodes bit 31 switches it on). */
-        const bool leafRecords = size_t(n) * 32 + size_t(desc->tri_count) * 48 > LDS_SCENE_MAX_BYTES && g_leafRecords;
-        auto slotsOf = [&](uint32_t i) -> uint32_t { return leafRecords && desc->nodes[i].kind == WPT_NODE_TRIANGLE ? 3u : 1u; };
-        uint64_t slotCount = 0;
-        for (uint32_t i = 0; i < n; i++)
-            slotCount += slotsOf(i);
-        if (slotCount > NODE_INDEX_MASK)
-            return fail(WPT_ERR_UNSUPPORTED, "more than 2^30 - 1 slots in the device's node array");
+        const uint64_t slotCount = n;
         std::vector<uint32_t> place(size_t(n) + 1); /* depth-first index -> storage index; place[n] ends the walk */
-        place[n] = uint32_t(slotCount);
+        place[n] = n;
         uint32_t topNodes = g_topNodes;
         if (n <= topNodes) /* the whole tree is no larger than the part that would go in front: nothing to gain */
             topNodes = 0;
@@ -496,7 +486,7 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
                     next.clear();
                     for (uint32_t i : level) {
                         place[i] = cursor;
-                        cursor += slotsOf(i);
+                        cursor += 1;
                         if (desc->nodes[i].kind == WPT_NODE_INNER) {
                             next.push_back(i + 1);
                             next.push_back(desc->nodes[i].link);
@@ -514,7 +504,7 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
             for (uint32_t root : level)
                 for (uint32_t i = root; i < end[root]; i++) {
                     place[i] = cursor;
-                    cursor += slotsOf(i);
+                    cursor += 1;
                 }
             if (cursor != slotCount) {
                 wpt_scene_free(s);
@@ -523,8 +513,7 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
         }
         /* one node of padding: kernels that fetch aligned pairs of nodes read the whole last pair */
         std::vector<float4> dev(size_t(slotCount) * 2 + 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-        s->view.leafRecords = leafRecords ? 1u : 0u;
-        s->view.nodeCount = uint32_t(slotCount);
+        s->view.nodeCount = n;
         for (uint32_t i = 0; i < n; i++) {
             const wpt_bvh_node& nd = desc->nodes[i];
             const uint32_t skip = place[end[i]];
@@ -535,74 +524,108 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
             memcpy(&wd, &word, 4);
             dev[2 * size_t(place[i])] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0]);
             dev[2 * size_t(place[i]) + 1] = make_float4(nd.hi[1], nd.hi[2], sk, wd);
-            if (slotsOf(i) == 3) {
-                const wpt_tri_geom& g = desc->tri_geom[nd.link];
-                float index;
-                memcpy(&index, &nd.link, 4);
-                dev[2 * size_t(place[i]) + 2] = make_float4(g.v0[0], g.v0[1], g.v0[2], index);
-                dev[2 * size_t(place[i]) + 3] = make_float4(g.v1[0], g.v1[1], g.v1[2], 0.0f);
-                dev[2 * size_t(place[i]) + 4] = make_float4(g.v2[0], g.v2[1], g.v2[2], 0.0f);
-            }
         }
         UP(uploadArray(s, dev.data(), dev.size(), &nodes));
-#ifdef WPT_WIDE_WALK
-        {
-            /* the binary tree collapsed by one level (wpt_device.h, SceneView::wideNodes): wide nodes are made for the root and
-             * for every inner node that is an entry of a wide node, depth first */
-            std::vector<float4> wide;
-            std::vector<uint32_t> todo(1, 0u);        /* binary nodes to make a wide node for */
-            std::vector<uint32_t> wideOf(n, 0xffffffffu);
-            if (n > 0)
-                wideOf[0] = 0;
-            uint32_t made = n > 0 ? 1u : 0u;
-            for (size_t t = 0; t < todo.size(); t++) {
-                const uint32_t x = todo[t];
-                uint32_t entry[4];
-                int count = 0;
-                if (desc->nodes[x].kind == WPT_NODE_INNER) {
-                    const uint32_t child[2] = { x + 1, desc->nodes[x].link };
-                    for (int k = 0; k < 2; k++) {
-                        if (desc->nodes[child[k]].kind == WPT_NODE_INNER) {
-                            entry[count++] = child[k] + 1;
-                            entry[count++] = desc->nodes[child[k]].link;
-                        } else {
-                            entry[count++] = child[k];
-                        }
-                    }
-                } else {
-                    entry[count++] = x; /* a tree of one leaf */
+        const bool inLds = size_t(n) * 32 + size_t(desc->tri_count) * 48 <= LDS_SCENE_MAX_BYTES;
+        if ((g_walk & WPT_WALK_WIDE) && !inLds) {
+            /* The wide form (wpt_pathtrace.inc.h): the binary tree collapsed by one level.  Wide nodes are made for the root and
+             * for every inner node that is an entry of a wide node, in depth-first order (a wide node's first inner entry follows
+             * it).  The walk's argument needs finite boxes and every child's box within its parent's; its stack needs the tree's
+             * worst case to fit.  A tree that fails any of the three has no wide form and is walked as it is. */
+            bool ok = true;
+            for (uint32_t i = 0; i < n && ok; i++) {
+                const wpt_bvh_node& nd = desc->nodes[i];
+                for (int a = 0; a < 3; a++)
+                    ok = ok && std::isfinite(nd.lo[a]) && std::isfinite(nd.hi[a]);
+                if (nd.kind == WPT_NODE_INNER) {
+                    const uint32_t child[2] = { i + 1, nd.link };
+                    for (int k = 0; k < 2; k++)
+                        for (int a = 0; a < 3; a++)
+                            ok = ok && desc->nodes[child[k]].lo[a] >= nd.lo[a] && desc->nodes[child[k]].hi[a] <= nd.hi[a];
                 }
-                float q[8][4];
-                uint32_t ref[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
-                for (int r = 0; r < 8; r++)
-                    for (int k = 0; k < 4; k++)
-                        q[r][k] = 0.0f;
-                for (int k = 0; k < count; k++) {
-                    const wpt_bvh_node& nd = desc->nodes[entry[k]];
-                    for (int a = 0; a < 3; a++) {
-                        q[a][k] = nd.lo[a];
-                        q[3 + a][k] = nd.hi[a];
-                    }
-                    if (nd.kind == WPT_NODE_INNER) {
-                        wideOf[entry[k]] = made++;
-                        todo.push_back(entry[k]);
-                        ref[k] = NODE_CHILD | wideOf[entry[k]];
-                    } else if (nd.kind == WPT_NODE_TRIANGLE) {
-                        ref[k] = nd.link;
-                    } else if (nd.kind == WPT_NODE_SPHERE) {
-                        ref[k] = PRIM_SPHERE | nd.link;
-                    }
-                }
-                memcpy(q[6], ref, 16);
-                for (int r = 0; r < 8; r++)
-                    wide.push_back(make_float4(q[r][0], q[r][1], q[r][2], q[r][3]));
             }
-            if (made > NODE_INDEX_MASK)
-                return fail(WPT_ERR_UNSUPPORTED, "more than 2^30 - 1 wide nodes");
-            /* todo[] is in order of creation, which is the order of the wide indices handed out above */
-            UP(uploadArray(s, wide.data(), wide.size(), &s->view.wideNodes));
+            std::vector<float4> wide;
+            std::vector<uint32_t> made;        /* binary node of each wide node, in order of creation */
+            std::vector<uint32_t> entries;     /* 4 per wide node: binary nodes, 0xffffffff = none */
+            if (ok) {
+                std::vector<uint32_t> todo(1, 0u); /* depth first: a stack of binary nodes to make wide nodes for */
+                while (!todo.empty()) {
+                    const uint32_t x = todo.back();
+                    todo.pop_back();
+                    made.push_back(x);
+                    uint32_t entry[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+                    int count = 0;
+                    if (desc->nodes[x].kind == WPT_NODE_INNER) {
+                        const uint32_t child[2] = { x + 1, desc->nodes[x].link };
+                        for (int k = 0; k < 2; k++) {
+                            if (desc->nodes[child[k]].kind == WPT_NODE_INNER) {
+                                entry[count++] = child[k] + 1;
+                                entry[count++] = desc->nodes[child[k]].link;
+                            } else {
+                                entry[count++] = child[k];
+                            }
+                        }
+                    } else {
+                        entry[count++] = x; /* a tree of one leaf */
+                    }
+                    for (int k = 0; k < 4; k++)
+                        entries.push_back(entry[k]);
+                    for (int k = count - 1; k >= 0; k--) /* the first inner entry is made next */
+                        if (desc->nodes[entry[k]].kind == WPT_NODE_INNER && entry[k] != x)
+                            todo.push_back(entry[k]);
+                }
+                ok = made.size() <= NODE_INDEX_MASK;
+            }
+            if (ok) {
+                /* wide index of every binary node that has one; creation order is a pre-order, so a reverse pass sees children first */
+                std::vector<uint32_t> wideOf(n, 0xffffffffu);
+                for (size_t w = 0; w < made.size(); w++)
+                    wideOf[made[w]] = uint32_t(w);
+                std::vector<uint32_t> depth(made.size(), 0u); /* entries that can wait on the stack while the walk is below this wide node */
+                for (size_t w = made.size(); w-- > 0;) {
+                    int count = 0;
+                    while (count < 4 && entries[4 * w + count] != 0xffffffffu)
+                        count++;
+                    uint32_t worst = 0;
+                    for (int k = 0; k < count; k++) {
+                        const uint32_t e = entries[4 * w + k];
+                        const uint32_t below = (desc->nodes[e].kind == WPT_NODE_INNER && e != made[w]) ? depth[wideOf[e]] : 0u;
+                        worst = std::max(worst, uint32_t(count - 1 - k) + below);
+                    }
+                    depth[w] = worst;
+                }
+                ok = depth[0] <= WIDE_STACK;
+                wide.resize(made.size() * 8, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                for (size_t w = 0; w < made.size() && ok; w++) {
+                    float q[8][4];
+                    uint32_t ref[4] = { WIDE_NONE, WIDE_NONE, WIDE_NONE, WIDE_NONE };
+                    for (int r = 0; r < 8; r++)
+                        for (int k = 0; k < 4; k++)
+                            q[r][k] = 0.0f;
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t e = entries[4 * w + k];
+                        if (e == 0xffffffffu)
+                            continue;
+                        const wpt_bvh_node& nd = desc->nodes[e];
+                        for (int a = 0; a < 3; a++) {
+                            q[a][k] = nd.lo[a];
+                            q[3 + a][k] = nd.hi[a];
+                        }
+                        if (nd.kind == WPT_NODE_INNER)
+                            ref[k] = NODE_CHILD | wideOf[e];
+                        else if (nd.kind == WPT_NODE_TRIANGLE)
+                            ref[k] = nd.link;
+                        else if (nd.kind == WPT_NODE_SPHERE)
+                            ref[k] = PRIM_SPHERE | nd.link;
+                    }
+                    memcpy(q[6], ref, 16);
+                    for (int r = 0; r < 8; r++)
+                        wide[8 * w + r] = make_float4(q[r][0], q[r][1], q[r][2], q[r][3]);
+                }
+            }
+            if (ok)
+                UP(uploadArray(s, wide.data(), wide.size(), &s->view.wideNodes));
         }
-#endif
     }
     UP(uploadArray(s, reinterpret_cast<const float4*>(desc->tri_geom), size_t(desc->tri_count) * 3, &geom));
     UP(uploadArray(s, reinterpret_cast<const float4*>(desc->tri_attr), size_t(desc->tri_count) * 6, &attr));
@@ -847,10 +870,9 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     const bool count = counters_device != nullptr;
     /* The walk of a light ray towards the environment ends at its first accepted hit (wpt_pathtrace.inc.h: the answer it is
      * traced for is known there).  Counting launches walk on as the reference does, so that their counters are the
-     * reference's; measurements: WPT_COUNT_PRODUCT_WALKS makes them count what the product kernel walks,
-     * WPT_FULL_SHADOW_WALKS switches the short cut off everywhere. */
-    args.xcdBands = getenv("WPT_XCD_BANDS") ? uint32_t(atoi(getenv("WPT_XCD_BANDS"))) : 0u;
-    args.shadowWalksEnd = getenv("WPT_FULL_SHADOW_WALKS") ? 0u : (count ? (getenv("WPT_COUNT_PRODUCT_WALKS") ? 1u : 0u) : 1u);
+     * reference's; measurements (wpt_set_walk): WPT_WALK_COUNT_PRODUCT makes them count what the product kernel walks,
+     * WPT_WALK_FULL_SHADOW switches the short cut off everywhere. */
+    args.shadowWalksEnd = (g_walk & WPT_WALK_FULL_SHADOW) ? 0u : (count ? ((g_walk & WPT_WALK_COUNT_PRODUCT) ? 1u : 0u) : 1u);
     const size_t ldsBytes = size_t(scene->nodeCount) * 32 + size_t(scene->triCount) * 48;
     /* scheduler defaults from sweeps on the Cornell box (scene in LDS, short walks) and on the
      * Sponza-class scene (deep tree in HBM: traversal dominates, so long blocks may run with fewer
@@ -892,8 +914,8 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
         uint32_t launches = 0;
         const hipError_t e = wptk::renderWavefront(args, kernels, g_wfConfig, stream, &launches);
         if (e == hipSuccess) {
-            g_lastPasses = launches;
-            g_kernelName = "wf_trace + wf_shade";
+            g_lastPasses.store(launches, std::memory_order_relaxed);
+            g_kernelName.store("wf_trace + wf_shade", std::memory_order_relaxed);
             return WPT_OK;
         }
         /* The library's own choice must not fail where the single kernel would not: without the memory for the records
@@ -902,7 +924,6 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
             return fail(e == hipErrorOutOfMemory ? WPT_ERR_OUT_OF_MEMORY : WPT_ERR_HIP, std::string("wavefront render: ") + hipGetErrorString(e));
         (void)hipGetLastError();
     }
-    g_kernelName = nullptr;
     uint32_t* pool = nullptr;
     const bool pooled = !count && !(g_variant & 0x10u) && block_size < 0x80000000u && grid.x > uint32_t(scene->cuCount);
     if (pooled && hipMallocAsync(reinterpret_cast<void**>(&pool), sizeof(uint32_t), stream) != hipSuccess) {
@@ -918,14 +939,10 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     args.cost = nullptr;
     args.order = nullptr;
     args.orderCount = nullptr;
-    /* Measurements (a kept negative): the kernel whose workgroups deal their paths to their lanes anew,
-     * sorted by what they need next, at every n-th look at the lane counts (WPT_REDEAL=n; with WPT_REDEAL_IDENTITY every
-     * path stays in its lane at the full price of a deal).  Scenes in LDS, as long as the staging area fits with them into
-     * the 64 KiB a workgroup may ask for.  Read per launch: tools/redeal_cost.py changes it within a process. */
-    const char* const redealWord = getenv("WPT_REDEAL");
-    const bool redeal = redealWord != nullptr && atoi(redealWord) > 0
-            && COLD_BYTES + ldsBytes + size_t(scene->view.materialCount) * sizeof(wpt_material) + wptk::REDEAL_BYTES <= 64u * 1024u;
-    args.redealEvery = redeal ? (uint32_t(atoi(redealWord)) & 0xffffu) | (getenv("WPT_REDEAL_IDENTITY") ? 0x80000000u : 0u) : 1u;
+    /* the wide walk where the scene has that form (wpt_set_walk before the upload): product launches of the kernels that fetch
+     * the scene from HBM; counting launches and moving scenes walk the binary tree */
+    const bool wide = scene->view.wideNodes != nullptr && !count && !anim && !(basic && !rgl);
+    g_kernelName.store(wide ? "wpt_pathtrace, wide walk" : nullptr, std::memory_order_relaxed);
     auto launch = [&](const wptk::KernelArgs& a) {
         if (anim) {
             /* its own instantiation, like the measured BRDFs */
@@ -947,16 +964,17 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
             else
                 launchFullCount(a, grid, stream);
         } else if (rgl) {
-            launchFullRgl(a, grid, stream);
+            if (wide)
+                launchFullRglWide(a, grid, stream);
+            else
+                launchFullRgl(a, grid, stream);
         } else {
-            if (basic && lds && redeal)
-                g_kernelName = "wpt_pathtrace, paths re-dealt";
-            if (basic && lds && redeal)
-                launchBasicLdsRedeal(a, grid, ldsBytes + (a.materialsInLds ? size_t(scene->view.materialCount) * sizeof(wpt_material) : 0), stream);
-            else if (basic && lds)
+            if (basic && lds)
                 launchBasicLds(a, grid, ldsBytes + (a.materialsInLds ? size_t(scene->view.materialCount) * sizeof(wpt_material) : 0), stream);
             else if (basic)
                 launchBasic(a, grid, stream);
+            else if (wide)
+                launchFullWide(a, grid, stream);
             else
                 launchFull(a, grid, stream);
         }
@@ -998,7 +1016,7 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     }
     if (!passesDone)
         launch(args);
-    g_lastPasses = passesDone ? 2u : 1u;
+    g_lastPasses.store(passesDone ? 2u : 1u, std::memory_order_relaxed);
     const hipError_t launched = hipGetLastError();
     for (void* p : { static_cast<void*>(pool), static_cast<void*>(carry), static_cast<void*>(cost), static_cast<void*>(order), static_cast<void*>(work) })
         if (p)
@@ -1178,10 +1196,12 @@ wpt_status wpt_set_wavefront(uint32_t mode, uint32_t groups, uint32_t chunk, uin
     if (mode > 2u)
         return fail(WPT_ERR_INVALID_ARGUMENT, "wavefront mode must be 0, 1 or 2");
     g_wfMode = mode;
-    g_wfConfig.groups = groups;
+    g_wfConfig.groups = groups & 0xffu;
+    g_wfConfig.tracePerCu = (groups >> 8) & 0xffu; /* measurements: workgroups of the trace per compute unit */
+    g_wfConfig.shadePerKind = (groups >> 16) & 1u; /* measurements: one shade launch per kind of material */
     g_wfConfig.chunk = chunk;
     g_wfConfig.buckets = (flags & 1u) ? 0u : 1u;
-    g_wfConfig.refillIdle = (flags >> 8) & 0xffu;
+    g_wfConfig.refillIdle = (flags >> 8) & 0x3fu;
     g_wfConfig.leafBias = 0;
     /* bits 16-31: node steps a ray takes per launch of the trace before it is suspended (0 = default, 0xffff = no limit) */
     g_wfConfig.stepBudget = (flags >> 16) == 0xffffu ? 0xffffffffu : (flags >> 16);
@@ -1193,7 +1213,14 @@ wpt_status wpt_set_wavefront(uint32_t mode, uint32_t groups, uint32_t chunk, uin
 wpt_status wpt_set_top_nodes(uint32_t nodes)
 {
     g_topNodes = nodes & 0x7fffffffu;
-    g_leafRecords = (nodes & 0x80000000u) != 0; /* bit 31: the triangles' corners also behind their leaf nodes */
+    return WPT_OK;
+}
+
+wpt_status wpt_set_walk(uint32_t flags)
+{
+    if (flags & ~(WPT_WALK_WIDE | WPT_WALK_FULL_SHADOW | WPT_WALK_COUNT_PRODUCT))
+        return fail(WPT_ERR_INVALID_ARGUMENT, "unknown walk flag");
+    g_walk = flags;
     return WPT_OK;
 }
 
@@ -1311,8 +1338,9 @@ wpt_status wpt_set_scheduler_stats(unsigned long long* stats_device)
 
 const char* wpt_kernel_name(void)
 {
-    /* the kernel family of the calling thread's last render call */
-    return g_kernelName ? g_kernelName : "wpt_pathtrace";
+    /* the kernel family of the process's most recent render call */
+    const char* name = g_kernelName.load(std::memory_order_relaxed);
+    return name ? name : "wpt_pathtrace";
 }
 
 const char* wpt_device_name(int device)
@@ -1327,7 +1355,7 @@ const char* wpt_device_name(int device)
 
 uint32_t wpt_last_render_passes(void)
 {
-    return g_lastPasses;
+    return g_lastPasses.load(std::memory_order_relaxed);
 }
 
 const char* wpt_build_info(void)

@@ -462,8 +462,7 @@ struct SceneView {
     const float* envM;
     const int32_t* envMs;
     const float* envMcs;
-    uint32_t nodeCount, triCount; /* nodeCount: 32-byte slots of `nodes` (a triangle leaf takes three where leafRecords is set) */
-    uint32_t leafRecords;         /* 1: a triangle leaf's corners follow its node: nodes[2 * leaf + 2 .. + 4], the first one's w = triangle index */
+    uint32_t nodeCount, triCount;
     uint32_t hotspotCount;
     uint32_t envType, envCompat;
     int32_t envTex, envN;
@@ -474,13 +473,11 @@ struct SceneView {
     uint32_t sphereCount;
     const wpt_animation* animations; /* key frame animations of instances and camera */
     const wpt_keyframe* keyframes;
-#ifdef WPT_WIDE_WALK
-    /* Variant build (oracle/wpt_oracle.cpp::bvhTraverseWide): the binary tree collapsed by one level.
-     * 8 quadwords per wide node: lo.x, lo.y, lo.z, hi.x, hi.y, hi.z of up to four entries (the node's grandchildren, a child
-     * that is a leaf standing for itself, in the reference's order), their references (NODE_CHILD | wide node, a triangle
+    /* The binary tree collapsed by one level, or NULL where the scene has no wide form (wpt_capi.hip builds it, wpt_pathtrace.inc.h
+     * walks it).  8 quadwords per wide node: lo.x, lo.y, lo.z, hi.x, hi.y, hi.z of up to four entries (the node's grandchildren, a
+     * child that is a leaf standing for itself, in the reference's order), their references (NODE_CHILD | wide node, a triangle
      * index, PRIM_SPHERE | sphere index, 0xffffffff = no entry), one spare.  Wide node 0 is the root's. */
     const float4* wideNodes;
-#endif
 };
 
 /* ---- animations at a ray's time (wpt_anim.h) ---- */
@@ -1213,7 +1210,7 @@ template<uint32_t F> WPT_D Scatter materialScatter(const SceneView& sv, const wp
         a.x = a.y = a.z = 0.0f;
         pwo = a;
         p = 0.0f;
-        if (wwi.z > 0.0f) { /* BRDF::sample's own first test */
+        if (!(wwi.z <= 0.0f)) { /* BRDF::sample's own first test */
             wptrgl::rglIncidentCall<DeviceRglMath>(sv.rglBrdfs[m.tex[0]], sv.rglData, wwi, mc.rgl);
             mc.haveRgl = true;
             a = wptrgl::rglSampleCall<DeviceRglMath>(sv.rglBrdfs[m.tex[0]], sv.rglData, mc.rgl, uu, wwi, pwo, p);
@@ -1437,7 +1434,7 @@ template<uint32_t F> WPT_D void materialEval(const SceneView& sv, const wpt_mate
             wptrgl::V3 a;
             a.x = a.y = a.z = 0.0f;
             p = 0.0f;
-            if (wwi.z > 0.0f && wwo.z > 0.0f) {
+            if (!(wwi.z <= 0.0f || wwo.z <= 0.0f)) {
                 if (!mc.haveRgl) {
                     wptrgl::rglIncidentCall<DeviceRglMath>(b, sv.rglData, wwi, mc.rgl);
                     mc.haveRgl = true;

@@ -5,15 +5,12 @@
 
 /* three waves per SIMD (168 registers): the measured-BRDF evaluation spills heavily at 128 (Bistro-class 16-spp frame 1423 against
  * 1477 ms) */
-#ifndef WPT_RGL_OCC
-#define WPT_RGL_OCC 3
-#endif
 
 namespace wptk {
 
 void launchFullRgl(const KernelArgs& args, dim3 grid, hipStream_t stream)
 {
-    launchMaybePooled(wpt_pathtrace<FEAT_ALL | FEAT_RGL, false, false, WPT_RGL_OCC>, args, grid, COLD_BYTES, stream);
+    launchMaybePooled(wpt_pathtrace<FEAT_ALL | FEAT_RGL, false, false, 3>, args, grid, COLD_BYTES, stream);
 }
 
 }

@@ -1,0 +1,12 @@
+/* wpt_k_full_wide.hip -- instantiates wpt_pathtrace<FEAT_ALL, false, false, 4, true>: all features, the wide walk */
+#define WPT_MATH_TABLES_IN_LDS /* this unit's kernels keep the tables of expf / powf in LDS (wpt_math.h) */
+#include "wpt_pathtrace.inc.h"
+
+namespace wptk {
+
+void launchFullWide(const KernelArgs& args, dim3 grid, hipStream_t stream)
+{
+    launchMaybePooled(wpt_pathtrace<FEAT_ALL, false, false, 4, true>, args, grid, COLD_BYTES, stream);
+}
+
+}

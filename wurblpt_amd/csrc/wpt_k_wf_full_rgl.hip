@@ -7,5 +7,5 @@
 #include "wpt_wavefront.inc.h"
 
 namespace wptk {
-WPT_WF_LAUNCHERS(wfFullRgl, FEAT_ALL | FEAT_RGL, true, false)
+WPT_WF_LAUNCHERS(wfFullRgl, FEAT_ALL | FEAT_RGL, true)
 }

@@ -82,8 +82,6 @@ struct KernelArgs {
     uint32_t waitBelow;    /* scheduler: a kind of material with fewer lanes than this in a long round stands back once (0 = never) */
     uint32_t fuse;         /* scheduler: 1 = one long round serves SHADE, NEE-END and NEW lanes together */
     uint32_t shadowWalksEnd; /* 1: the walk of a light ray towards the environment ends at its first accepted hit (not in counting launches) */
-    uint32_t xcdBands;     /* measurements: 1 = the workgroups of an XCD share a contiguous eighth of the launch's pixels */
-    uint32_t redealEvery;  /* re-dealing kernel: the workgroup deals its paths anew at every n-th look at the lane counts */
     float* frame;
     /* Pixel pool (or NULL): lanes whose pixel is finished take the next lane index of the launch from this counter, which
      * starts at the number of lanes launched.  A launch then is as many workgroups as the GPU holds at once, and a wave
@@ -131,92 +129,44 @@ WPT_D bool lanePixel(const KernelArgs& args, uint32_t gid, uint32_t& pixel)
     return inBlock;
 }
 
-/* A node's two quadwords for the lanes that `need` them, fetched by PAIRS of lanes: in a first instruction lanes 2i and
- * 2i + 1 load the two halves of lane 2i's node, in a second those of lane 2i + 1's, and the halves change lanes by DPP.
- * Every instruction then asks for a cache line once, from two neighbouring lanes.  With one lane loading both halves in
- * two instructions the line is asked for twice, and with many waves on a compute unit the second request no longer
- * finds it in L1: measured (tools/micro/node_fetch.hip, 17 MB of nodes, four waves per SIMD) 118 G fetches per second
- * against 262 G for walks that do nothing else.  Called by all lanes of the wave together (the exchange reads the
- * neighbour's registers).  The path tracer's own walks are not bound there: in the single kernel the pairs cut the L1
- * accesses of the Sponza-class frame by 40 %, left the L2 requests as they were (the second half found its line in L1
- * all along) and added half as many vector instructions again, 255 -> 310 ms (gpurun_out/pmc_wf2_summary.txt); it is
- * an option of the wavefront trace only. */
-WPT_D void fetchNodePaired(const float4* nodes, uint32_t node, bool need, float4& pn0, float4& pn1)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int SWAP = 0xb1; /* quad_perm [1, 0, 3, 2]: each lane reads its pair's other lane */
-    const uint32_t odd = threadIdx.x & 1u;
-    const uint32_t mine = need ? node : 0xffffffffu;
-    const uint32_t theirs = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, SWAP, 0xf, 0xf, false);
-    const uint32_t nodeA = odd ? theirs : mine, nodeB = odd ? mine : theirs; /* the even lane's node, the odd lane's */
-    float4 qa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), qb = qa;
-    if (nodeA != 0xffffffffu)
-        qa = nodes[2 * (size_t)nodeA + odd];
-    if (nodeB != 0xffffffffu)
-        qb = nodes[2 * (size_t)nodeB + odd];
-    /* the even lane holds its own first half (qa) and sends the odd lane's first half (qb); the odd lane holds its own
-     * second half (qb) and sends the even lane's second half (qa) */
-    const float4 send = odd ? qa : qb;
-    float4 got;
-    got.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.x), SWAP, 0xf, 0xf, false));
-    got.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.y), SWAP, 0xf, 0xf, false));
-    got.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.z), SWAP, 0xf, 0xf, false));
-    got.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.w), SWAP, 0xf, 0xf, false));
-    if (need) {
-        pn0 = odd ? got : qa;
-        pn1 = odd ? qb : got;
-    }
-#else
-    if (need) {
-        pn0 = nodes[2 * (size_t)node];
-        pn1 = nodes[2 * (size_t)node + 1];
-    }
-#endif
-}
-
 /* lane states, in scheduling priority order for ties */
 enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5, S_START = 6 /* within a long round: has a ray to start */ };
 
-/* REDEAL (scene in LDS only): at every look at the lane counts the workgroup deals its 256 paths to its lanes anew, sorted by
- * what they need next -- traversal, shading by kind of material, the end of a light ray, a new sample, nothing.  A path's cold
- * words stay where they are in LDS (ps.base is the path's slot, not the lane's); its 22 hot words change lanes through a
- * staging area of three quadwords per lane, in two rounds.  What a path computes does not depend on the lane it sits in. */
-constexpr uint32_t REDEAL_CLASSES = 8;
-constexpr uint32_t REDEAL_STAGE_QUADS = 3;
-constexpr uint32_t REDEAL_BYTES = (WG / 64) * REDEAL_CLASSES * 4 + REDEAL_STAGE_QUADS * WG * 16;
+/* ---- the wide walk (WIDE kernels; scenes fetched from HBM) ----
+ * The binary tree collapsed by one level at upload (wpt_capi.hip, SceneView::wideNodes): a wide node holds the boxes of a
+ * node's up to four grandchildren (a child that is a leaf stands for itself) in the order BVH::hit comes to them
+ * (bvh.hpp:277-311), and one step tests all four from one 128-byte line.  A child whose box the ray passes through under the
+ * bound of that moment waits for its turn with its entry distance -- the next one in registers, the others on a small stack --
+ * and is admitted at its turn if that distance is still within the bound, which is AABB::mayHit (aabb.hpp:70-86) under the
+ * bound of its turn as long as (a) no slab distance is NaN and (b) the bound has not grown in between.  The inner nodes
+ * that disappear decide nothing of their own: a child's box lies within its parent's (checked at upload) and the slab
+ * arithmetic is monotone, so a child that passes implies the parent the reference tested before it.  Where (a) or (b) fails
+ * the lane walks the binary tree instead, which IS the reference's walk:
+ *   (a) a slab distance is NaN only for 0 * inf or inf - inf: a ray with a zero, infinite or NaN direction component, or an
+ *       origin that is not finite (the boxes are finite: checked at upload), takes the binary walk from its start;
+ *   (b) a hit is accepted by one comparison and its distance stored by another (hitable_triangle.hpp:283-296), so the bound
+ *       can GROW by an ulp at a hit (one ray in 200 000 on the Sponza-class scene, tests/test_wide_walk.py); a lane that
+ *       sees that starts its ray again from the root in the binary walk.
+ * Checked on the CPU leaf test for leaf test against BVH::hit (oracle/wpt_oracle.cpp::bvhTraverseWide) and on the GPU bit for
+ * bit against the oracle.  The stack cannot overflow: wpt_scene_upload offers the wide form only for trees whose worst case
+ * fits WIDE_STACK entries. */
+constexpr uint32_t WIDE_STACK = 64;          /* pending children per lane (8 bytes each, scratch memory) */
+constexpr uint32_t WIDE_NONE = 0xffffffffu;  /* no child (also: an empty entry of a wide node) */
+constexpr int RAY_WALK_BINARY = 0x40;        /* in RayAux::k: this ray walks the binary tree */
 
-template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, bool REDEAL = false>
+template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, bool WIDE = false>
 __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
 {
-    static_assert(!REDEAL || (LDSSCENE && !COUNT && !(F & (FEAT_ANIM | FEAT_SPHERES))), "re-dealing: the plain kernel with the scene in LDS");
+    static_assert(!WIDE || (!LDSSCENE && !COUNT), "the wide walk: product kernels that fetch the scene from HBM (counting launches walk like the reference)");
     /* node prefetch: for scenes in HBM (Sponza-class frame 3 % faster); not from LDS, where the fetch is short and the
-     * registers that hold the node ahead lengthen every step (Cornell 4 % slower in round 2; again with round 3's kernel,
-     * 117 registers either way: 966 against 1017 Msamples/s, -DWPT_LDS_PREFETCH=1) */
-#ifndef WPT_LDS_PREFETCH
-#define WPT_LDS_PREFETCH 0 /* experiments: 1 = the kernel with the scene in LDS requests its next node ahead as well */
-#endif
-#ifdef WPT_WIDE_WALK_HERE
-    /* Variant build: this unit's rendering kernel walks the tree collapsed by one level (SceneView::wideNodes; the walk is
-     * oracle/wpt_oracle.cpp::bvhTraverseWide, checked there against BVH::hit).  A prototype for measuring: lanes with a NaN
-     * slab distance are not given the reference's own tests yet. */
-    constexpr bool WIDE = !LDSSCENE && !COUNT;
-#else
-    constexpr bool WIDE = false;
-#endif
-    constexpr bool PREFETCH = (!LDSSCENE || WPT_LDS_PREFETCH) && !WIDE;
-    /* leaf records (wpt_capi.hip): the walk reads a triangle's corners behind its leaf node; not where the corners are
-     * moved by an animation first (those kernels need the instance and flag words of the triangle array anyway) */
-    constexpr bool LEAFREC = !LDSSCENE && !(F & FEAT_ANIM);
+     * registers that hold the node ahead lengthen every step (Cornell 4 % slower) */
+    constexpr bool PREFETCH = !LDSSCENE && !WIDE;
     /* Node steps per look at the lane counts.  The look itself (two ballots, their counts, the leave and leaf decisions:
      * some twenty scalar instructions and two branches in every lane's way) costs a wave as much issue time as half a
      * node step.  From LDS a step is short, and taking up to three in a row before looking again gave 852 against 799
      * Msamples/s on the Cornell frame (2: 839, 4: 841, 6: 836, 8: 791: lanes that reach a leaf wait out the rest); from
-     * HBM the steps are memory round trips and nothing is gained (Sponza-class 118.7 - 121.0 against 120.4, 10 M
-     * triangles 53 - 55 against 56.5 for 2 - 4 steps). */
-#ifndef WPT_LDS_STEPS
-#define WPT_LDS_STEPS 3 /* experiments build other values into a second library (Makefile: EXTRA) */
-#endif
-    constexpr int STEPS = LDSSCENE ? WPT_LDS_STEPS : 1;
+     * HBM the steps are memory round trips and nothing is gained. */
+    constexpr int STEPS = LDSSCENE ? 3 : 1;
     /* [ math tables ][ cold path words: SLOT_COUNT x WG float4 ][ LDSSCENE: nodes, triangle positions ] */
     extern __shared__ float4 lds[];
     float4* const ldsCold = lds + TABLE_BYTES / 16;
@@ -232,11 +182,9 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     const wpt_params& par = args.par;
     const uint32_t nodeCount = sv.nodeCount;
 
-    uint32_t ldsSceneQuads = 0; /* REDEAL: its words lie behind the scene */
     if (LDSSCENE) {
         /* nodes (2 x float4 each) followed by the triangle positions (3 x float4 each) */
         const uint32_t n4 = 2 * nodeCount, t4 = 3 * sv.triCount;
-        ldsSceneQuads = n4 + t4 + (args.materialsInLds ? sv.materialCount * (uint32_t)(sizeof(wpt_material) / 16) : 0u);
         for (uint32_t i = threadIdx.x; i < n4; i += WG)
             ldsScene[i] = sv.nodes[i];
         for (uint32_t i = threadIdx.x; i < t4; i += WG)
@@ -251,30 +199,12 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         }
     }
     __syncthreads();
-#ifdef WPT_TOP_IN_LDS_HERE /* defined by the one translation unit whose launcher adds the LDS (wpt_k_full.hip) */
-    /* Variant build: the first WPT_TOP_IN_LDS nodes of the array -- the tree's upper levels, stored level
-     * by level in front (wpt_set_top_nodes) -- are walked from LDS by the kernels that fetch the scene from HBM, so that the
-     * vector L1 serves the levels below them.  The launchers add WPT_TOP_IN_LDS * 32 bytes of LDS. */
-    const uint32_t topQuads = LDSSCENE ? 0u : 2u * (nodeCount < (uint32_t)WPT_TOP_IN_LDS_HERE ? nodeCount : (uint32_t)WPT_TOP_IN_LDS_HERE);
-    if (!LDSSCENE) {
-        for (uint32_t i = threadIdx.x; i < topQuads; i += WG)
-            ldsScene[i] = sv.nodes[i];
-        __syncthreads();
-    }
-    auto node4 = [&](uint32_t i) -> float4 {
-        if constexpr (LDSSCENE)
-            return ldsScene[i];
-        else
-            return i < topQuads ? ldsScene[i] : sv.nodes[i];
-    };
-#else
     auto node4 = [&](uint32_t i) -> float4 {
         if constexpr (LDSSCENE)
             return ldsScene[i];
         else
             return sv.nodes[i];
     };
-#endif
     auto tri4 = [&](uint32_t i) -> float4 {
         if constexpr (LDSSCENE)
             return ldsScene[2 * nodeCount + i];
@@ -319,11 +249,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             args.cost[pixel] = (uint32_t)clock64();
         return have;
     };
-    /* Workgroups b, b + 8, b + 16, ... share an XCD and its L2 (round-robin placement; observed, not promised).  With
-     * xcdBands they render one contiguous eighth of the launch's pixels between them, so that an L2 holds the nodes behind one
-     * part of the picture instead of a share of everything (measurements; the launch must be a multiple of eight workgroups). */
-    const uint32_t logicalBlock = (args.xcdBands && (gridDim.x & 7u) == 0) ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const bool inBlock = startPixel(logicalBlock * WG + threadIdx.x);
+    const bool inBlock = startPixel(blockIdx.x * WG + threadIdx.x);
     LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
     /* wave-level scheduler statistics (COUNT builds): rounds and lane counts per state */
     unsigned long long sched[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -332,17 +258,11 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     RayAux aux = rayAux(ps.d);
     uint32_t node = 0, leafPrim = 0;
     float amax = k_maxval;
-#ifdef WPT_WIDE_WALK_HERE
-    /* children that wait for their turn: reference and entry distance (bits), the walk's own stack in scratch memory */
-    constexpr uint32_t WIDE_PENDING = 40;
-    constexpr uint32_t WIDE_NONE = 0xfffffffeu;
-    uint2 pend[WIDE_PENDING];
-    uint32_t sp = 0;
-    /* the child whose turn is next waits in registers, so that a step starts with its node's fetch and not with a load from
-     * the stack (the first form popped from scratch first: two dependent round trips per step, 109 against 144 Msamples/s) */
-    uint32_t curRef = WIDE_NONE;
+    /* WIDE: the child whose turn is next (reference, entry distance) waits in registers, so that a step starts with its node's
+     * fetch and not with a load from the stack; the others wait on the stack in the reference's order */
+    uint2 pend[WIDE ? WIDE_STACK : 1];
+    uint32_t sp = 0, curRef = WIDE_NONE;
     float curEntry = 0.0f;
-#endif
     Candidate best;
     best.prim = NO_HIT;
     best.a = best.invDet = best.U = best.V = best.W = 0.0f;
@@ -354,29 +274,30 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         amax = k_maxval;
         best.prim = NO_HIT;
         state = S_NODE;
-#ifdef WPT_WIDE_WALK_HERE
-        if (WIDE) { /* the root's wide node, admitted under any bound (the root's own box decides nothing its children do not) */
+        if (WIDE) {
+            /* slab distances are numbers for every finite box iff the reciprocals are finite and not zero and the origin is
+             * finite; other rays walk the binary tree */
+            const bool numbers = __builtin_fabsf(aux.inv.x) < __builtin_inff() && __builtin_fabsf(aux.inv.y) < __builtin_inff()
+                    && __builtin_fabsf(aux.inv.z) < __builtin_inff() && aux.inv.x != 0.0f && aux.inv.y != 0.0f && aux.inv.z != 0.0f
+                    && __builtin_fabsf(ps.o.x) < __builtin_inff() && __builtin_fabsf(ps.o.y) < __builtin_inff() && __builtin_fabsf(ps.o.z) < __builtin_inff();
+            if (!numbers)
+                aux.k |= RAY_WALK_BINARY;
+            /* the root's wide node, admitted under any bound (the root's own box decides nothing its children do not) */
             curRef = NODE_CHILD | 0u;
             curEntry = 0.0f;
             sp = 0;
         }
-#endif
         if (COUNT)
             lc.rays++;
     };
     /* state after the walk has left the tree */
     auto endOfRayState = [&]() { return ps.rayKind == RAY_PATH ? (int)S_SHADE : (int)S_NEEEND; };
-    /* what a block of wpt_blocks.h asks for next */
     /* what a block of wpt_blocks.h asks for next.  Rays start together at the end of the long round: the reciprocals and
      * the shear of a direction (three divisions and the axis choice, some sixty instructions) then run once for the
      * SHADE, NEE-END and NEW lanes of the round, not once behind each of their blocks. */
     auto afterBlock = [&](int next) {
         if (next == NEXT_TRACE)
-#ifdef WPT_SEPARATE_STARTS /* experiments: every block starts its own rays */
-            beginRay();
-#else
             state = S_START;
-#endif
         else if (next != NEXT_WAIT) /* a waiting lane keeps its state and its hit */
             state = next == NEXT_NEW ? (int)S_NEW : (int)S_DONE;
     };
@@ -403,115 +324,18 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         }
     };
 
-    uint32_t looks = 0;
     for (;;) {
         /* ---- the wave's scheduler ----
          * Traversal (NODE steps and LEAF tests) is one block with its own inner policy; the long
          * blocks (SHADE, NEE-END, NEW) run when they are well filled, or when no traversal work
          * is left in the wave.  Waiting lanes lose nothing but time: every lane still executes
          * its own operations in order. */
-        if (REDEAL && (looks++ % (args.redealEvery & 0xffffu)) == 0) { /* the waves of a workgroup count their looks alike */
-            uint32_t* const ldsCounts = reinterpret_cast<uint32_t*>(ldsScene + ldsSceneQuads); /* [wave][class] */
-            float4* const ldsStage = ldsScene + ldsSceneQuads + (WG / 64) * REDEAL_CLASSES / 4;  /* [quad][lane] */
-            const uint32_t wave = threadIdx.x >> 6;
-            const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            /* what the path needs next: 0 traversal, 1 - 4 shading (no hit or a light, Lambertian, GGX, the rest), 5 the end
-             * of a light ray, 6 a new sample, 7 nothing */
-            uint32_t cls = 7;
-            if (state == S_NODE || state == S_LEAF) {
-                cls = 0;
-            } else if (state == S_SHADE) {
-                cls = 1;
-                if (best.prim != NO_HIT) {
-                    const wpt_material* m = sv.materials + __float_as_uint(tri4(3 * best.prim + 1).w);
-                    for (int guard = 0; guard < 4 && m->type == WPT_MAT_TWOSIDED; guard++)
-                        m = sv.materials + (best.invDet < 0.0f ? m->tex[1] : m->tex[0]);
-                    const uint32_t type = m->type;
-                    cls = type == WPT_MAT_LIGHT_DIFFUSE ? 1u : type == WPT_MAT_LAMBERTIAN ? 2u : type == WPT_MAT_GGX ? 3u : 4u;
-                }
-            } else if (state == S_NEEEND) {
-                cls = 5;
-            } else if (state == S_NEW) {
-                cls = 6;
-            }
-            uint32_t inWave[REDEAL_CLASSES];
-            uint32_t rank = 0;
-#pragma unroll
-            for (uint32_t c = 0; c < REDEAL_CLASSES; c++) {
-                const unsigned long long of = __ballot(cls == c);
-                inWave[c] = (uint32_t)__popcll(of);
-                if (cls == c)
-                    rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(of >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)of, 0u));
-            }
-            if (lane == 0) {
-                uint4* const mine = reinterpret_cast<uint4*>(ldsCounts + wave * REDEAL_CLASSES);
-                mine[0] = make_uint4(inWave[0], inWave[1], inWave[2], inWave[3]);
-                mine[1] = make_uint4(inWave[4], inWave[5], inWave[6], inWave[7]);
-            }
-            __syncthreads();
-            /* place of the path in the workgroup's order: classes one after the other, within a class wave by wave */
-            uint32_t dest = 0, before = 0, idle = 0;
-#pragma unroll
-            for (uint32_t c = 0; c < REDEAL_CLASSES; c++) {
-                uint32_t mineAt = before;
-#pragma unroll
-                for (uint32_t w = 0; w < WG / 64; w++) {
-                    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)ldsCounts[w * REDEAL_CLASSES + c]);
-                    if (w < wave)
-                        mineAt += n;
-                    before += n;
-                    if (c == REDEAL_CLASSES - 1)
-                        idle += n;
-                }
-                if (cls == c)
-                    dest = mineAt + rank;
-            }
-            if (idle == WG)
-                break; /* the whole workgroup at once: nothing left for any of its paths */
-            if (args.redealEvery & 0x80000000u)
-                dest = threadIdx.x; /* measurements: every path stays where it is, at the full price of a deal */
-            const uint32_t path = (uint32_t)(ps.base - ldsCold);
-            ldsStage[dest] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-            ldsStage[WG + dest] = make_float4(ps.d.y, ps.d.z, aux.inv.x, aux.inv.y);
-            ldsStage[2 * WG + dest] = make_float4(aux.inv.z, __int_as_float(aux.k), aux.Sx, aux.Sy);
-            __syncthreads();
-            {
-                const float4 q0 = ldsStage[threadIdx.x], q1 = ldsStage[WG + threadIdx.x], q2 = ldsStage[2 * WG + threadIdx.x];
-                ps.o = mk3(q0.x, q0.y, q0.z);
-                ps.d = mk3(q0.w, q1.x, q1.y);
-                aux.inv = mk3(q1.z, q1.w, q2.x);
-                aux.k = __float_as_int(q2.y);
-                aux.Sx = q2.z;
-                aux.Sy = q2.w;
-            }
-            __syncthreads();
-            ldsStage[dest] = make_float4(__uint_as_float(node), __uint_as_float(leafPrim), amax, __uint_as_float(best.prim));
-            ldsStage[WG + dest] = make_float4(best.a, best.invDet, best.U, best.V);
-            ldsStage[2 * WG + dest] = make_float4(best.W, __uint_as_float((uint32_t)state | ((uint32_t)ps.rayKind << 4) | (path << 8)), 0.0f, 0.0f);
-            __syncthreads();
-            {
-                const float4 q0 = ldsStage[threadIdx.x], q1 = ldsStage[WG + threadIdx.x], q2 = ldsStage[2 * WG + threadIdx.x];
-                node = __float_as_uint(q0.x);
-                leafPrim = __float_as_uint(q0.y);
-                amax = q0.z;
-                best.prim = __float_as_uint(q0.w);
-                best.a = q1.x;
-                best.invDet = q1.y;
-                best.U = q1.z;
-                best.V = q1.w;
-                best.W = q2.x;
-                const uint32_t word = __float_as_uint(q2.y);
-                state = (int)(word & 15u);
-                ps.rayKind = (int)((word >> 4) & 15u);
-                ps.base = ldsCold + (word >> 8);
-            }
-        }
         const int cTrav = __popcll(__ballot(state == S_NODE || state == S_LEAF));
         const int cShade = __popcll(__ballot(state == S_SHADE));
         const int cNee = __popcll(__ballot(state == S_NEEEND));
         const int cNew = __popcll(__ballot(state == S_NEW));
-        if (!REDEAL && (cTrav | cShade | cNee | cNew) == 0)
-            break; /* re-dealing: a wave without work stays for the workgroup's barriers, and its idle lanes for the pool */
+        if ((cTrav | cShade | cNee | cNew) == 0)
+            break;
         int pick;
         const bool fused = args.fuse != 0;
         {
@@ -549,6 +373,28 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             /* the node a lane will test next is known one iteration ahead: its two quadwords are requested at the end
              * of the iteration before, so that the fetch runs behind the loop's ballots and branches */
             float4 pn0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pn1 = pn0;
+            /* AABB::mayHit + the stackless form of BVH::hit's walk: one node step of the lanes in state NODE (WIDE: of those among
+             * them that walk the binary tree) */
+                auto binaryStep = [&]() {
+                if (COUNT)
+                    lc.nodes++;
+                const float4 n0 = PREFETCH ? pn0 : node4(2 * node), n1 = PREFETCH ? pn1 : node4(2 * node + 1);
+                const uint32_t skip = __float_as_uint(n1.z);
+                const uint32_t word = __float_as_uint(n1.w);
+                const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.o, aux.inv, par.min_hit_distance, amax);
+                /* select form of: hit & inner -> first child; hit & leaf -> test it, then skip; else -> skip */
+                const bool inner = word >= NODE_CHILD;
+                const bool toLeaf = hit && !inner;
+                leafPrim = toLeaf ? word : leafPrim;
+                node = (hit && inner) ? (word & NODE_INDEX_MASK) : skip;
+                state = toLeaf ? (int)S_LEAF : (int)S_NODE;
+                if (!toLeaf && node >= nodeCount)
+                    state = endOfRayState();
+                if (PREFETCH && state == S_NODE) {
+                    pn0 = node4(2 * node);
+                    pn1 = node4(2 * node + 1);
+                }
+            };
             if (PREFETCH && state == S_NODE) {
                 pn0 = node4(2 * node);
                 pn1 = node4(2 * node + 1);
@@ -566,8 +412,8 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         sched[4] += nLeaf;
                     }
                     if (state == S_LEAF) {
-                        /* HitableTriangle::hit, candidate part (hitable_triangle.hpp:189-271); `node` already is the
-                         * node to go on with (a leaf's subtree is the leaf itself) */
+                        /* HitableTriangle::hit, candidate part (hitable_triangle.hpp:189-271); the walk already knows where
+                         * it goes on (a leaf's subtree is the leaf itself) */
                         if (COUNT)
                             lc.leaves++;
                         Candidate c;
@@ -577,19 +423,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                             c.invDet = c.U = c.V = c.W = 0.0f;
                             accepted = sphereTest(sphereNow<F>(sv, ps, sv.spheres[leafPrim & ~PRIM_SPHERE]), ps.o, ps.d, par.min_hit_distance, amax, c.a);
                         } else {
-                            float4 g0, g1, g2;
-                            if (LEAFREC && sv.leafRecords) {
-                                /* the corners lie behind the leaf's node; leafPrim is the leaf's slot until the test is through */
-                                const float4* at = sv.nodes + 2 * (size_t)leafPrim + 2;
-                                g0 = at[0];
-                                g1 = at[1];
-                                g2 = at[2];
-                                leafPrim = __float_as_uint(g0.w);
-                            } else {
-                                g0 = tri4(3 * leafPrim);
-                                g1 = tri4(3 * leafPrim + 1);
-                                g2 = tri4(3 * leafPrim + 2);
-                            }
+                            const float4 g0 = tri4(3 * leafPrim), g1 = tri4(3 * leafPrim + 1), g2 = tri4(3 * leafPrim + 2);
                             f3 v0 = mk3(g0.x, g0.y, g0.z), v1 = mk3(g1.x, g1.y, g1.z), v2 = mk3(g2.x, g2.y, g2.z);
                             if ((F & FEAT_ANIM) && (__float_as_uint(g2.w) & WPT_TRI_ANIMATE)) {
                                 /* the instance moves: its corners at the ray's time (hitable_triangle.hpp:209-218) */
@@ -600,23 +434,32 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                             }
                             accepted = triangleTest(v0, v1, v2, ps.o, aux, par.min_hit_distance, amax, c);
                         }
+                        /* WIDE: a hit whose stored distance lies beyond the bound it was accepted under (the two are separate
+                         * comparisons in the reference) makes the bound grow: children dropped under the smaller bound may be
+                         * due after all, so this ray starts again from the root in the binary walk */
+                        const bool grown = WIDE && accepted && !(aux.k & RAY_WALK_BINARY) && !(c.a <= amax);
                         if (accepted) {
                             c.prim = leafPrim;
                             best = c;
                             amax = c.a;
                         }
-#ifdef WPT_WIDE_WALK_HERE
-                        if (WIDE)
+                        if (WIDE && !(aux.k & RAY_WALK_BINARY))
                             state = curRef == WIDE_NONE ? endOfRayState() : (int)S_NODE;
                         else
-#endif
-                        state = node >= nodeCount ? endOfRayState() : (int)S_NODE;
+                            state = node >= nodeCount ? endOfRayState() : (int)S_NODE;
                         /* A light ray towards the environment asks one thing: is anything in the way (blockNeeEnd,
                          * wurblpt.hpp:240-250).  Up to a walk's first accepted hit the bound is the ray's own, so every box
                          * and leaf decision is the reference's, and the answer is known there: the walk ends.  (Counting
                          * launches are given shadowWalksEnd = 0 and walk on, as the reference does: their numbers are its numbers.) */
-                        if ((F & FEAT_ENVMAP) && args.shadowWalksEnd && accepted && ps.rayKind == RAY_NEE_ENV)
+                        if ((F & FEAT_ENVMAP) && args.shadowWalksEnd && accepted && ps.rayKind == RAY_NEE_ENV) {
                             state = S_NEEEND;
+                        } else if (grown) {
+                            aux.k |= RAY_WALK_BINARY;
+                            node = 0;
+                            amax = k_maxval;
+                            best.prim = NO_HIT;
+                            state = S_NODE;
+                        }
                         if (PREFETCH && state == S_NODE) {
                             pn0 = node4(2 * node);
                             pn1 = node4(2 * node + 1);
@@ -627,81 +470,65 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         sched[1]++;
                         sched[2] += nNode;
                     }
-#ifdef WPT_WIDE_WALK_HERE
-                    if (WIDE && state == S_NODE) {
-                        /* The child whose turn it is (registers): admitted if its entry distance is within the bound of this
-                         * moment (the reference's test at its turn); a leaf goes to its test, an inner node's four entries are
-                         * tested WITHOUT the bound, the first the ray passes through is next, the others wait on the stack in
-                         * the reference's order.  The stack's top is requested before the node, so that it is there when no
-                         * entry of this step is next. */
-                        const uint32_t ref = curRef;
-                        const bool admitted = curEntry <= amax;
-                        uint2 top = make_uint2(WIDE_NONE, 0u);
-                        if (sp > 0)
-                            top = pend[sp - 1];
-                        curRef = WIDE_NONE;
-                        if (admitted && ref < NODE_CHILD) {
-                            leafPrim = ref;
-                            state = S_LEAF;
-                        } else if (admitted) {
-                            const float4* w = sv.wideNodes + 8 * (size_t)(ref & NODE_INDEX_MASK);
-                            const float4 lx = w[0], ly = w[1], lz = w[2], hx = w[3], hy = w[4], hz = w[5], rf = w[6];
-                            const float amin = par.min_hit_distance;
-                            /* entries 3, 2, 1, 0: the last one that passes (the first in the reference's order) stays in
-                             * registers, the one it displaces goes to the stack */
-                            auto entryOf = [&](float lox, float loy, float loz, float hix, float hiy, float hiz, uint32_t r) {
-                                const float t0x = (lox - ps.o.x) * aux.inv.x, t0y = (loy - ps.o.y) * aux.inv.y, t0z = (loz - ps.o.z) * aux.inv.z;
-                                const float t1x = (hix - ps.o.x) * aux.inv.x, t1y = (hiy - ps.o.y) * aux.inv.y, t1z = (hiz - ps.o.z) * aux.inv.z;
-                                const float near = __builtin_fmaxf(__builtin_fmaxf(amin, __builtin_fminf(t0x, t1x)),
-                                        __builtin_fmaxf(__builtin_fminf(t0y, t1y), __builtin_fminf(t0z, t1z)));
-                                const float far = __builtin_fminf(__builtin_fminf(k_maxval, __builtin_fmaxf(t0x, t1x)),
-                                        __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
-                                if (r != 0xffffffffu && near <= far) {
-                                    if (curRef != WIDE_NONE && sp < WIDE_PENDING)
-                                        pend[sp++] = make_uint2(curRef, __float_as_uint(curEntry));
-                                    curRef = r;
-                                    curEntry = near;
-                                }
-                            };
-                            entryOf(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, __float_as_uint(rf.w));
-                            entryOf(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, __float_as_uint(rf.z));
-                            entryOf(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, __float_as_uint(rf.y));
-                            entryOf(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, __float_as_uint(rf.x));
+                    if constexpr (WIDE) {
+                        if (state == S_NODE && !(aux.k & RAY_WALK_BINARY)) {
+                            /* The child whose turn it is: admitted if its entry distance is within the bound of this moment
+                             * (the reference's test at its turn); a leaf goes to its test, an inner node's four entries are
+                             * tested under the bound, the first the ray passes through is next, the others wait on the stack in
+                             * the reference's order.  The stack's top is requested before the node, so that it is there when no
+                             * entry of this step is next. */
+                            const uint32_t ref = curRef;
+                            const bool admitted = curEntry <= amax;
+                            uint2 top = make_uint2(WIDE_NONE, 0u);
+                            if (sp > 0)
+                                top = pend[sp - 1];
+                            curRef = WIDE_NONE;
+                            if (admitted && ref < NODE_CHILD) {
+                                leafPrim = ref;
+                                state = S_LEAF;
+                            } else if (admitted) {
+                                const float4* w = sv.wideNodes + 8 * (size_t)(ref & NODE_INDEX_MASK);
+                                const float4 lx = w[0], ly = w[1], lz = w[2], hx = w[3], hy = w[4], hz = w[5], rf = w[6];
+                                const float amin = par.min_hit_distance;
+                                /* entries 3, 2, 1, 0: the last one that passes (the first in the reference's order) stays in
+                                 * registers, the one it displaces goes to the stack */
+                                auto entryOf = [&](float lox, float loy, float loz, float hix, float hiy, float hiz, uint32_t r) {
+                                    const float t0x = (lox - ps.o.x) * aux.inv.x, t0y = (loy - ps.o.y) * aux.inv.y, t0z = (loz - ps.o.z) * aux.inv.z;
+                                    const float t1x = (hix - ps.o.x) * aux.inv.x, t1y = (hiy - ps.o.y) * aux.inv.y, t1z = (hiz - ps.o.z) * aux.inv.z;
+                                    const float near = __builtin_fmaxf(__builtin_fmaxf(amin, __builtin_fminf(t0x, t1x)),
+                                            __builtin_fmaxf(__builtin_fminf(t0y, t1y), __builtin_fminf(t0z, t1z)));
+                                    const float far = __builtin_fminf(__builtin_fminf(amax, __builtin_fmaxf(t0x, t1x)),
+                                            __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
+                                    if (r != WIDE_NONE && near <= far) {
+                                        if (curRef != WIDE_NONE)
+                                            pend[sp++] = make_uint2(curRef, __float_as_uint(curEntry));
+                                        curRef = r;
+                                        curEntry = near;
+                                    }
+                                };
+                                entryOf(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, __float_as_uint(rf.w));
+                                entryOf(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, __float_as_uint(rf.z));
+                                entryOf(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, __float_as_uint(rf.y));
+                                entryOf(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, __float_as_uint(rf.x));
+                            }
+                            if (curRef == WIDE_NONE && top.x != WIDE_NONE) { /* nothing of this step is next: the stack's top is */
+                                curRef = top.x;
+                                curEntry = __uint_as_float(top.y);
+                                sp--;
+                            }
+                            if (state == S_NODE && curRef == WIDE_NONE)
+                                state = endOfRayState();
                         }
-                        if (curRef == WIDE_NONE && top.x != WIDE_NONE) { /* nothing of this step is next: the stack's top is */
-                            curRef = top.x;
-                            curEntry = __uint_as_float(top.y);
-                            sp--;
+                        /* the few rays that walk the binary tree (a NaN slab distance is possible, or the bound has grown) */
+                        if (__ballot(state == S_NODE && (aux.k & RAY_WALK_BINARY)) != 0) {
+                            if (state == S_NODE && (aux.k & RAY_WALK_BINARY))
+                                binaryStep();
                         }
-                        if (state == S_NODE && curRef == WIDE_NONE)
-                            state = endOfRayState();
-                    }
-                    if (!WIDE)
-#endif
+                    } else {
 #pragma unroll
-                    for (int step = 0; step < STEPS; step++)
-                    if (state == S_NODE) {
-                        /* AABB::mayHit + the stackless form of BVH::hit's walk */
-                        if (COUNT)
-                            lc.nodes++;
-                        const float4 n0 = PREFETCH ? pn0 : node4(2 * node), n1 = PREFETCH ? pn1 : node4(2 * node + 1);
-                        const uint32_t skip = __float_as_uint(n1.z);
-                        const uint32_t word = __float_as_uint(n1.w);
-                        const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.o, aux.inv, par.min_hit_distance, amax);
-                        /* select form of: hit & inner -> first child; hit & leaf -> test it, then skip; else -> skip */
-                        const bool inner = word >= NODE_CHILD;
-                        const bool toLeaf = hit && !inner;
-                        /* what the leaf test needs: the primitive, or (leaf records) the slot of the triangle's leaf */
-                        const uint32_t leafWord = (LEAFREC && sv.leafRecords && !(word & PRIM_SPHERE)) ? node : word;
-                        leafPrim = toLeaf ? leafWord : leafPrim;
-                        node = (hit && inner) ? (word & NODE_INDEX_MASK) : skip;
-                        state = toLeaf ? (int)S_LEAF : (int)S_NODE;
-                        if (!toLeaf && node >= nodeCount)
-                            state = endOfRayState();
-                        if (PREFETCH && state == S_NODE) {
-                            pn0 = node4(2 * node);
-                            pn1 = node4(2 * node + 1);
-                        }
+                        for (int step = 0; step < STEPS; step++)
+                            if (state == S_NODE)
+                                binaryStep();
                     }
                 }
             }
@@ -758,15 +585,12 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 }
                 afterBlock(next);
             }
-            if (!REDEAL)
-                fromPool();
+            fromPool();
             if (COUNT) /* shader clock spent per kind of block: [11] traversal [12] shade [13] nee-end [14] new */
                 sched[14] += (unsigned long long)(clock64() - tBlock);
         }
         if (pick != S_NODE && state == S_START)
             beginRay();
-        if (REDEAL) /* whichever wave a finished path has come to rest in */
-            fromPool();
     }
 
     if (COUNT && args.counters && inBlock) {
@@ -828,12 +652,13 @@ void launchGroundTruth(const GroundTruthArgs& args, hipStream_t stream);
 constexpr uint32_t ORDER_BUCKETS = 128;
 void launchOrderBuild(const KernelArgs& args, uint32_t* order, uint32_t* work, hipStream_t stream);
 void launchBasicLds(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
-void launchBasicLdsRedeal(const KernelArgs& args, dim3 grid, size_t sceneLdsBytes, hipStream_t stream);
 void launchBasic(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchBasicCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFull(const KernelArgs& args, dim3 grid, hipStream_t stream);
+void launchFullWide(const KernelArgs& args, dim3 grid, hipStream_t stream); /* the wide walk (SceneView::wideNodes) */
 void launchFullCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFullRgl(const KernelArgs& args, dim3 grid, hipStream_t stream);
+void launchFullRglWide(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFullRglCount(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFullAnim(const KernelArgs& args, dim3 grid, hipStream_t stream);
 void launchFullAnimCount(const KernelArgs& args, dim3 grid, hipStream_t stream);

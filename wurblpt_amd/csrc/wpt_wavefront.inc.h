@@ -6,7 +6,7 @@
  * stage (128 registers, four waves per SIMD).  Here the same path logic (wpt_blocks.h, unchanged) and the same walk
  * (same visiting order as bvh.hpp:277-311) are two kernels that hand a pixel's ray back and forth through HBM:
  *
- *   wf_trace   persistent waves at 64 registers / eight waves per SIMD that hold nothing but rays: origin, reciprocals,
+ *   wf_trace   persistent waves (76 registers, built for WF_TRACE_WAVES waves per SIMD) that hold nothing but rays: origin, reciprocals,
  *              shear, node, bound, candidate.  A wave takes rays from the iteration's queue in chunks (one atomic per
  *              chunk) and deals them to its lanes as they finish, so its lanes are always walking; a finished lane
  *              writes the candidate to the pixel's record and files the pixel under the kind of shading it needs next
@@ -27,8 +27,7 @@
  *   8      ray origin, time          9   ray direction, kind of ray
  *   10     candidate: primitive, distance, 1 / det, U        11   V, W
  *   12     a suspended walk: next node, bound
- *   13..15 free (the variant build -DWPT_EVAL_BEHIND_RAY keeps a path ray's candidate, direction and origin there while the
- *          light ray whose end will evaluate a measured BRDF is traced: DESIGN.md section 7)
+ *   13..15 free
  *
  * The walk of a light ray towards the environment ends at its first accepted hit, as in the single kernel (the answer it is
  * traced for -- anything in the way? -- is known there).
@@ -51,12 +50,7 @@ constexpr uint32_t WF_SLOTS = 16; /* quadwords per lane record */
 /* Waves per SIMD the trace is built for.  More waves do not walk faster: dependent fetches of random nodes reach their
  * highest rate at two to four waves per SIMD and fall off beyond (tools/micro/node_fetch.hip: 262 G fetches per second at
  * four, 137 G at eight for 17 MB of nodes) -- the lines a compute unit's lanes have in flight outgrow its L1. */
-#ifndef WF_TRACE_WAVES
-#define WF_TRACE_WAVES 4
-#endif
-#ifndef WF_TRACE_UNIFIED
-#define WF_TRACE_UNIFIED 0 /* 1: every lane keeps one fetch in flight and an iteration runs leaf tests AND node steps (measured slower) */
-#endif
+constexpr int WF_TRACE_WAVES = 4;
 enum { WF_RAY_O = 8, WF_RAY_D = 9, WF_HIT0 = 10, WF_HIT1 = 11, WF_WALK = 12 };
 constexpr uint32_t WF_RESUME = 0x100u; /* in the kind-of-ray word: the record holds a suspended walk */
 
@@ -135,7 +129,7 @@ template<bool SPHERES> WPT_D uint32_t shadeKind(const SceneView& sv, uint32_t ra
     }
 }
 
-template<bool SPHERES, bool PAIRED>
+template<bool SPHERES>
 __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
 {
     const SceneView& sv = a.k.sv;
@@ -152,29 +146,13 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
     for (uint32_t i = threadIdx.x; i < 2 * topNodes; i += WG)
         ldsTop[i] = sv.nodes[i];
     __syncthreads();
-    /* Fetch of the node a lane tests next, behind the step that found it.  PAIRED: a lane fetches the aligned PAIR of
-     * nodes (64 bytes) that holds its node and keeps it: the line comes up from L2 whole whatever part of it is read,
-     * seven steps of ten go on to the node behind the current one (first child, or whatever follows a leaf), and for
-     * an even node that one is the pair's other half -- no request at all. */
-    float4 pq0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pq1 = pq0, pq2 = pq0, pq3 = pq0;
-    uint32_t pairAt = 0xffffffffu;
+    /* fetch of the node a lane tests next, behind the step that found it */
     auto fetchNode = [&](uint32_t node, bool want, float4& pn0, float4& pn1) {
         if (!want)
             return;
         if (node < topNodes) {
             pn0 = ldsTop[2 * node];
             pn1 = ldsTop[2 * node + 1];
-        } else if constexpr (PAIRED) {
-            if ((node >> 1) != pairAt) {
-                const float4* at = sv.nodes + 4 * (size_t)(node >> 1);
-                pq0 = at[0];
-                pq1 = at[1];
-                pq2 = at[2];
-                pq3 = at[3];
-                pairAt = node >> 1;
-            }
-            pn0 = (node & 1u) ? pq2 : pq0;
-            pn1 = (node & 1u) ? pq3 : pq1;
         } else {
             pn0 = sv.nodes[2 * (size_t)node];
             pn1 = sv.nodes[2 * (size_t)node + 1];
@@ -206,9 +184,6 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
     aux.Sx = aux.Sy = 0.0f;
     uint32_t node = 0, leafPrim = 0, gid = 0, stepsLeft = 0;
     bool shadowRay = false;
-#ifdef WPT_EVAL_BEHIND_RAY
-    bool pendingEnd = false;
-#endif
     float amax = k_maxval;
     Candidate best;
     best.prim = NO_HIT;
@@ -218,11 +193,7 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
     for (;;) {
         /* ---- deal rays to the lanes that have none ---- */
         const unsigned long long idle = __ballot(state == T_IDLE);
-        /* batches (refillIdle >= 64): rays are dealt to an EMPTY wave only, so that its lanes start at the root together
-         * and walk the top of the tree over the same lines; what still walks when fewer than refillIdle - 64 lanes are left
-         * is suspended and queued for the next launch */
-        const bool batches = a.refillIdle >= 64u;
-        if (idle != 0 && (!batches || idle == ~0ull)) {
+        if (idle != 0) {
             if (chunkNext == chunkEnd && !dry) {
                 uint32_t first = 0;
                 if (lane == 0)
@@ -265,11 +236,7 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                     stepsLeft = a.stepBudget ? a.stepBudget : 0xffffffffu;
                     state = T_NODE;
                     /* a light ray towards the environment: its walk ends at the first accepted hit (wpt_pathtrace.inc.h) */
-                    shadowRay = a.k.shadowWalksEnd != 0 && ((__float_as_uint(rd.w) & ~WF_RESUME) == (uint32_t)RAY_NEE_ENV
-#ifdef WPT_EVAL_BEHIND_RAY
-                            || (__float_as_uint(rd.w) & ~WF_RESUME) == (uint32_t)RAY_NEE_ENV_PENDING
-#endif
-                            );
+                    shadowRay = a.k.shadowWalksEnd != 0 && (__float_as_uint(rd.w) & ~WF_RESUME) == (uint32_t)RAY_NEE_ENV;
                 }
                 fetchNode(node, dealt, pn0, pn1);
                 chunkNext += take;
@@ -283,85 +250,7 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
         /* walk until refillIdle lanes have finished (while there is something to deal them), or to the end */
         const bool canRefill = chunkNext != chunkEnd || !dry;
         int leaveBelow = canRefill ? 65 - (int)a.refillIdle : 1;
-        if (batches) {
-            /* never more than a quarter of the batch: a small batch (the end of a frame has few rays left) parked before it
-             * has walked would come back the same, launch after launch, without end */
-            const int walking = __popcll(__ballot(state != T_IDLE));
-            const int quarter = walking >> 2;
-            leaveBelow = canRefill ? ((int)a.refillIdle - 64 < quarter ? (int)a.refillIdle - 64 : quarter) : 1;
-        }
         leaveBelow = leaveBelow < 1 ? 1 : leaveBelow;
-#if WF_TRACE_UNIFIED
-        /* Unified steps.  Every walking lane has ONE fetch in flight, issued at the end of the iteration before: its next
-         * node's two quadwords, or -- when the step before found a leaf -- the triangle's three.  An iteration waits for
-         * them once and then runs the leaf test for the lanes that came for one and the node step for the others, each
-         * under its mask.  With separate rounds for nodes and leaves (the single kernel's scheduler, and this kernel's first
-         * form) a wave has one memory round trip in flight at a time and a lane stands still through every round of the
-         * other kind.  Measured, bit-exact: Sponza-class 366 against 315 ms, measured BRDFs 1406 against 1262, 10 M triangles
-         * 540 against 510 -- running both stretches of code in every iteration costs more issue time than the shorter wait
-         * gives back.  Not the default (WF_TRACE_UNIFIED). */
-        float4 q2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        auto fetchLeaf = [&](uint32_t prim) {
-            if (!(SPHERES && (prim & PRIM_SPHERE))) {
-                /* leaf records: the corners lie behind the leaf's node, leafPrim is the leaf's slot until the test */
-                const float4* g = sv.leafRecords ? sv.nodes + 2 * (size_t)prim + 2 : sv.triGeom + 3 * (size_t)prim;
-                pn0 = g[0];
-                pn1 = g[1];
-                q2 = g[2];
-            }
-        };
-        if (state == T_LEAF) /* (a lane never enters the loop in this state; kept for symmetry with the refill) */
-            fetchLeaf(leafPrim);
-        for (;;) {
-            const unsigned long long mNode = __ballot(state == T_NODE), mLeaf = __ballot(state == T_LEAF);
-            if (__popcll(mNode) + __popcll(mLeaf) < leaveBelow)
-                break;
-            const bool wasLeaf = state == T_LEAF, wasNode = state == T_NODE;
-            if (mLeaf != 0 && wasLeaf) {
-                /* HitableTriangle::hit / HitableSphere::hit, candidate part; `node` already is the node to go on with */
-                Candidate c;
-                bool accepted;
-                if (SPHERES && (leafPrim & PRIM_SPHERE)) {
-                    c.invDet = c.U = c.V = c.W = 0.0f;
-                    accepted = sphereTest(sv.spheres[leafPrim & ~PRIM_SPHERE], o, d, amin, amax, c.a);
-                } else {
-                    if (sv.leafRecords)
-                        leafPrim = __float_as_uint(pn0.w);
-                    accepted = triangleTest(mk3(pn0.x, pn0.y, pn0.z), mk3(pn1.x, pn1.y, pn1.z), mk3(q2.x, q2.y, q2.z), o, aux, amin, amax, c);
-                }
-                if (accepted) {
-                    c.prim = leafPrim;
-                    best = c;
-                    amax = c.a;
-                }
-                state = (node >= nodeCount || (accepted && shadowRay)) ? (int)T_DONE : (int)T_NODE;
-                if (state == T_NODE && stepsLeft == 0)
-                    state = T_SUSPEND; /* between two nodes: nothing pending but (node, bound, candidate) */
-            }
-            if (mNode != 0 && wasNode) {
-                /* AABB::mayHit + the stackless form of BVH::hit's walk (wpt_pathtrace.inc.h) */
-                const float4 n0 = pn0, n1 = pn1;
-                const uint32_t skip = __float_as_uint(n1.z);
-                const uint32_t word = __float_as_uint(n1.w);
-                const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, aux.inv, amin, amax);
-                const bool inner = word >= NODE_CHILD;
-                const bool toLeaf = hit && !inner;
-                const uint32_t leafWord = (sv.leafRecords && !(word & PRIM_SPHERE)) ? node : word;
-                leafPrim = toLeaf ? leafWord : leafPrim;
-                node = (hit && inner) ? (word & NODE_INDEX_MASK) : skip;
-                state = toLeaf ? (int)T_LEAF : (int)T_NODE;
-                if (!toLeaf && node >= nodeCount)
-                    state = T_DONE;
-                stepsLeft = stepsLeft ? stepsLeft - 1 : 0;
-                if (state == T_NODE && stepsLeft == 0)
-                    state = T_SUSPEND;
-            }
-            /* what each lane tests next is asked for now */
-            fetchNode(node, state == T_NODE, pn0, pn1);
-            if (state == T_LEAF)
-                fetchLeaf(leafPrim);
-        }
-#else
         for (;;) {
             const int nNode = __popcll(__ballot(state == T_NODE));
             const int nLeaf = __popcll(__ballot(state == T_LEAF));
@@ -377,11 +266,8 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                         c.invDet = c.U = c.V = c.W = 0.0f;
                         accepted = sphereTest(sv.spheres[leafPrim & ~PRIM_SPHERE], o, d, amin, amax, c.a);
                     } else {
-                        /* leaf records: the corners lie behind the leaf's node, leafPrim is the leaf's slot until here */
-                        const float4* g = sv.leafRecords ? sv.nodes + 2 * (size_t)leafPrim + 2 : sv.triGeom + 3 * (size_t)leafPrim;
+                        const float4* g = sv.triGeom + 3 * (size_t)leafPrim;
                         const float4 g0 = g[0], g1 = g[1], g2 = g[2];
-                        if (sv.leafRecords)
-                            leafPrim = __float_as_uint(g0.w);
                         accepted = triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), o, aux, amin, amax, c);
                     }
                     if (accepted) {
@@ -405,8 +291,7 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                     const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, aux.inv, amin, amax);
                     const bool inner = word >= NODE_CHILD;
                     const bool toLeaf = hit && !inner;
-                    const uint32_t leafWord = (sv.leafRecords && !(word & PRIM_SPHERE)) ? node : word;
-                    leafPrim = toLeaf ? leafWord : leafPrim;
+                    leafPrim = toLeaf ? word : leafPrim;
                     node = (hit && inner) ? (word & NODE_INDEX_MASK) : skip;
                     state = toLeaf ? (int)T_LEAF : (int)T_NODE;
                     if (!toLeaf && node >= nodeCount)
@@ -418,33 +303,6 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                 }
                 fetchNode(node, wantNode, pn0, pn1);
             }
-        }
-#endif
-        if (batches && canRefill && __ballot(state == T_NODE || state == T_LEAF) != 0) {
-            /* the few that still walk make room for a full batch: a pending leaf test first (a walk is suspended between
-             * two nodes), then they are written back as they stand */
-            if (state == T_LEAF) {
-                Candidate c;
-                bool accepted;
-                if (SPHERES && (leafPrim & PRIM_SPHERE)) {
-                    c.invDet = c.U = c.V = c.W = 0.0f;
-                    accepted = sphereTest(sv.spheres[leafPrim & ~PRIM_SPHERE], o, d, amin, amax, c.a);
-                } else {
-                    const float4* g = sv.leafRecords ? sv.nodes + 2 * (size_t)leafPrim + 2 : sv.triGeom + 3 * (size_t)leafPrim;
-                    const float4 g0 = g[0], g1 = g[1], g2 = g[2];
-                    if (sv.leafRecords)
-                        leafPrim = __float_as_uint(g0.w);
-                    accepted = triangleTest(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), o, aux, amin, amax, c);
-                }
-                if (accepted) {
-                    c.prim = leafPrim;
-                    best = c;
-                    amax = c.a;
-                }
-                state = (node >= nodeCount || (accepted && shadowRay)) ? (int)T_DONE : (int)T_NODE;
-            }
-            if (state == T_NODE)
-                state = T_SUSPEND;
         }
         /* ---- finished rays: the candidate goes to the pixel's record, the pixel to the queue of its kind; rays out of
          * steps are written back as they stand and queued for the next trace ---- */
@@ -466,32 +324,9 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                         *kindWord = kw & ~WF_RESUME; /* through: the record holds a result again */
                     if (a.buckets)
                         kind = shadeKind<SPHERES>(sv, kw & ~WF_RESUME, best.prim, best.invDet);
-#ifdef WPT_EVAL_BEHIND_RAY
-                    /* a light ray with its material's evaluation pending that nothing was in the way of: a queue of its own,
-                     * filled from the far end of the measured BRDFs' (a pixel is in one queue per iteration, so the two never
-                     * meet); shadowed ones end like any other light ray */
-                    if (a.buckets && (kw & ~WF_RESUME) == (uint32_t)RAY_NEE_ENV_PENDING && best.prim == NO_HIT) {
-                        kind = WF_BUCKETS;
-                        pendingEnd = true;
-                    }
-#endif
                 }
                 state = T_IDLE;
             }
-#ifdef WPT_EVAL_BEHIND_RAY
-            {
-                const unsigned long long pend = __ballot(pendingEnd);
-                if (pend != 0) {
-                    uint32_t base = 0;
-                    if (lane == 0)
-                        base = atomicAdd(&cur->pad[0], (uint32_t)__popcll(pend));
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    if (pendingEnd)
-                        a.bucketQueue[(size_t)WF_B_RGL * a.laneCount + (a.laneCount - 1u - (base + rankIn(pend)))] = gid;
-                    pendingEnd = false;
-                }
-            }
-#endif
             const unsigned long long suspended = __ballot(suspend);
             if (suspended != 0) {
                 uint32_t base = 0;
@@ -552,18 +387,6 @@ WPT_D bool shadeSlice(const WfIter* cur, uint32_t kindMask, uint32_t group, uint
         }
         at += groups;
     }
-#ifdef WPT_EVAL_BEHIND_RAY
-    if ((kindMask >> WF_B_RGL) & 1u) { /* ends of light rays with an evaluation pending: kind WF_BUCKETS, the far end of the measured BRDFs' queue */
-        const uint32_t n = cur->pad[0];
-        const uint32_t groups = (n + WG - 1) / WG;
-        if (group < at + groups) {
-            kind = WF_BUCKETS;
-            first = (group - at) * WG;
-            count = n;
-            return true;
-        }
-    }
-#endif
     return false;
 }
 
@@ -595,11 +418,7 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
         count = a.laneCount;
     } else if (a.buckets) {
         if (shadeSlice(cur, a.kindMask, blockIdx.x, kind, first, count))
-#ifdef WPT_EVAL_BEHIND_RAY
-            queueIn = a.bucketQueue + (size_t)(kind < WF_BUCKETS ? kind : (uint32_t)WF_B_RGL) * a.laneCount;
-#else
             queueIn = a.bucketQueue + (size_t)kind * a.laneCount;
-#endif
         else
             return; /* uniform for the workgroup */
     } else {
@@ -646,11 +465,7 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
         ps.rayKind = RAY_PATH;
         ps.o = ps.d = mk3(0.0f, 0.0f, 1.0f);
         if (have) {
-#ifdef WPT_EVAL_BEHIND_RAY
-            gid = queueIn[kind == WF_BUCKETS && a.buckets ? a.laneCount - 1u - entry : entry];
-#else
             gid = queueIn[entry];
-#endif
             rec = a.state + (size_t)gid * WF_SLOTS;
 #pragma unroll
             for (int k = 0; k < SLOT_COUNT; k++)
@@ -673,36 +488,10 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
     if (have) {
         LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
         if (!INIT) {
-#ifdef WPT_EVAL_BEHIND_RAY
-            if (ps.rayKind == RAY_PATH) {
-                next = blockShade<F, false>(sv, par, tri4, ps, best, lc, 0, true);
-                if (next == NEXT_TRACE && ps.rayKind == RAY_NEE_ENV_PENDING) {
-                    /* what the evaluation behind the light ray will need of the path ray: candidate, direction, origin -- the
-                     * record still holds them (the new ray is written below), they move to its three free quadwords */
-                    const float4 ro = rec[WF_RAY_O], rd = rec[WF_RAY_D], h0 = rec[WF_HIT0], h1 = rec[WF_HIT1];
-                    rec[13] = h0;
-                    rec[14] = make_float4(h1.x, h1.y, rd.x, rd.y);
-                    rec[15] = make_float4(rd.z, ro.x, ro.y, ro.z);
-                }
-            } else if (ps.rayKind == RAY_NEE_ENV_PENDING && best.prim == NO_HIT) {
-                const float4 q0 = rec[13], q1 = rec[14], q2 = rec[15];
-                Candidate pathBest;
-                pathBest.prim = __float_as_uint(q0.x);
-                pathBest.a = q0.y;
-                pathBest.invDet = q0.z;
-                pathBest.U = q0.w;
-                pathBest.V = q1.x;
-                pathBest.W = q1.y;
-                next = blockNeeEndPending<F>(sv, par, tri4, ps, pathBest, mk3(q2.y, q2.z, q2.w), mk3(q1.z, q1.w, q2.x));
-            } else {
-                next = blockNeeEnd<F>(sv, par, tri4, ps, best); /* (a shadowed pending ray ends like any light ray towards the environment: nothing to add) */
-            }
-#else
             if (ps.rayKind == RAY_PATH)
                 next = blockShade<F, false>(sv, par, tri4, ps, best, lc, 0); /* tracePath, one path component (wurblpt.hpp:131-252) */
             else
                 next = blockNeeEnd<F>(sv, par, tri4, ps, best);            /* the next-event ray's contribution, then the path continues */
-#endif
         }
         if (next == NEXT_NEW) { /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
             next = blockNew<F>(fa, ps, sv);
@@ -750,6 +539,8 @@ constexpr size_t WF_SHADE_LDS = COLD_BYTES + 32;
 /* launch geometry of a wavefront render (wpt_set_wavefront); 0 = default */
 struct WfConfig {
     uint32_t groups, chunk, refillIdle, buckets, leafBias, stepBudget, topNodes;
+    uint32_t tracePerCu;   /* measurements: workgroups of the trace per compute unit (0 = what fits) */
+    uint32_t shadePerKind; /* measurements: one shade launch per kind of material, so that a kernel trace tells them apart */
 };
 struct WfLaunchers;
 /* The host side (wpt_wavefront_host.hip): renders the pixels of `args` (the lane -> pixel mapping of one launch of the
@@ -758,31 +549,27 @@ struct WfLaunchers;
  * *launches receives the number of kernel launches. */
 hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, const WfConfig& cfg, hipStream_t stream, uint32_t* launches);
 
-/* one launcher set per feature set, each in its own translation unit */
+/* The trace kernel is instantiated in ONE translation unit (wpt_k_wf_trace.hip: with and without sphere leaves), so that the
+ * shade kernels' units, which differ in their build settings, can never disagree about it. */
+void launchWfTrace(bool spheres, const WfArgs& a, dim3 grid, hipStream_t stream);
+int wfTraceBlocksPerCu(bool spheres, size_t dynamicLdsBytes);
+
+/* one launcher set per feature set; the shade kernels each in their own translation unit */
 struct WfLaunchers {
-    void (*trace)(const WfArgs&, dim3, hipStream_t);
+    bool spheres; /* which instantiation of the trace */
     void (*init)(const WfArgs&, dim3, hipStream_t);
     void (*shade)(const WfArgs&, dim3, hipStream_t);
-    int (*traceBlocksPerCu)();
 };
 const WfLaunchers& wfBasic();
 const WfLaunchers& wfFull();
 const WfLaunchers& wfFullRgl();
 
-#define WPT_WF_LAUNCHERS(NAME, FEATURES, SPHERES, PAIRED)                                                                              \
-    static void NAME##Trace(const WfArgs& a, dim3 grid, hipStream_t s) { hipLaunchKernelGGL((wf_trace<SPHERES, PAIRED>), grid, dim3(WG), size_t(a.topNodes) * 32, s, a); } \
+#define WPT_WF_LAUNCHERS(NAME, FEATURES, SPHERES)                                                                              \
     static void NAME##Init(const WfArgs& a, dim3 grid, hipStream_t s) { hipLaunchKernelGGL((wf_shade<FEATURES, true>), grid, dim3(WG), WF_SHADE_LDS, s, a); } \
     static void NAME##Shade(const WfArgs& a, dim3 grid, hipStream_t s) { hipLaunchKernelGGL((wf_shade<FEATURES, false>), grid, dim3(WG), WF_SHADE_LDS, s, a); } \
-    static int NAME##TraceBlocks()                                                                                             \
-    {                                                                                                                          \
-        int perCu = 0;                                                                                                         \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, wf_trace<SPHERES, PAIRED>, (int)WG, 0) != hipSuccess)                 \
-            perCu = 0;                                                                                                         \
-        return perCu;                                                                                                          \
-    }                                                                                                                          \
     const WfLaunchers& NAME()                                                                                                  \
     {                                                                                                                          \
-        static const WfLaunchers l = { NAME##Trace, NAME##Init, NAME##Shade, NAME##TraceBlocks };                              \
+        static const WfLaunchers l = { SPHERES, NAME##Init, NAME##Shade };                                                     \
         return l;                                                                                                              \
     }
 

@@ -8,7 +8,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -107,12 +106,14 @@ hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, c
         groupCount--;
     const uint32_t perGroup = ((lanes + groupCount - 1) / groupCount + WG - 1) / WG * WG;
     const uint32_t chunk = cfg.chunk ? cfg.chunk : 128u;
-    int perCu = kernels.traceBlocksPerCu();
+    /* the top of the tree in LDS: with the 8 KiB of staging, four workgroups per compute unit hold 32 KiB each */
+    const uint32_t topNodes = cfg.topNodes == 0xffffffffu ? 0u : std::min(std::min(cfg.topNodes ? cfg.topNodes : 768u, 768u), args.sv.nodeCount);
+    int perCu = wfTraceBlocksPerCu(kernels.spheres, size_t(topNodes) * 32);
     perCu = perCu < 1 ? 1 : (perCu > WF_TRACE_WAVES ? WF_TRACE_WAVES : perCu);
-    if (const char* e = getenv("WPT_WF_TRACE_PER_CU")) /* experiments: workgroups of the trace per compute unit */
-        perCu = std::max(1, std::min(perCu, atoi(e)));
+    if (cfg.tracePerCu)
+        perCu = std::max(1, std::min(perCu, int(cfg.tracePerCu)));
     const uint32_t traceResident = uint32_t(perCu) * std::max(1u, args.cuCount);
-    const bool perKind = getenv("WPT_WF_SHADE_PER_KIND") != nullptr;
+    const bool perKind = cfg.shadePerKind != 0;
 
     float4* state = nullptr;
     uint32_t* queues = nullptr;
@@ -144,8 +145,7 @@ hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, c
         gr.args.leafBias = cfg.leafBias ? cfg.leafBias : 32u;
         gr.args.kindMask = (1u << WF_BUCKETS) - 1u;
         gr.args.stepBudget = cfg.stepBudget == 0xffffffffu ? 0u : (cfg.stepBudget ? cfg.stepBudget : 512u);
-        /* the top of the tree in LDS: with the 8 KiB of staging, four workgroups per compute unit hold 32 KiB each */
-        gr.args.topNodes = cfg.topNodes == 0xffffffffu ? 0u : std::min(std::min(cfg.topNodes ? cfg.topNodes : 768u, 768u), args.sv.nodeCount);
+        gr.args.topNodes = topNodes;
         gr.known = gr.args.laneCount;
         gr.iteration = 0;
         gr.active = gr.args.laneCount != 0;
@@ -174,14 +174,10 @@ hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, c
                     return e;
             }
             const uint32_t traceGroups = std::max(1u, std::min(traceResident, (gr.known + chunk * (WG / 64) - 1) / (chunk * (WG / 64))));
-#ifdef WPT_EVAL_BEHIND_RAY
-            const uint32_t shadeGroups = (gr.known + WG - 1) / WG + (gr.args.buckets ? WF_BUCKETS + 1u : 0u); /* a ninth queue's rounding */
-#else
             const uint32_t shadeGroups = (gr.known + WG - 1) / WG + (gr.args.buckets ? WF_BUCKETS : 0u);
-#endif
             for (uint32_t i = 0; i < BATCH; i++) {
                 gr.args.iteration = gr.iteration + i;
-                kernels.trace(gr.args, dim3(traceGroups), s);
+                launchWfTrace(kernels.spheres, gr.args, dim3(traceGroups), s);
                 if (perKind && gr.args.buckets) {
                     /* measurements: one shade launch per kind, so that a kernel trace tells what each kind costs */
                     for (uint32_t kd = 0; kd < WF_BUCKETS; kd++) {

@@ -16,10 +16,12 @@ def lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("WPT_LIB_DIR", "lib"), "libwurblpt_hip.so")
 
 
+WALK_WIDE, WALK_FULL_SHADOW, WALK_COUNT_PRODUCT = 1, 2, 4  # wpt_set_walk (include/wurblpt_hip.h)
+
 EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_current_device", "wpt_scene_upload", "wpt_scene_free", "wpt_scene_check",
            "wpt_postproc_to_srgb", "wpt_postproc_max_luminance", "wpt_postproc_uniform_rational_quantization",
            "wpt_postproc_scale_luminance", "wpt_postproc_host", "wpt_ground_truth_device", "wpt_ground_truth", "wpt_render_bands_device", "wpt_render_bands",
-           "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_set_top_nodes", "wpt_set_wavefront", "wpt_kernel_name", "wpt_device_name", "wpt_build_info", "wpt_last_render_passes",
+           "wpt_render_block_device", "wpt_render_block", "wpt_set_launch_config", "wpt_set_top_nodes", "wpt_set_walk", "wpt_set_wavefront", "wpt_kernel_name", "wpt_device_name", "wpt_build_info", "wpt_last_render_passes",
            "wpt_last_error"]
 
 
@@ -53,6 +55,8 @@ def lib():
                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.wpt_set_launch_config.argtypes = [C.c_uint32, C.c_uint32]
         L.wpt_set_wavefront.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.wpt_set_walk.argtypes = [C.c_uint32]
+        L.wpt_set_top_nodes.argtypes = [C.c_uint32]
         L.wpt_kernel_name.restype = C.c_char_p
         L.wpt_last_error.restype = C.c_char_p
         L.wpt_selftest_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
