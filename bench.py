@@ -41,6 +41,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 VALU_PEAK_GLANEOPS = 256 * 4 * 32 * 2.4
 LDS_SCENE_MAX_BYTES = 20 * 1024  # wpt_pathtrace.inc.h: scenes up to this size are traversed from LDS
 SECONDARY = "sponza_like_1920x1080_256spp_envmap_is"
+# the default line's secondary workloads: name, timed steps, warm-up steps, samples_sqrt of the counted pass (None: the frame's own)
+SECONDARIES = [(SECONDARY, 3, 1, None),
+               ("courtyard_like_10M_1920x1080_121spp", 2, 1, None),
+               ("measured_like_3840x2160_529spp_rgl", 1, 1, 6)]
 
 WORKLOADS = {
     # name: (builder kwargs, width, height, samples_sqrt)
@@ -232,7 +236,7 @@ def roofline_of(name, scene, cnt, spp, count_sqrt, avg_ms, avg_samples, n_launch
     return roofline
 
 
-def measure_one_gpu(name, w, scene, dscene, steps, warmup, cpu_seconds, lib_id, torch, device, host, barrier=None, walk_flags=0):
+def measure_one_gpu(name, w, scene, dscene, steps, warmup, cpu_seconds, lib_id, torch, device, host, barrier=None, walk_flags=0, count_sqrt=None):
     """W untimed + K timed renders of the workload's frame on this GPU (one render call each), the counted pass for the
     roofline, the CPU baseline on a block of the same frame and the parity of that block."""
     width, height, ssqrt = w["width"], w["height"], w["samples_sqrt"]
@@ -241,9 +245,11 @@ def measure_one_gpu(name, w, scene, dscene, steps, warmup, cpu_seconds, lib_id, 
     frame = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
     # counted pass (untimed): work per sample for the roofline's algorithmic bytes; the counting build renders the timed
-    # frame, sample for sample
+    # frame, sample for sample (secondary workloads with hundreds of samples per pixel: the same pixels with count_sqrt^2
+    # samples each -- the first strata rows of the same sequences; the line says so in roofline.counted_on)
+    csq = min(ssqrt, count_sqrt) if count_sqrt else ssqrt
     counters = torch.zeros(6, dtype=torch.int64, device="cuda")
-    dscene.render_block_into(frame, ssqrt, None, params, counters, stream)
+    dscene.render_block_into(frame, csq, None, params, counters, stream)
     torch.cuda.synchronize()
     names = ("samples", "rays", "node_visits", "leaf_tests", "pdf_tests", "scatters")
     cnt = dict(zip(names, [int(x) for x in counters.cpu().tolist()]))
@@ -256,7 +262,7 @@ def measure_one_gpu(name, w, scene, dscene, steps, warmup, cpu_seconds, lib_id, 
         device.lib().wpt_set_walk(walk_flags | device.WALK_COUNT_PRODUCT)
         try:
             counters.zero_()
-            dscene.render_block_into(frame, ssqrt, None, params, counters, stream)
+            dscene.render_block_into(frame, csq, None, params, counters, stream)
             torch.cuda.synchronize()
             walked = dict(zip(names, [int(x) for x in counters.cpu().tolist()]))
         finally:
@@ -287,7 +293,7 @@ def measure_one_gpu(name, w, scene, dscene, steps, warmup, cpu_seconds, lib_id, 
              "kernel_launches_per_launch launches of the kernel(s), whose durations add up to it")
     out = {
         "value": float(pixels) * spp * steps / elapsed / 1e6, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
-        "roofline": roofline_of(name, scene, cnt, spp, ssqrt, avg_ms, float(pixels) * spp, len(ms), basis, lib_id, device, walked=walked),
+        "roofline": roofline_of(name, scene, cnt, spp, csq, avg_ms, float(pixels) * spp, len(ms), basis, lib_id, device, walked=walked),
         "frame_finite": bool(torch.isfinite(frame).all().item()),
     }
     if cpu_seconds > 0:
@@ -306,13 +312,17 @@ def main():
     ap.add_argument("--samples-sqrt", type=int, default=0, help="override spp (debug only; changes the workload name)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-secondary", action="store_true", help="N = 1: do not measure the Sponza-class workload beside the primary one")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: do not measure the workloads whose scene is fetched from HBM (BASELINE configs 3 - 5) beside the primary one")
     ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--skip-secondary", action="append", default=[], choices=sorted(WORKLOADS), help="leave this secondary workload out (repeatable)")
     ap.add_argument("--obj", default=None, help="the real Sponza OBJ file: the Sponza-class workload imports it (wurblpt-sponza.cpp:46-71) instead of the procedural stand-in")
     ap.add_argument("--envmap", default=None, help="environment map image for --obj (HDR / EXR / PFM); without it the constant environment of wurblpt-sponza.cpp:60-63")
     ap.add_argument("--streams", type=int, default=8, help="concurrent block launches per GPU when N > 1")
     ap.add_argument("--force-blocks", type=int, default=0, metavar="RANKS",
                     help="N = 1 only (rehearsal): run the N > 1 code path -- block queue, worker threads, streams -- as if RANKS ranks shared the frame; this process renders every block")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the N > 1 code path at any world size, also 1 (under torch.distributed.run --nproc-per-node=1): process group, "
+                         "one builder per node, this rank's bands in one launch, the frame reduce, per-rank statistics, --verify")
     ap.add_argument("--dynamic-blocks", action="store_true",
                     help="N > 1: hand blocks out from a shared counter as MPICoordinator does (default: block i to rank i mod N)")
     ap.add_argument("--verify", action="store_true",
@@ -333,7 +343,8 @@ def main():
         raise SystemExit("bench.py --gpus %d runs in %d process(es): launch it as python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ... (or plain python bench.py for --gpus 1)"
                          % (args.gpus, world, args.gpus, args.gpus))
-    if world > 1 and not os.environ.get("WPT_HOST_THREADS"):
+    distributed = world > 1 or args.force_distributed
+    if distributed and not os.environ.get("WPT_HOST_THREADS"):
         # torch.distributed.run exports OMP_NUM_THREADS=1; the host-side BVH build (rank 0 only, see below) may use its share
         os.environ["OMP_NUM_THREADS"] = str(max(1, host_cores()))
 
@@ -354,7 +365,7 @@ def main():
         assert torch.cuda.device_count() >= world and local_rank < torch.cuda.device_count(), \
             "%d ranks need %d GPUs on this node, %d are visible" % (world, world, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if distributed:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -375,7 +386,7 @@ def main():
     width, height, ssqrt = w["width"], w["height"], w["samples_sqrt"]
     spp = ssqrt * ssqrt
     pixels = width * height
-    if world > 1:
+    if distributed:
         # one builder per node: rank 0 builds and flattens the scene (with all host cores: the BVH build of the
         # 10 M triangle scene takes most of a minute), the other ranks map its file from /dev/shm
         from wurblpt_amd import scenefile
@@ -402,11 +413,11 @@ def main():
     config = {"workload": name, "width": width, "height": height, "spp": spp, "triangles": int(scene.d.tri_count), "bvh_nodes": int(scene.d.node_count)}
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    sharded = world > 1 or args.force_blocks > 0
+    sharded = distributed or args.force_blocks > 0
     if not sharded:
         # ---- N = 1: one render call per step ----
         m, frame = measure_one_gpu(name, w, scene, dscene, args.steps, args.warmup, cpu_seconds, lib_id, torch, device, host, barrier, walk_flags)
@@ -420,19 +431,27 @@ def main():
         for k in ("cpu_baseline", "parity"):
             if k in m:
                 out[k] = m[k]
-        if not args.no_secondary and args.workload != SECONDARY and not args.samples_sqrt:
-            # the Sponza-class workload under the same clock: its scene is fetched from HBM (the primary one lives in LDS)
+        if not args.no_secondary and args.workload == "cornell_1024x1024_1024spp_ggx_glass" and not args.samples_sqrt:
+            # the workloads whose scene is fetched from HBM under the same clock (the primary one lives in LDS): BASELINE
+            # configs[2], [3] and [4], each with its own roofline, CPU baseline and parity
             del dscene, frame
-            sname, sw = workload(SECONDARY)
-            t2 = time.perf_counter()
-            sscene = build_scene(sw)
-            t2 = time.perf_counter() - t2
-            sd = device.DeviceScene(sscene)
-            sm, _ = measure_one_gpu(sname, sw, sscene, sd, args.secondary_steps, 1, min(cpu_seconds, 8.0), lib_id, torch, device, host, walk_flags=walk_flags)
-            sm.update(workload=sname, unit="Msamples/s", scene_build_s=t2,
-                      config={"workload": sname, "width": sw["width"], "height": sw["height"], "spp": sw["samples_sqrt"] ** 2,
-                              "triangles": int(sscene.d.tri_count), "bvh_nodes": int(sscene.d.node_count), "parallelism": "1 launch"})
-            out["secondary"] = [sm]
+            out["secondary"] = []
+            for sname0, ssteps, swarm, scount in SECONDARIES:
+                if sname0 in args.skip_secondary:
+                    continue
+                sname, sw = workload(sname0)
+                t2 = time.perf_counter()
+                sscene = build_scene(sw)
+                t2 = time.perf_counter() - t2
+                sd = device.DeviceScene(sscene)
+                sm, sframe = measure_one_gpu(sname, sw, sscene, sd, ssteps if sname0 != SECONDARY else args.secondary_steps, swarm, min(cpu_seconds, 8.0), lib_id,
+                                             torch, device, host, walk_flags=walk_flags, count_sqrt=scount)
+                sm.update(workload=sname, unit="Msamples/s", scene_build_s=t2,
+                          config={"workload": sname, "width": sw["width"], "height": sw["height"], "spp": sw["samples_sqrt"] ** 2,
+                                  "triangles": int(sscene.d.tri_count), "bvh_nodes": int(sscene.d.node_count), "parallelism": "1 launch"})
+                out["secondary"].append(sm)
+                del sd, sframe, sscene
+                torch.cuda.empty_cache()
         print(json.dumps(out), flush=True)
         return
 
@@ -446,17 +465,17 @@ def main():
     kernel_ms = []   # (event, event, samples) per render call on this rank, timed steps only
     reduce_ms = []   # host-timed seconds of the frame reduce per timed step
     from wurblpt_amd import blocks
-    store = dist.distributed_c10d._get_default_store() if world > 1 else None
+    store = dist.distributed_c10d._get_default_store() if distributed else None
     streams = [torch.cuda.Stream() for _ in range(args.streams)]
     block_size = blocks.plan_block_size(pixels, width, max(world, args.force_blocks), args.streams)
     band_rows = max(1, block_size // width)
     bands = -(-height // band_rows)
-    my_pixels = sum(min(band_rows, height - b * band_rows) for b in range(rank, bands, world)) * width if world > 1 else pixels
+    my_pixels = sum(min(band_rows, height - b * band_rows) for b in range(rank, bands, world)) * width if distributed else pixels
 
     def step(index, timed):
         frame.zero_()
         torch.cuda.synchronize()
-        if world > 1 and not args.dynamic_blocks:
+        if distributed and not args.dynamic_blocks:
             # this rank's interleaved share (band i to rank i mod N) in one launch
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main_stream)
@@ -471,7 +490,7 @@ def main():
             if timed:
                 reduce_ms.append(time.perf_counter() - t)
             return
-        if args.dynamic_blocks or world == 1:
+        if args.dynamic_blocks or not distributed:
             queue = blocks.BlockQueue(pixels, block_size, store, "wpt_block_counter_%d" % index)
         else:
             queue = blocks.InterleavedBlocks(pixels, block_size, rank, world)
@@ -506,7 +525,7 @@ def main():
     launches = [(a.elapsed_time(b), s) for a, b, s in kernel_ms]
     # per rank: its kernel time per step, its reduce time per step, how many of its pixels there are per lane of its GPU
     per_rank = blocks.rank_stats(sum(m for m, _ in launches) / max(1, args.steps), 1e3 * sum(reduce_ms) / max(1, len(reduce_ms)), my_pixels, "cuda")
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -514,7 +533,7 @@ def main():
     ok = bool(torch.isfinite(frame).all().item()) if rank == 0 else True
     verified = None
     parity = None
-    if (args.verify or (world > 1 and not args.no_verify)) and rank == 0:
+    if (args.verify or (distributed and not args.no_verify)) and rank == 0:
         # the sharded frame (rank 0 holds the sum of all ranks' bands) against one launch over all pixels
         whole = torch.zeros_like(frame)
         dscene.render_block_into(whole, ssqrt, None, params, None, main_stream)
@@ -532,7 +551,7 @@ def main():
         avg_samples = sum(s for _, s in launches) / max(1, len(launches))
         basis = ("algorithmic bytes of one launch / its duration (HIP events on the launch's stream); a launch is one render call: "
                  "kernel_launches_per_launch launches of the kernel(s), whose durations add up to it")
-        if launches and (args.dynamic_blocks or world == 1):
+        if launches and (args.dynamic_blocks or not distributed):
             # this rank's launches overlap on its streams: price its whole share against the timed region instead
             avg_ms = elapsed * 1e3
             avg_samples = sum(s for _, s in launches)
@@ -548,7 +567,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": dict(config, parallelism=(
                 "pixel blocks of %d from a shared counter over %d GPUs (%d streams each) + RCCL reduce" % (block_size, world, args.streams)
-                if (args.dynamic_blocks or world == 1) else
+                if (args.dynamic_blocks or not distributed) else
                 "bands of %d rows, band i to rank i mod %d, one launch per GPU + RCCL reduce" % (band_rows, world))),
             "roofline": roofline,
             "frame_finite": ok,
@@ -564,7 +583,7 @@ def main():
         if parity is not None:
             out["parity"] = parity
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

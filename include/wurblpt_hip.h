@@ -438,7 +438,7 @@ wpt_status wpt_set_top_nodes(uint32_t nodes);
  *                           (128-byte nodes that hold the boxes of a node's four grandchildren), and product launches walk that:
  *                           four box tests per fetch, leaf tests in BVH::hit's order (bvh.hpp:277-311), the same hits bit for bit
  *                           (wpt_pathtrace.inc.h says why; rays for which the argument does not hold walk the binary tree).
- *                           Trees with a non-finite box, a child's box outside its parent's, or a worst case of more than 64
+ *                           Trees with a non-finite box, a child's box outside its parent's, or a worst case of more than 96
  *                           waiting entries have no wide form and are walked as before.
  *   WPT_WALK_FULL_SHADOW    light rays towards the environment walk the tree to the end like the reference's (product launches
  *                           end such a walk at its first accepted hit: the answer the ray is traced for is known there)
@@ -463,13 +463,16 @@ wpt_status wpt_set_walk(uint32_t flags);
 wpt_status wpt_set_wavefront(uint32_t mode, uint32_t groups, uint32_t chunk, uint32_t flags);
 /* The library reads no environment variable. */
 
-/* Profiling hook: `stats_device` (device pointer to 24 uint64, or NULL to switch off) receives
+/* Profiling hook: `stats_device` (device pointer to WPT_SCHED_STATS uint64, or NULL to switch off) receives
  * the wave scheduler's statistics of launches that also count work (counters_device != NULL):
  * [0] NODE rounds [1] NODE loop iterations [2] sum of lanes active in them, then (rounds, lanes)
  * for LEAF [3,4], SHADE [5,6], NEE-END [7,8], NEW [9,10]; shader-clock ticks a wave spent in
  * traversal [11], SHADE [12], NEE-END [13], NEW [14]; [15] unused; [16..23] shader-clock ticks summed
  * over lanes per section of the SHADE block (hit record, scatter, emission, light pdf 1, light sample,
- * light pdf 2, evaluation towards the light, environment sampling / continuation). */
+ * light pdf 2, evaluation towards the light, environment sampling / continuation); [24 .. 47] executions of each stretch of
+ * the kernel's code by waves (at least one lane ran it) and [48 .. 71] by lanes, in the order of wpt_blocks.h's SEC_* (node step,
+ * leaf test, ray start, ...: tools/instruction_budget.py multiplies them with the stretches' instruction counts). */
+#define WPT_SCHED_STATS 72
 wpt_status wpt_set_scheduler_stats(unsigned long long* stats_device);
 
 /* Kernel family of the process's most recent render call (for profile matching). */

@@ -1,10 +1,15 @@
-"""usage: python tools/sched_stats.py [variant-word] [sponza]
+"""usage: python tools/sched_stats.py [variant-word] [sponza] [--json out.json]
 Prints the wave scheduler's statistics for the Cornell GGX+glass frame (GPU box)."""
 import ctypes as C
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+json_path = None
+if "--json" in sys.argv:  # for tools/instruction_budget.py
+    at = sys.argv.index("--json")
+    json_path = sys.argv[at + 1]
+    del sys.argv[at:at + 2]
 import torch
 from wurblpt_amd import device, host
 var = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -12,7 +17,7 @@ if var:
     device.lib().wpt_set_launch_config(0, var)
 sc = host.sponza_like(1920, 1080) if (len(sys.argv) > 2 and sys.argv[2] == "sponza") else host.cornell(1024, 1024, 1, 2)
 ds = device.DeviceScene(sc)
-stats = torch.zeros(24, dtype=torch.int64, device="cuda")
+stats = torch.zeros(72, dtype=torch.int64, device="cuda")
 device.lib().wpt_set_scheduler_stats.argtypes = [C.c_void_p]
 device.lib().wpt_set_scheduler_stats(C.c_void_p(stats.data_ptr()))
 spp_sqrt = 2 if len(sys.argv) > 2 else 4
@@ -24,6 +29,9 @@ if len(sys.argv) > 3 and sys.argv[3] == "pool":
     ds.render(spp_sqrt)
 s = [int(x) for x in stats.cpu().tolist()]
 n = cnt["samples"]
+if json_path:
+    import json
+    json.dump({"samples": n, "counters": cnt, "sched": s[:24], "sec_wave": s[24:48], "sec_lane": s[48:72]}, open(json_path, "w"))
 print("per sample:", {k: round(v / n, 3) for k, v in cnt.items()})
 names = ["NODE", "LEAF", "SHADE", "NEEEND", "NEW"]
 print("NODE: rounds/sample-lane %.3f iters/round %.2f avg active lanes %.1f  (lane-steps %.1f/sample)" % (s[0] * 64 / n, s[1] / max(1, s[0]), s[2] / max(1, s[1]), s[2] / n))

@@ -114,9 +114,11 @@ def render_sharded(queue, render_block, workers):
 
 
 def reduce_frame(frame, dst=0):
-    """Final gather: sum of the per-rank frames onto rank `dst` (RCCL over xGMI for CUDA tensors)."""
+    """Final gather: sum of the per-rank frames onto rank `dst` (RCCL over xGMI for CUDA tensors).  Whenever a process group
+    exists the collective runs, also over a single rank (bench.py --force-distributed: the communicator and the reduce are RCCL's
+    on the one GPU of a test box)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         if frame.is_cuda and dist.get_backend() == "gloo":
             dist.all_reduce(frame, op=dist.ReduceOp.SUM)  # gloo has no reduce for device tensors (rehearsals only)
         else:
@@ -135,7 +137,7 @@ def rank_stats(kernel_ms_per_step, reduce_ms_per_step, my_pixels, device="cpu"):
     import torch.distributed as dist
     mine = torch.tensor([float(kernel_ms_per_step), float(reduce_ms_per_step), float(my_pixels) / LANES_PER_GPU], dtype=torch.float64, device=device)
     rows = [mine]
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         rows = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(rows, mine)
     rows = [[float(x) for x in r.cpu().tolist()] for r in rows]

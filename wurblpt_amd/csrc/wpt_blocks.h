@@ -36,6 +36,12 @@ constexpr uint32_t NO_HIT = 0xffffffffu;
 enum { RAY_PATH = 0, RAY_NEE_LIGHT = 1, RAY_NEE_ENV = 2, RAY_PATH_WAITED = 3 /* a path ray's hit that has stood back once */ };
 enum { NEXT_TRACE = 0, NEXT_NEW = 1, NEXT_DONE = 2, NEXT_WAIT = 3 };
 
+/* COUNT builds: how often each stretch of the kernel's code runs, for the instruction budget (tools/instruction_budget.py multiplies
+ * them with the stretches' instruction counts from the assembly): executions by a wave (at least one lane in it) and by lanes */
+enum { SEC_NODE_STEP = 0, SEC_LEAF_TEST, SEC_BEGIN_RAY, SEC_MISS, SEC_HIT_RECORD, SEC_SCATTER_LAMBERT, SEC_SCATTER_GGX, SEC_SCATTER_GLASS, SEC_SCATTER_OTHER,
+       SEC_EMISSION, SEC_LIGHT_SAMPLE, SEC_PDF_SETUP, SEC_PDF_LIGHT, SEC_EVAL_LAMBERT, SEC_EVAL_GGX, SEC_EVAL_OTHER, SEC_NEE_SETUP, SEC_ADVANCE, SEC_NEE_END,
+       SEC_NEE_END_LIGHT, SEC_NEW_SAMPLE, SEC_PIXEL_DONE, SEC_LOOK, SEC_LOOK_INNER, SEC_COUNT };
+
 struct LaneCounters {
     uint32_t rays, nodes, leaves, pdfs, scatters;
     /* COUNT builds: shader clock this lane spent in the sections of blockShade (profiling only):
@@ -43,7 +49,25 @@ struct LaneCounters {
      * [4] light sample, [5] light pdf of the light direction, [6] evaluation towards the light,
      * [7] environment sampling / continuation */
     unsigned long long shadeClock[8];
+    uint32_t secWave[SEC_COUNT], secLane[SEC_COUNT];
 };
+constexpr LaneCounters LANE_COUNTERS_ZERO = {};
+
+/* called by every lane that is active around stretch k; `mine`: this lane runs it */
+template<bool COUNT> WPT_D void sec(LaneCounters& lc, int k, bool mine = true)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (COUNT) {
+        const unsigned long long lanes = __ballot(mine);
+        if (mine) {
+            lc.secLane[k]++;
+            const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            if ((int)lane == __ffsll((long long)lanes) - 1)
+                lc.secWave[k]++;
+        }
+    }
+#endif
+}
 
 /* ---- the cold words of a path, by slot (x, y, z, w) ----
  *   0 prng s0 s1 s2 s3        1 att                      2 ray.ri (refractiveIndex)    3 nextAtt
@@ -276,6 +300,7 @@ WPT_D void hotSpotsMeanPdfPair(const SceneView& sv, Tri4 tri4, f3 org, f3 dirA, 
     const RayAux hA = rayAux<true>(dirA), hB = rayAux<true>(dirB);
     float sumA = 0.0f, sumB = 0.0f;
     for (uint32_t i = 0; i < sv.hotspotCount; i++) {
+        sec<COUNT>(lc, SEC_PDF_LIGHT);
         const uint32_t p = sv.hotspots[i].prim;
         if ((F & FEAT_SPHERES) && sv.hotspots[i].kind == WPT_HOTSPOT_SPHERE) {
             const wpt_sphere& sp = sv.spheres[p];
@@ -451,6 +476,7 @@ template<uint32_t F, bool COUNT, class Tri4, class PS>
 WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& ps, const Candidate& best, LaneCounters& lc, int waitBelow = 0)
 {
     const bool haveEnv = (F & FEAT_ENVMAP) && sv.envType != WPT_ENV_NONE;
+    sec<COUNT>(lc, SEC_MISS, best.prim == NO_HIT);
     if (best.prim == NO_HIT) {
         if (haveEnv) {
             f4 rad = mul(ps.get4(SLOT_ATT), envL(sv, ps.d));
@@ -477,6 +503,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
     };
     if (COUNT)
         tSection = clock64();
+    sec<COUNT>(lc, SEC_HIT_RECORD);
     Hit h = finishHit<F>(sv, best, ray.o, ray.d, ps.time, tri4);
     const wpt_material& m = resolveMaterial<F>(sv, h.material, h);
     if ((F & ~(FEAT_GGX | FEAT_GLASS)) == 0 && waitBelow > 0) { /* the all-features builds have no register to spare for it */
@@ -503,6 +530,11 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
     if (COUNT)
         lc.scatters++;
     section(0);
+    sec<COUNT>(lc, SEC_SCATTER_LAMBERT, m.type == WPT_MAT_LAMBERTIAN);
+    sec<COUNT>(lc, SEC_SCATTER_GGX, m.type == WPT_MAT_GGX);
+    sec<COUNT>(lc, SEC_SCATTER_GLASS, m.type == WPT_MAT_GLASS || m.type == WPT_MAT_MIRROR);
+    sec<COUNT>(lc, SEC_SCATTER_OTHER, m.type != WPT_MAT_LAMBERTIAN && m.type != WPT_MAT_GGX && m.type != WPT_MAT_GLASS && m.type != WPT_MAT_MIRROR && m.type != WPT_MAT_LIGHT_DIFFUSE);
+    sec<COUNT>(lc, SEC_EMISSION);
     Prng prng = loadPrng(ps);
 #ifdef WPT_MATERIAL_CACHE
     /* what scatter reads from the material's textures is kept for the evaluation towards the light (the wavefront shade
@@ -534,6 +566,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
         else
             nextAtt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+    sec<COUNT>(lc, SEC_LIGHT_SAMPLE, sr.type == SCATTER_RANDOM && sv.hotspotCount > 0);
     if (sr.type == SCATTER_RANDOM && sv.hotspotCount > 0) {
         /* light sampling with MIS (wurblpt.hpp:179-220).  The pdf of the scattered direction draws nothing from the
          * generator, so it can wait for the direction towards the light and be evaluated together with that one's. */
@@ -559,13 +592,18 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
         }
         section(4);
         float hotSpotsPdf, directPdf;
+        sec<COUNT>(lc, SEC_PDF_SETUP);
         hotSpotsMeanPdfPair<F, COUNT>(sv, tri4, h.p, sr.dir, directDir, ps, lc, hotSpotsPdf, directPdf);
         nextAtt = sclr(nextAtt, powerHeuristicWeight(sr.pdf, hotSpotsPdf));
         section(5);
+        sec<COUNT>(lc, SEC_EVAL_LAMBERT, directPdf > 0.0f && m.type == WPT_MAT_LAMBERTIAN);
+        sec<COUNT>(lc, SEC_EVAL_GGX, directPdf > 0.0f && m.type == WPT_MAT_GGX);
+        sec<COUNT>(lc, SEC_EVAL_OTHER, directPdf > 0.0f && m.type != WPT_MAT_LAMBERTIAN && m.type != WPT_MAT_GGX);
         if (directPdf > 0.0f) {
             float dpdf;
             f4 directAtt;
             materialEval<F>(sv, m, ray, h, directDir, directAtt, dpdf, mc);
+            sec<COUNT>(lc, SEC_NEE_SETUP, dpdf > 0.0f);
             if (dpdf > 0.0f) {
                 const f4 neeFactor = sclr(divs(mul(att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
                 Slot nee;
@@ -608,6 +646,7 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
      * carries the incoming ray's index unchanged (material_lambertian.hpp:83, material_ggx.hpp:224,
      * material_modphong.hpp:307), so the slot already holds the value to continue with, also while a
      * next-event ray is in flight; only explicit scattering (glass, mirror, transparent ModPhong) sets it. */
+    sec<COUNT>(lc, SEC_ADVANCE);
     ps.o = h.p;
     if (sr.type == SCATTER_EXPLICIT)
         ps.set4(SLOT_RI, sr.ri);

@@ -522,8 +522,11 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
             float sk, wd;
             memcpy(&sk, &skip, 4);
             memcpy(&wd, &word, 4);
-            dev[2 * size_t(place[i])] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0]);
+            dev[2 * size_t(place[i])] = make_float4(nd.lo[0], nd.hi[0], nd.lo[1], nd.lo[2]); /* nodeLo / nodeHi (wpt_device.h) */
             dev[2 * size_t(place[i]) + 1] = make_float4(nd.hi[1], nd.hi[2], sk, wd);
+            for (int a = 0; a < 3; a++)
+                if (nd.lo[a] != nd.lo[a] || nd.hi[a] != nd.hi[a])
+                    s->view.boxesMayBeNan = 1u;
         }
         UP(uploadArray(s, dev.data(), dev.size(), &nodes));
         const bool inLds = size_t(n) * 32 + size_t(desc->tri_count) * 48 <= LDS_SCENE_MAX_BYTES;
@@ -941,7 +944,7 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     args.orderCount = nullptr;
     /* the wide walk where the scene has that form (wpt_set_walk before the upload): product launches of the kernels that fetch
      * the scene from HBM; counting launches and moving scenes walk the binary tree */
-    const bool wide = scene->view.wideNodes != nullptr && !count && !anim && !(basic && !rgl);
+    const bool wide = scene->view.wideNodes != nullptr && !count && !anim; /* (only scenes fetched from HBM have the form) */
     g_kernelName.store(wide ? "wpt_pathtrace, wide walk" : nullptr, std::memory_order_relaxed);
     auto launch = [&](const wptk::KernelArgs& a) {
         if (anim) {
@@ -971,10 +974,10 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
         } else {
             if (basic && lds)
                 launchBasicLds(a, grid, ldsBytes + (a.materialsInLds ? size_t(scene->view.materialCount) * sizeof(wpt_material) : 0), stream);
+            else if (wide) /* also for the basic feature set: the wide walk exists in the all-features instantiations */
+                launchFullWide(a, grid, stream);
             else if (basic)
                 launchBasic(a, grid, stream);
-            else if (wide)
-                launchFullWide(a, grid, stream);
             else
                 launchFull(a, grid, stream);
         }

@@ -401,20 +401,47 @@ WPT_D bool boxTestChains(float t0x, float t0y, float t0z, float t1x, float t1y, 
 /* AABB::mayHit.  When none of the six slab distances is NaN the comparison chains are plain
  * minima and maxima (the sign of a zero cannot change the final comparison), which the hardware
  * has as single instructions (v_min_f32 / v_max3_f32) where a compare + select pair costs three
- * issue slots; the rare lanes with a NaN take the chains as written. */
-WPT_D bool boxTest(f3 lo, f3 hi, f3 org, f3 inv, float amin, float amax)
+ * issue slots; the rare lanes with a NaN take the chains as written.
+ * CHECK = false leaves the test for NaN out: for rays whose slab distances are numbers whatever the box (rayMayNan below). */
+typedef float v2f __attribute__((ext_vector_type(2)));
+template<bool CHECK = true> WPT_D bool boxTest(f3 lo, f3 hi, f3 org, f3 inv, float amin, float amax)
 {
-    const float t0x = (lo.x - org.x) * inv.x, t0y = (lo.y - org.y) * inv.y, t0z = (lo.z - org.z) * inv.z;
-    const float t1x = (hi.x - org.x) * inv.x, t1y = (hi.y - org.y) * inv.y, t1z = (hi.z - org.z) * inv.z;
+    /* the six distances as three pairs, the way the node record holds the bounds (nodeLo / nodeHi): one packed subtract and
+     * one packed multiply per pair, each element the same IEEE operation as (bound - origin) * reciprocal */
+    const v2f tx = (v2f { lo.x, hi.x } - v2f { org.x, org.x }) * v2f { inv.x, inv.x };
+    const v2f t0yz = (v2f { lo.y, lo.z } - v2f { org.y, org.z }) * v2f { inv.y, inv.z };
+    const v2f t1yz = (v2f { hi.y, hi.z } - v2f { org.y, org.z }) * v2f { inv.y, inv.z };
+    const float t0x = tx.x, t1x = tx.y, t0y = t0yz.x, t0z = t0yz.y, t1y = t1yz.x, t1z = t1yz.y;
     const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
             __builtin_fmaxf(__builtin_fminf(t0z, t1z), amin));
     const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
             __builtin_fminf(__builtin_fmaxf(t0z, t1z), amax));
     bool hit = tmin <= tmax;
-    if (__builtin_expect(__builtin_isunordered(t0x, t1x) || __builtin_isunordered(t0y, t1y) || __builtin_isunordered(t0z, t1z), 0))
+    if (CHECK && __builtin_expect(__builtin_isunordered(t0x, t1x) || __builtin_isunordered(t0y, t1y) || __builtin_isunordered(t0z, t1z), 0))
         hit = boxTestChains(t0x, t0y, t0z, t1x, t1y, t1z, amin, amax);
     return hit;
 }
+
+/* Can a slab distance (box - origin) * (1 / direction) of this ray be NaN for a box whose coordinates are numbers?  Only as
+ * 0 * inf or inf - inf: a reciprocal that is zero, infinite or NaN (a direction component that is infinite, zero -- also a
+ * denormal whose reciprocal overflows -- or NaN), or an origin that is not finite.  For every other ray the six distances are
+ * numbers (possibly infinite), and the walks skip the test for NaN per box.  (A box coordinate that is NaN itself: SceneView::
+ * boxesMayBeNan, found at upload, keeps the test for every ray.) */
+constexpr int RAY_MAY_NAN = 0x40; /* in RayAux::k, above the three axes */
+WPT_D bool rayMayNan(f3 org, f3 inv)
+{
+    const float inf = __builtin_inff();
+    const bool numbers = __builtin_fabsf(inv.x) < inf && __builtin_fabsf(inv.y) < inf && __builtin_fabsf(inv.z) < inf
+            && inv.x != 0.0f && inv.y != 0.0f && inv.z != 0.0f
+            && __builtin_fabsf(org.x) < inf && __builtin_fabsf(org.y) < inf && __builtin_fabsf(org.z) < inf;
+    return !numbers;
+}
+
+/* the device's node record, two quadwords: lo.x hi.x lo.y lo.z | hi.y hi.z skip word -- the x bounds side by side, the y and z
+ * bounds as pairs, so that the packed subtract / multiply of the box test take them as they come (three register moves per
+ * node less than lo.xyz hi.x | hi.yz) */
+WPT_D f3 nodeLo(float4 n0, float4 n1) { (void)n1; return mk3(n0.x, n0.z, n0.w); }
+WPT_D f3 nodeHi(float4 n0, float4 n1) { return mk3(n0.y, n1.x, n1.y); }
 
 /* feature bits: what a kernel instantiation can evaluate */
 enum {
@@ -445,7 +472,7 @@ struct Hit {
 };
 
 struct SceneView {
-    const float4* nodes;     /* 2 x float4 per node: lo.xyz hi.x | hi.yz skip prim (device form) */
+    const float4* nodes;     /* 2 x float4 per node: lo.x hi.x lo.y lo.z | hi.y hi.z skip word (device form, nodeLo / nodeHi) */
     const float4* triGeom;   /* 3 x float4 per triangle */
     const float4* triAttr;   /* 6 x float4 per triangle */
     const wpt_instance* instances;
@@ -463,6 +490,7 @@ struct SceneView {
     const int32_t* envMs;
     const float* envMcs;
     uint32_t nodeCount, triCount;
+    uint32_t boxesMayBeNan;       /* 1: a box coordinate of the tree is NaN (found at upload): every box test checks its slab distances */
     uint32_t hotspotCount;
     uint32_t envType, envCompat;
     int32_t envTex, envN;

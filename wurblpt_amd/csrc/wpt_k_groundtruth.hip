@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) wpt_ground_truth_kernel(const GroundTruth
         const float4 n0 = sv.nodes[2 * node], n1 = sv.nodes[2 * node + 1];
         const uint32_t skip = __float_as_uint(n1.z);
         const uint32_t prim = __float_as_uint(n1.w);
-        const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.o, aux.inv, args.par.min_hit_distance, amax);
+        const bool hit = boxTest(nodeLo(n0, n1), nodeHi(n0, n1), ps.o, aux.inv, args.par.min_hit_distance, amax);
         if (hit && prim < NODE_CHILD) {
             Candidate c;
             bool accepted;

@@ -150,9 +150,9 @@ enum { S_NODE = 0, S_LEAF = 1, S_SHADE = 2, S_NEEEND = 3, S_NEW = 4, S_DONE = 5,
  * Checked on the CPU leaf test for leaf test against BVH::hit (oracle/wpt_oracle.cpp::bvhTraverseWide) and on the GPU bit for
  * bit against the oracle.  The stack cannot overflow: wpt_scene_upload offers the wide form only for trees whose worst case
  * fits WIDE_STACK entries. */
-constexpr uint32_t WIDE_STACK = 64;          /* pending children per lane (8 bytes each, scratch memory) */
+constexpr uint32_t WIDE_STACK = 96;          /* pending children per lane (8 bytes each, scratch memory): the 10 M triangle scene's worst case is 66 */
 constexpr uint32_t WIDE_NONE = 0xffffffffu;  /* no child (also: an empty entry of a wide node) */
-constexpr int RAY_WALK_BINARY = 0x40;        /* in RayAux::k: this ray walks the binary tree */
+constexpr int RAY_WALK_BINARY = 0x80;        /* in RayAux::k: this ray walks the binary tree although its slab distances are numbers (its bound has grown) */
 
 template<uint32_t F, bool COUNT, bool LDSSCENE, int OCC, bool WIDE = false>
 __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         return have;
     };
     const bool inBlock = startPixel(blockIdx.x * WG + threadIdx.x);
-    LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
+    LaneCounters lc = LANE_COUNTERS_ZERO;
     /* wave-level scheduler statistics (COUNT builds): rounds and lane counts per state */
     unsigned long long sched[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int state = inBlock ? S_NEW : S_DONE;
@@ -274,14 +274,11 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
         amax = k_maxval;
         best.prim = NO_HIT;
         state = S_NODE;
+        /* rays for which a slab distance can be NaN (a zero direction component, say) are rare; only they test for it per box,
+         * and in WIDE kernels they walk the binary tree */
+        if (rayMayNan(ps.o, aux.inv))
+            aux.k |= RAY_MAY_NAN;
         if (WIDE) {
-            /* slab distances are numbers for every finite box iff the reciprocals are finite and not zero and the origin is
-             * finite; other rays walk the binary tree */
-            const bool numbers = __builtin_fabsf(aux.inv.x) < __builtin_inff() && __builtin_fabsf(aux.inv.y) < __builtin_inff()
-                    && __builtin_fabsf(aux.inv.z) < __builtin_inff() && aux.inv.x != 0.0f && aux.inv.y != 0.0f && aux.inv.z != 0.0f
-                    && __builtin_fabsf(ps.o.x) < __builtin_inff() && __builtin_fabsf(ps.o.y) < __builtin_inff() && __builtin_fabsf(ps.o.z) < __builtin_inff();
-            if (!numbers)
-                aux.k |= RAY_WALK_BINARY;
             /* the root's wide node, admitted under any bound (the root's own box decides nothing its children do not) */
             curRef = NODE_CHILD | 0u;
             curEntry = 0.0f;
@@ -330,6 +327,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
          * blocks (SHADE, NEE-END, NEW) run when they are well filled, or when no traversal work
          * is left in the wave.  Waiting lanes lose nothing but time: every lane still executes
          * its own operations in order. */
+        sec<COUNT>(lc, SEC_LOOK);
         const int cTrav = __popcll(__ballot(state == S_NODE || state == S_LEAF));
         const int cShade = __popcll(__ballot(state == S_SHADE));
         const int cNee = __popcll(__ballot(state == S_NEEEND));
@@ -373,6 +371,8 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             /* the node a lane will test next is known one iteration ahead: its two quadwords are requested at the end
              * of the iteration before, so that the fetch runs behind the loop's ballots and branches */
             float4 pn0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pn1 = pn0;
+            /* does any ray of the wave need its slab distances tested for NaN? (rays start in the long round only) */
+            const bool nanPossible = sv.boxesMayBeNan != 0 || __ballot((aux.k & RAY_MAY_NAN) != 0 && (state == S_NODE || state == S_LEAF)) != 0;
             /* AABB::mayHit + the stackless form of BVH::hit's walk: one node step of the lanes in state NODE (WIDE: of those among
              * them that walk the binary tree) */
                 auto binaryStep = [&]() {
@@ -381,7 +381,9 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 const float4 n0 = PREFETCH ? pn0 : node4(2 * node), n1 = PREFETCH ? pn1 : node4(2 * node + 1);
                 const uint32_t skip = __float_as_uint(n1.z);
                 const uint32_t word = __float_as_uint(n1.w);
-                const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ps.o, aux.inv, par.min_hit_distance, amax);
+                bool hit = boxTest<false>(nodeLo(n0, n1), nodeHi(n0, n1), ps.o, aux.inv, par.min_hit_distance, amax);
+                if (nanPossible) /* wave-uniform, rarely true */
+                    hit = boxTest<true>(nodeLo(n0, n1), nodeHi(n0, n1), ps.o, aux.inv, par.min_hit_distance, amax);
                 /* select form of: hit & inner -> first child; hit & leaf -> test it, then skip; else -> skip */
                 const bool inner = word >= NODE_CHILD;
                 const bool toLeaf = hit && !inner;
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 pn1 = node4(2 * node + 1);
             }
             for (;;) {
+                sec<COUNT>(lc, SEC_LOOK_INNER);
                 const int nNode = __popcll(__ballot(state == S_NODE));
                 const int nLeaf = __popcll(__ballot(state == S_LEAF));
                 if (nNode + nLeaf < leaveBelow)
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         sched[3]++;
                         sched[4] += nLeaf;
                     }
+                    sec<COUNT>(lc, SEC_LEAF_TEST, state == S_LEAF);
                     if (state == S_LEAF) {
                         /* HitableTriangle::hit, candidate part (hitable_triangle.hpp:189-271); the walk already knows where
                          * it goes on (a leaf's subtree is the leaf itself) */
@@ -437,13 +441,13 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         /* WIDE: a hit whose stored distance lies beyond the bound it was accepted under (the two are separate
                          * comparisons in the reference) makes the bound grow: children dropped under the smaller bound may be
                          * due after all, so this ray starts again from the root in the binary walk */
-                        const bool grown = WIDE && accepted && !(aux.k & RAY_WALK_BINARY) && !(c.a <= amax);
+                        const bool grown = WIDE && accepted && !(aux.k & (RAY_MAY_NAN | RAY_WALK_BINARY)) && !(c.a <= amax);
                         if (accepted) {
                             c.prim = leafPrim;
                             best = c;
                             amax = c.a;
                         }
-                        if (WIDE && !(aux.k & RAY_WALK_BINARY))
+                        if (WIDE && !(aux.k & (RAY_MAY_NAN | RAY_WALK_BINARY)))
                             state = curRef == WIDE_NONE ? endOfRayState() : (int)S_NODE;
                         else
                             state = node >= nodeCount ? endOfRayState() : (int)S_NODE;
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                         sched[2] += nNode;
                     }
                     if constexpr (WIDE) {
-                        if (state == S_NODE && !(aux.k & RAY_WALK_BINARY)) {
+                        if (state == S_NODE && !(aux.k & (RAY_MAY_NAN | RAY_WALK_BINARY))) {
                             /* The child whose turn it is: admitted if its entry distance is within the bound of this moment
                              * (the reference's test at its turn); a leaf goes to its test, an inner node's four entries are
                              * tested under the bound, the first the ray passes through is next, the others wait on the stack in
@@ -520,15 +524,17 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                                 state = endOfRayState();
                         }
                         /* the few rays that walk the binary tree (a NaN slab distance is possible, or the bound has grown) */
-                        if (__ballot(state == S_NODE && (aux.k & RAY_WALK_BINARY)) != 0) {
-                            if (state == S_NODE && (aux.k & RAY_WALK_BINARY))
+                        if (__ballot(state == S_NODE && (aux.k & (RAY_MAY_NAN | RAY_WALK_BINARY))) != 0) {
+                            if (state == S_NODE && (aux.k & (RAY_MAY_NAN | RAY_WALK_BINARY)))
                                 binaryStep();
                         }
                     } else {
 #pragma unroll
-                        for (int step = 0; step < STEPS; step++)
+                        for (int step = 0; step < STEPS; step++) {
+                            sec<COUNT>(lc, SEC_NODE_STEP, state == S_NODE);
                             if (state == S_NODE)
                                 binaryStep();
+                        }
                     }
                 }
             }
@@ -552,6 +558,8 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 sched[7]++;
                 sched[8] += cNee;
             }
+            sec<COUNT>(lc, SEC_NEE_END, state == S_NEEEND);
+            sec<COUNT>(lc, SEC_NEE_END_LIGHT, state == S_NEEEND && ps.rayKind == RAY_NEE_LIGHT && best.prim == ps.getW(SLOT_NEE));
             if (state == S_NEEEND) /* the next-event ray's contribution, then the path continues */
                 afterBlock(blockNeeEnd<F>(sv, par, tri4, ps, best));
             if (COUNT)
@@ -564,9 +572,11 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 sched[9]++;
                 sched[10] += __popcll(__ballot(state == S_NEW));
             }
+            sec<COUNT>(lc, SEC_NEW_SAMPLE, state == S_NEW);
             if (state == S_NEW) { /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
                 const bool passEnds = firstPass && (ps.getW(SLOT_ACC) >> 16) >= args.rowStop;
                 const int next = passEnds ? (int)NEXT_DONE : blockNew<F>(fa, ps, sv);
+                sec<COUNT>(lc, SEC_PIXEL_DONE, next == NEXT_DONE);
                 if (next == NEXT_DONE) {
                     const uint32_t pxy = ps.getW(SLOT_SRDIR);
                     const size_t at = (size_t)(pxy >> 16) * args.width + (pxy & 0xffffu);
@@ -589,8 +599,11 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
             if (COUNT) /* shader clock spent per kind of block: [11] traversal [12] shade [13] nee-end [14] new */
                 sched[14] += (unsigned long long)(clock64() - tBlock);
         }
-        if (pick != S_NODE && state == S_START)
-            beginRay();
+        if (pick != S_NODE) {
+            sec<COUNT>(lc, SEC_BEGIN_RAY, state == S_START);
+            if (state == S_START)
+                beginRay();
+        }
     }
 
     if (COUNT && args.counters && inBlock) {
@@ -608,6 +621,14 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
     if (COUNT && args.schedStats && inBlock) { /* [16..23]: lane-weighted clock per section of the SHADE block */
         for (int i = 0; i < 8; i++)
             atomicAdd(args.schedStats + 16 + i, lc.shadeClock[i]);
+    }
+    if (COUNT && args.schedStats) { /* [24 ..]: executions of each stretch of code by waves, then by lanes (SEC_COUNT each) */
+        for (int i = 0; i < SEC_COUNT; i++) {
+            if (lc.secWave[i])
+                atomicAdd(args.schedStats + 24 + i, (unsigned long long)lc.secWave[i]);
+            if (lc.secLane[i])
+                atomicAdd(args.schedStats + 24 + SEC_COUNT + i, (unsigned long long)lc.secLane[i]);
+        }
     }
 }
 

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                     const float4 n0 = pn0, n1 = pn1;
                     const uint32_t skip = __float_as_uint(n1.z);
                     const uint32_t word = __float_as_uint(n1.w);
-                    const bool hit = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, aux.inv, amin, amax);
+                    const bool hit = boxTest(nodeLo(n0, n1), nodeHi(n0, n1), o, aux.inv, amin, amax);
                     const bool inner = word >= NODE_CHILD;
                     const bool toLeaf = hit && !inner;
                     leafPrim = toLeaf ? word : leafPrim;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
         }
     }
     if (have) {
-        LaneCounters lc = { 0, 0, 0, 0, 0, { 0, 0, 0, 0, 0, 0, 0, 0 } };
+        LaneCounters lc = LANE_COUNTERS_ZERO;
         if (!INIT) {
             if (ps.rayKind == RAY_PATH)
                 next = blockShade<F, false>(sv, par, tri4, ps, best, lc, 0); /* tracePath, one path component (wurblpt.hpp:131-252) */
