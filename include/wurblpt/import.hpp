@@ -21,6 +21,7 @@
 #pragma once
 
 #include <cstdio>
+#include <array>
 #include <map>
 #include <set>
 #include <string>
@@ -65,7 +66,25 @@ inline ArrayContainer toNormalMap(const ArrayContainer& bumpMap, float bumpScali
     return normalMap;
 }
 
-/* import.hpp:93-169: one Texture per (file, factor, offset, linearisation, bump scaling) */
+/* Does every texel of an 8-bit image carry one grey level in its first three components?  (Images with fewer than three
+ * components are grey by construction.)  Height maps are sometimes stored as RGB files; the importer tells them from normal
+ * maps by this (import.hpp:140-160). */
+inline bool isGreyImage(const ArrayContainer& img)
+{
+    if (img.componentCount() < 3)
+        return true;
+    const size_t n = img.elementCount();
+    for (size_t e = 0; e < n; e++) {
+        const uint8_t* t = img.get<uint8_t>(e);
+        if (!(t[0] == t[1] && t[1] == t[2]))
+            return false;
+    }
+    return true;
+}
+
+/* The Texture an MTL statement names: one per (file, factor, offset, linearisation, bump scaling), kept in textureMap
+ * (import.hpp:93-169).  bumpScaling > 0: the file is a bump or normal map -- a grey one is a height map and becomes a normal
+ * map first.  Files that could not be read (empty containers) and bump maps that are not 8-bit get constant stand-ins. */
 inline Texture* importTexture(std::map<std::string, Texture*>& textureMap, const std::map<std::string, ArrayContainer>& textureFileMap,
         const std::string& name, const float factor[3], const float offset[3], int* componentCount = nullptr,
         LinearizeSRGBType linearizeSRGBType = LinearizeSRGB_Auto, float bumpScaling = -1.0f /* < 0: not a bump map */)
@@ -74,43 +93,29 @@ inline Texture* importTexture(std::map<std::string, Texture*>& textureMap, const
     const std::string cacheName = name + "_factor=" + std::to_string(factor[0]) + ',' + std::to_string(factor[1])
         + "_offset=" + std::to_string(offset[0]) + ',' + std::to_string(offset[1]) + "_linsrgb=" + lin
         + "_bumpscal=" + std::to_string(bumpScaling);
-    auto it = textureMap.find(cacheName);
-    if (it != textureMap.end())
-        return it->second;
-    ArrayContainer img = textureFileMap.at(name);
-    Texture* tex;
-    if (img.elementCount() == 0) {
-        tex = new TextureConstant(vec4(0.5f));
-        fprintf(stderr, "    texture %s: replaced with dummy texture\n", cacheName.c_str());
-    } else {
-        if (componentCount)
-            *componentCount = int(img.componentCount());
-        if (bumpScaling > 0.0f) {
-            if (img.componentType() != uint8) {
-                tex = new TextureConstant(vec4(0.5f, 0.5f, 1.0f, 0.0f));
-                fprintf(stderr, "    texture %s: cannot handle a bump/normal map that is not uint8, replaced with dummy texture\n", cacheName.c_str());
-            } else {
-                /* grey bump maps are sometimes stored as RGB: a map is a bump map unless a texel has colour */
-                bool imageIsBumpMap = true;
-                if (img.componentCount() >= 3) {
-                    for (size_t e = 0; e < img.elementCount(); e++) {
-                        const uint8_t* elem = img.get<uint8_t>(e);
-                        if (elem[0] != elem[1] || elem[0] != elem[2] || elem[1] != elem[2]) {
-                            imageIsBumpMap = false;
-                            break;
-                        }
-                    }
-                }
-                if (imageIsBumpMap)
-                    img = toNormalMap(img, bumpScaling);
-                tex = createTextureImage(img, linearizeSRGBType, vec2(factor[0], factor[1]), vec2(offset[0], offset[1]));
-            }
-        } else {
-            tex = createTextureImage(img, linearizeSRGBType, vec2(factor[0], factor[1]), vec2(offset[0], offset[1]));
-        }
-    }
-    textureMap.insert(std::pair<std::string, Texture*>(cacheName, tex));
-    return tex;
+    const auto known = textureMap.find(cacheName);
+    if (known != textureMap.end())
+        return known->second;
+    auto keep = [&](Texture* tex) {
+        textureMap.emplace(cacheName, tex);
+        return tex;
+    };
+    auto standIn = [&](const vec4& value, const char* why) {
+        fprintf(stderr, "    texture %s: %sreplaced with dummy texture\n", cacheName.c_str(), why);
+        return keep(new TextureConstant(value));
+    };
+    const ArrayContainer& file = textureFileMap.at(name);
+    if (file.elementCount() == 0)
+        return standIn(vec4(0.5f), "");
+    if (componentCount)
+        *componentCount = int(file.componentCount());
+    const bool bump = bumpScaling > 0.0f;
+    if (bump && file.componentType() != uint8)
+        return standIn(vec4(0.5f, 0.5f, 1.0f, 0.0f), "cannot handle a bump/normal map that is not uint8, ");
+    const vec2 f(factor[0], factor[1]), o(offset[0], offset[1]);
+    if (bump && isGreyImage(file))
+        return keep(createTextureImage(toNormalMap(file, bumpScaling), linearizeSRGBType, f, o));
+    return keep(createTextureImage(file, linearizeSRGBType, f, o));
 }
 
 constexpr unsigned int ImportBitDisableLightSources = (1 << 0); /* import.hpp:187-196 */
@@ -118,6 +123,59 @@ constexpr unsigned int ImportBitDisableHotSpots = (1 << 1);
 constexpr unsigned int ImportBitTwoSidedMaterials = (1 << 2);
 constexpr unsigned int ImportBitInvertedTf = (1 << 3);
 constexpr unsigned int ImportBitWithGlass = (1 << 4);
+
+/* The vertices of one part of a shape (its faces of one material), de-indexed: an OBJ corner is a triple (position, normal,
+ * texture coordinate) of independent indices, a Mesh wants one index per distinct corner.  add() hands every triple its
+ * number in order of first appearance (the reference's tuple map, import.hpp:416-464).  A part keeps its normals / texture
+ * coordinates only as long as every corner so far had them; from the first corner without (or with a normal that is not a
+ * direction) the arrays stop growing and the caller recomputes or drops them. */
+struct ShapeVertices {
+    enum Status { Ok, InvalidNormal /* a warning: normals will be recomputed */, BadPosition, BadAttribute };
+    const ObjData& obj;
+    std::map<std::array<int, 3>, unsigned int> number;
+    std::vector<vec3> positions, normals;
+    std::vector<vec2> texcoords;
+    std::vector<unsigned int> indices;
+    bool haveNormals = true, haveTexCoords = true;
+
+    explicit ShapeVertices(const ObjData& o) : obj(o) {}
+
+    Status add(const ObjIndex& corner)
+    {
+        const std::array<int, 3> key = { corner.vertex, corner.normal, corner.texcoord };
+        const auto seen = number.find(key);
+        if (seen != number.end()) {
+            indices.push_back(seen->second);
+            return Ok;
+        }
+        if (corner.vertex < 0 || size_t(corner.vertex) >= obj.vertices.size() / 3)
+            return BadPosition;
+        Status status = Ok;
+        positions.push_back(vec3(obj.vertices.data() + 3 * corner.vertex));
+        haveNormals = haveNormals && corner.normal >= 0;
+        haveTexCoords = haveTexCoords && corner.texcoord >= 0;
+        if (haveNormals) {
+            if (size_t(corner.normal) >= obj.normals.size() / 3)
+                return BadAttribute;
+            const vec3 n = vec3(obj.normals.data() + 3 * corner.normal);
+            if (all(isfinite(n)) && dot(n, n) >= epsilon) {
+                normals.push_back(normalize(n));
+            } else {
+                haveNormals = false;
+                status = InvalidNormal;
+            }
+        }
+        if (haveTexCoords) {
+            if (size_t(corner.texcoord) >= obj.texcoords.size() / 2)
+                return BadAttribute;
+            texcoords.push_back(vec2(obj.texcoords.data() + 2 * corner.texcoord));
+        }
+        const unsigned int fresh = unsigned(number.size());
+        number.emplace(key, fresh);
+        indices.push_back(fresh);
+        return status;
+    }
+};
 
 /* MaterialGlass::transparentColorToAbsorption (material_glass.hpp:154-165) */
 inline vec3 transparentColorToAbsorption(const vec3& c, float targetDistance = 0.01f)
@@ -246,68 +304,34 @@ inline bool importIntoScene(Scene& scene, const std::string& filename, const Tra
         }
     }
 
-    /* the shapes: one MeshInstance per (material, shape); serial, see the header of this file */
+    /* the shapes: one MeshInstance per (material, shape); serial, see the header of this file (import.hpp:404-498) */
     Material* nullMaterial = scene.take(new MaterialLambertian(vec4(0.5f)));
     for (int matId = -1; matId < int(materials.size()); matId++) {
         for (size_t s = 0; s < obj.shapes.size(); s++) {
             const ObjShape& shape = obj.shapes[s];
-            std::map<std::tuple<int, int, int>, unsigned int> indexTupleMap;
-            std::vector<vec3> positions, normals;
-            std::vector<vec2> texcoords;
-            std::vector<unsigned int> indices;
-            bool haveNormals = true, haveTexCoords = true;
+            ShapeVertices part(obj);
             for (size_t i = 0; i < shape.indices.size(); i++) {
                 if (shape.materialIds[i / 3] != matId)
                     continue;
-                const ObjIndex& index = shape.indices[i];
-                const int vi = index.vertex, ni = index.normal, ti = index.texcoord;
-                const std::tuple<int, int, int> indexTuple = std::make_tuple(vi, ni, ti);
-                auto it = indexTupleMap.find(indexTuple);
-                if (it != indexTupleMap.end()) {
-                    indices.push_back(it->second);
-                    continue;
-                }
-                const unsigned int newIndex = indexTupleMap.size();
-                if (vi < 0 || size_t(vi) >= obj.vertices.size() / 3) {
+                const ShapeVertices::Status st = part.add(shape.indices[i]);
+                if (st == ShapeVertices::BadPosition)
                     fprintf(stderr, "%s: vertex index out of range in shape '%s'\n", filename.c_str(), shape.name.c_str());
+                if (st == ShapeVertices::InvalidNormal)
+                    fprintf(stderr, "      warning: invalid normals in shape %zu '%s'\n", s, shape.name.c_str());
+                if (st == ShapeVertices::BadPosition || st == ShapeVertices::BadAttribute)
                     return false;
-                }
-                positions.push_back(vec3(obj.vertices.data() + 3 * vi));
-                if (ni < 0)
-                    haveNormals = false;
-                if (ti < 0)
-                    haveTexCoords = false;
-                if (haveNormals) {
-                    if (size_t(ni) >= obj.normals.size() / 3)
-                        return false;
-                    const vec3 n = vec3(obj.normals.data() + 3 * ni);
-                    if (!all(isfinite(n)) || dot(n, n) < epsilon) {
-                        fprintf(stderr, "      warning: invalid normals in shape %zu '%s'\n", s, shape.name.c_str());
-                        haveNormals = false;
-                    } else {
-                        normals.push_back(normalize(n));
-                    }
-                }
-                if (haveTexCoords) {
-                    if (size_t(ti) >= obj.texcoords.size() / 2)
-                        return false;
-                    texcoords.push_back(vec2(obj.texcoords.data() + 2 * ti));
-                }
-                indices.push_back(newIndex);
-                indexTupleMap.insert(std::make_pair(indexTuple, newIndex));
             }
-            if (indices.size() == 0)
+            if (part.indices.empty())
                 continue;
-            if (!haveNormals)
-                normals = computeNormals(positions, indices);
-            if (!haveTexCoords)
-                texcoords.clear();
-            Material* mat = matId < 0 ? nullMaterial : materials[matId];
-            const bool matIsLight = matId < 0 ? false : bool(materialIsLight[matId]);
-            const bool matWantsTangents = matId < 0 ? false : bool(materialWantsTangents[matId]);
-            Mesh* mesh = new Mesh(positions, normals, texcoords, indices, transformation, matWantsTangents);
-            scene.take(mesh);
-            scene.take(new MeshInstance(mesh, mat), (matIsLight && !(importBits & ImportBitDisableHotSpots)) ? HotSpot : ColdSpot);
+            if (!part.haveNormals)
+                part.normals = computeNormals(part.positions, part.indices);
+            if (!part.haveTexCoords)
+                part.texcoords.clear();
+            const bool real = matId >= 0;
+            Mesh* mesh = scene.take(new Mesh(part.positions, part.normals, part.texcoords, part.indices, transformation,
+                        real && materialWantsTangents[matId]));
+            const bool hot = real && materialIsLight[matId] && !(importBits & ImportBitDisableHotSpots);
+            scene.take(new MeshInstance(mesh, real ? materials[matId] : nullMaterial), hot ? HotSpot : ColdSpot);
         }
     }
     fprintf(stderr, "%s: import done\n", filename.c_str());
