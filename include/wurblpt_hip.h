@@ -434,8 +434,8 @@ wpt_status wpt_set_launch_config(uint32_t threads_per_group, uint32_t variant);
 wpt_status wpt_set_top_nodes(uint32_t nodes);
 /* How rays walk the tree (results do not depend on it; process-global like the hooks above, set it before uploading and
  * rendering, not while other threads render):
- *   WPT_WALK_WIDE           scenes uploaded from now on whose tree is fetched from HBM also get the tree collapsed by one level
- *                           (128-byte nodes that hold the boxes of a node's four grandchildren), and product launches walk that:
+ *   WPT_WALK_WIDE           scenes uploaded from now on also get the tree collapsed by one level (128-byte nodes that hold the
+ *                           boxes of a node's four grandchildren), and product launches that fetch the scene from HBM walk that:
  *                           four box tests per fetch, leaf tests in BVH::hit's order (bvh.hpp:277-311), the same hits bit for bit
  *                           (wpt_pathtrace.inc.h says why; rays for which the argument does not hold walk the binary tree).
  *                           Trees with a non-finite box, a child's box outside its parent's, or a worst case of more than 96

@@ -64,7 +64,14 @@ def main():
     stats = json.load(open(sys.argv[2]))
     override = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else {}
     where = guess(bbs)
-    where.update(override)
+    # map.json: {"ranges": [[first label, last label, stretch], ...]} in kernel order (labels without the ".LBB0" prefix), and
+    # "per_run": {stretch: n} where n copies of a stretch's code are each counted as a run of their own (unrolled node steps)
+    order = [b["label"] for b in bbs]
+    for first, last, name in override.get("ranges", []):
+        i, j = order.index(".LBB0" + first if first != "entry" else "entry"), order.index(".LBB0" + last)
+        for k in range(i, j + 1):
+            where[order[k]] = name
+    copies = override.get("per_run", {})
     n = float(stats["samples"])
     wave = dict(zip(SECTIONS, stats["sec_wave"]))
     lane = dict(zip(SECTIONS, stats["sec_lane"]))
@@ -84,10 +91,13 @@ def main():
     total_w = total_l = 0.0
     rows = []
     for name, st in static.items():
-        key = {"node step (nan)": None, "prologue": None, "pixel start": "pixel done"}.get(name, name)
+        key = {"node step (nan)": None, "prologue": None, "pixel start": "pixel done", "scatter entry": "emission", "traversal entry": None}.get(name, name)
         w = wave.get(key, 0) if key else 0
         l = lane.get(key, 0) if key else 0
         per64 = w * 64.0 / n
+        c = float(copies.get(name, 1))
+        st["valu"] /= c
+        st["salu"] /= c
         rows.append((st["valu"] * per64, name, st, per64, (l / w) if w else 0.0, l / n))
     for cost, name, st, per64, lanes, lane_runs in sorted(rows, reverse=True):
         print("%-18s %6d %6d %12.2f %10.1f %9.0f %12.1f   %s" % (name, st["valu"], st["salu"], per64, lanes, cost, st["valu"] * lane_runs, " ".join(st["blocks"][:10])))

@@ -529,8 +529,7 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
                     s->view.boxesMayBeNan = 1u;
         }
         UP(uploadArray(s, dev.data(), dev.size(), &nodes));
-        const bool inLds = size_t(n) * 32 + size_t(desc->tri_count) * 48 <= LDS_SCENE_MAX_BYTES;
-        if ((g_walk & WPT_WALK_WIDE) && !inLds) {
+        if (g_walk & WPT_WALK_WIDE) {
             /* The wide form (wpt_pathtrace.inc.h): the binary tree collapsed by one level.  Wide nodes are made for the root and
              * for every inner node that is an entry of a wide node, in depth-first order (a wide node's first inner entry follows
              * it).  The walk's argument needs finite boxes and every child's box within its parent's; its stack needs the tree's
@@ -944,7 +943,7 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     args.orderCount = nullptr;
     /* the wide walk where the scene has that form (wpt_set_walk before the upload): product launches of the kernels that fetch
      * the scene from HBM; counting launches and moving scenes walk the binary tree */
-    const bool wide = scene->view.wideNodes != nullptr && !count && !anim; /* (only scenes fetched from HBM have the form) */
+    const bool wide = scene->view.wideNodes != nullptr && !count && !anim && !(basic && lds); /* (the kernel with the scene in LDS walks the binary tree) */
     g_kernelName.store(wide ? "wpt_pathtrace, wide walk" : nullptr, std::memory_order_relaxed);
     auto launch = [&](const wptk::KernelArgs& a) {
         if (anim) {
