@@ -331,6 +331,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant / scheduler tuning word for wpt_set_launch_config (experiments)")
     ap.add_argument("--wavefront", type=int, default=0, help="wpt_set_wavefront mode: 0 = the library decides, 1 = wavefront kernels wherever they exist, 2 = never")
     ap.add_argument("--wide-walk", action="store_true", help="wpt_set_walk(WPT_WALK_WIDE): scenes fetched from HBM are walked over the tree collapsed by one level (experiments)")
+    ap.add_argument("--triangles-as-given", action="store_true", help="wpt_set_walk(WPT_WALK_TRIANGLES_AS_GIVEN): triangle records stay in the caller's order (experiments)")
     ap.add_argument("--top-nodes", type=int, default=-1, help="BVH nodes stored level by level in front of the array (wpt_set_top_nodes; experiments)")
     args = ap.parse_args()
 
@@ -404,7 +405,7 @@ def main():
         device.lib().wpt_set_wavefront(args.wavefront, 0, 0, 0)
     if args.top_nodes >= 0:
         device.lib().wpt_set_top_nodes(args.top_nodes)
-    walk_flags = device.WALK_WIDE if args.wide_walk else 0
+    walk_flags = (device.WALK_WIDE if args.wide_walk else 0) | (device.WALK_TRIANGLES_AS_GIVEN if args.triangles_as_given else 0)
     device.lib().wpt_set_walk(walk_flags)  # before the upload: the wide form of a tree is built there
     lib_id = library_identity()
     dscene = device.DeviceScene(scene)

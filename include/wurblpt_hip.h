@@ -443,10 +443,14 @@ wpt_status wpt_set_top_nodes(uint32_t nodes);
  *   WPT_WALK_FULL_SHADOW    light rays towards the environment walk the tree to the end like the reference's (product launches
  *                           end such a walk at its first accepted hit: the answer the ray is traced for is known there)
  *   WPT_WALK_COUNT_PRODUCT  counting launches, which otherwise walk like the reference so that their counters are its
- *                           counters, count the product's shortened walks instead */
+ *                           counters, count the product's shortened walks instead
+ *   WPT_WALK_TRIANGLES_AS_GIVEN  scenes uploaded from now on keep their triangle records in the caller's order (measurements; by
+ *                           default the records are stored in the order of their leaves in the tree, so that a subtree's
+ *                           triangles share cache lines) */
 #define WPT_WALK_WIDE 1u
 #define WPT_WALK_FULL_SHADOW 2u
 #define WPT_WALK_COUNT_PRODUCT 4u
+#define WPT_WALK_TRIANGLES_AS_GIVEN 8u
 wpt_status wpt_set_walk(uint32_t flags);
 /* Which form of the path tracer renders frames whose scene is fetched from HBM (results do not depend on it):
  * mode 0 = the library decides per launch (default), 1 = the wavefront form wherever it exists (trace and shade as two

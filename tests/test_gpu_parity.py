@@ -1199,6 +1199,25 @@ def test_wide_walk_only_where_it_exists(dev, oracle):
     assert bits_equal(mgot, oracle.render(moving, 2, mp)[0])
 
 
+def test_triangle_storage_order_never_shows(dev, oracle):
+    """wpt_scene_upload stores the triangle records in the order of their leaves in the tree (a subtree's triangles share cache
+    lines); wpt_set_walk(WPT_WALK_TRIANGLES_AS_GIVEN) keeps the caller's order.  Indices are identities only -- leaf to record, hot
+    spot to record, the candidate a light ray must end on: frames and work counters are the oracle's either way, for triangle
+    lights (Cornell: the light's two triangles are hot spots), a transformed hot-spot instance and a scene in HBM."""
+    for sc, ssqrt in ((host.cornell(64, 48, 1, 2), 3), (host.random_triangles(1500, 5, with_texcoords=True, width=64, height=40, aperture=0.0), 2),
+                      (host.courtyard_like(64, 40, seed=6, triangles=9000, tex_size=16), 2)):
+        ref, rc = oracle.render(sc, ssqrt)
+        for flags in (0, dev.WALK_TRIANGLES_AS_GIVEN, dev.WALK_TRIANGLES_AS_GIVEN | dev.WALK_WIDE):
+            try:
+                dev.lib().wpt_set_walk(flags)
+                ds = dev.DeviceScene(sc)
+            finally:
+                dev.lib().wpt_set_walk(0)
+            got, _ = ds.render(ssqrt)
+            counted, gc = ds.render(ssqrt, with_counters=True)
+            assert bits_equal(got, ref) and bits_equal(counted, ref) and gc == rc, flags
+
+
 def test_fuzz_parity_with_the_wide_walk():
     """tools/fuzz_parity.py --wide, three rounds: 21 seeded random scenes of every family uploaded with the wide form."""
     import os

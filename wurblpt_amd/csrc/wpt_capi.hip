@@ -442,6 +442,7 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     const float4* nodes = nullptr;
     const float4* geom = nullptr;
     const float4* attr = nullptr;
+    std::vector<uint32_t> triNew; /* triangle index of the caller -> index on the device */
 #define UP(call)                  \
     do {                          \
         st = (call);              \
@@ -467,6 +468,22 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
         const uint32_t n = desc->node_count;
         if (n > NODE_INDEX_MASK)
             return fail(WPT_ERR_UNSUPPORTED, "more than 2^30 - 1 BVH nodes");
+        /* Storage order of the triangles: that of their leaves in the tree's depth-first order, so that the leaves of a subtree --
+         * which a ray tests one after the other, and neighbouring rays test too -- read neighbouring 48-byte records (a 128-byte
+         * line holds the triangles of two or three sibling leaves) instead of wherever the meshes' own order put them.  Triangle
+         * indices are identities only (leaf -> record, hot spot -> record, the candidate a light ray must end on): no value
+         * depends on them.  wpt_set_walk(WPT_WALK_TRIANGLES_AS_GIVEN) keeps the caller's order (measurements). */
+        triNew.assign(desc->tri_count, 0xffffffffu);
+        {
+            uint32_t next = 0;
+            if (!(g_walk & WPT_WALK_TRIANGLES_AS_GIVEN))
+                for (uint32_t i = 0; i < n; i++)
+                    if (desc->nodes[i].kind == WPT_NODE_TRIANGLE && triNew[desc->nodes[i].link] == 0xffffffffu)
+                        triNew[desc->nodes[i].link] = next++;
+            for (uint32_t t = 0; t < desc->tri_count; t++) /* triangles no leaf refers to (or all, in the caller's order) */
+                if (triNew[t] == 0xffffffffu)
+                    triNew[t] = next++;
+        }
         /* end[i] = first depth-first index behind the subtree of node i (validated above) */
         std::vector<uint32_t> end(n);
         for (uint32_t i = n; i-- > 0;)
@@ -517,7 +534,7 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
         for (uint32_t i = 0; i < n; i++) {
             const wpt_bvh_node& nd = desc->nodes[i];
             const uint32_t skip = place[end[i]];
-            const uint32_t word = nd.kind == WPT_NODE_INNER ? (NODE_CHILD | place[i + 1]) : nd.kind == WPT_NODE_TRIANGLE ? nd.link
+            const uint32_t word = nd.kind == WPT_NODE_INNER ? (NODE_CHILD | place[i + 1]) : nd.kind == WPT_NODE_TRIANGLE ? triNew[nd.link]
                 : nd.kind == WPT_NODE_SPHERE ? (PRIM_SPHERE | nd.link) : (NODE_CHILD | skip);
             float sk, wd;
             memcpy(&sk, &skip, 4);
@@ -616,7 +633,7 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
                         if (nd.kind == WPT_NODE_INNER)
                             ref[k] = NODE_CHILD | wideOf[e];
                         else if (nd.kind == WPT_NODE_TRIANGLE)
-                            ref[k] = nd.link;
+                            ref[k] = triNew[nd.link];
                         else if (nd.kind == WPT_NODE_SPHERE)
                             ref[k] = PRIM_SPHERE | nd.link;
                     }
@@ -629,8 +646,18 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
                 UP(uploadArray(s, wide.data(), wide.size(), &s->view.wideNodes));
         }
     }
-    UP(uploadArray(s, reinterpret_cast<const float4*>(desc->tri_geom), size_t(desc->tri_count) * 3, &geom));
-    UP(uploadArray(s, reinterpret_cast<const float4*>(desc->tri_attr), size_t(desc->tri_count) * 6, &attr));
+    {
+        std::vector<wpt_tri_geom> g(desc->tri_count);
+        for (uint32_t t = 0; t < desc->tri_count; t++)
+            g[triNew[t]] = desc->tri_geom[t];
+        UP(uploadArray(s, reinterpret_cast<const float4*>(g.data()), size_t(desc->tri_count) * 3, &geom));
+    }
+    {
+        std::vector<wpt_tri_attr> a(desc->tri_count);
+        for (uint32_t t = 0; t < desc->tri_count; t++)
+            a[triNew[t]] = desc->tri_attr[t];
+        UP(uploadArray(s, reinterpret_cast<const float4*>(a.data()), size_t(desc->tri_count) * 6, &attr));
+    }
     s->view.nodes = nodes;
     s->view.triGeom = geom;
     s->view.triAttr = attr;
@@ -681,7 +708,13 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
             }
         }
     }
-    UP(uploadArray(s, desc->hotspots, desc->hotspot_count, &s->view.hotspots));
+    {
+        std::vector<wpt_hotspot> h(desc->hotspots, desc->hotspots + desc->hotspot_count);
+        for (wpt_hotspot& hs : h)
+            if (hs.kind != WPT_HOTSPOT_SPHERE)
+                hs.prim = triNew[hs.prim];
+        UP(uploadArray(s, h.data(), h.size(), &s->view.hotspots));
+    }
     UP(uploadArray(s, desc->spheres, desc->sphere_count, &s->view.spheres));
     UP(uploadArray(s, desc->rgl_brdfs, desc->rgl_count, &s->view.rglBrdfs));
     UP(uploadArray(s, desc->rgl_data, size_t(desc->rgl_data_count), &s->view.rglData));
@@ -1220,7 +1253,7 @@ wpt_status wpt_set_top_nodes(uint32_t nodes)
 
 wpt_status wpt_set_walk(uint32_t flags)
 {
-    if (flags & ~(WPT_WALK_WIDE | WPT_WALK_FULL_SHADOW | WPT_WALK_COUNT_PRODUCT))
+    if (flags & ~(WPT_WALK_WIDE | WPT_WALK_FULL_SHADOW | WPT_WALK_COUNT_PRODUCT | WPT_WALK_TRIANGLES_AS_GIVEN))
         return fail(WPT_ERR_INVALID_ARGUMENT, "unknown walk flag");
     g_walk = flags;
     return WPT_OK;

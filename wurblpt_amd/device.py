@@ -16,7 +16,7 @@ def lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("WPT_LIB_DIR", "lib"), "libwurblpt_hip.so")
 
 
-WALK_WIDE, WALK_FULL_SHADOW, WALK_COUNT_PRODUCT = 1, 2, 4  # wpt_set_walk (include/wurblpt_hip.h)
+WALK_WIDE, WALK_FULL_SHADOW, WALK_COUNT_PRODUCT, WALK_TRIANGLES_AS_GIVEN = 1, 2, 4, 8  # wpt_set_walk (include/wurblpt_hip.h)
 
 EXPORTS = ["wpt_device_count", "wpt_select_device", "wpt_current_device", "wpt_scene_upload", "wpt_scene_free", "wpt_scene_check",
            "wpt_postproc_to_srgb", "wpt_postproc_max_luminance", "wpt_postproc_uniform_rational_quantization",
