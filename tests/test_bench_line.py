@@ -83,6 +83,10 @@ def test_workloads_are_the_configurations_baseline_json_names():
     w = bench.WORKLOADS
     assert w["cornell_1024x1024_1024spp_ggx_glass"]["samples_sqrt"] ** 2 == 1024 and w["cornell_256x256_64spp_lambertian"]["samples_sqrt"] ** 2 == 64
     assert bench.SECONDARY in w and w[bench.SECONDARY]["width"] == 1920 and w[bench.SECONDARY]["samples_sqrt"] ** 2 == 256
+    # the default line's secondaries: BASELINE configs[2], [3] and [4], the last two at the nearest perfect squares
+    names = [s[0] for s in bench.SECONDARIES]
+    assert names == [bench.SECONDARY, "courtyard_like_10M_1920x1080_121spp", "measured_like_3840x2160_529spp_rgl"] and all(n in w for n in names)
+    assert w[names[1]]["samples_sqrt"] == 11 and w[names[2]]["samples_sqrt"] == 23 and w[names[2]]["width"] == 3840
     text = json.dumps(base["configs"])
     for needle in ("1024", "256", "1920"):
         assert needle in text

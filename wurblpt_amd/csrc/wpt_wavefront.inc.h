@@ -219,6 +219,8 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                     o = mk3(ro.x, ro.y, ro.z);
                     d = mk3(rd.x, rd.y, rd.z);
                     aux = rayAux(d);
+                    if (rayMayNan(o, aux.inv)) /* only such rays test their slab distances for NaN per box (wpt_device.h) */
+                        aux.k |= RAY_MAY_NAN;
                     node = 0;
                     amax = k_maxval;
                     best.prim = NO_HIT;
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
         }
         /* walk until refillIdle lanes have finished (while there is something to deal them), or to the end */
         const bool canRefill = chunkNext != chunkEnd || !dry;
+        const bool nanPossible = sv.boxesMayBeNan != 0 || __ballot((aux.k & RAY_MAY_NAN) != 0 && state != T_IDLE) != 0; /* rays are dealt above only */
         int leaveBelow = canRefill ? 65 - (int)a.refillIdle : 1;
         leaveBelow = leaveBelow < 1 ? 1 : leaveBelow;
         for (;;) {
@@ -288,7 +291,9 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                     const float4 n0 = pn0, n1 = pn1;
                     const uint32_t skip = __float_as_uint(n1.z);
                     const uint32_t word = __float_as_uint(n1.w);
-                    const bool hit = boxTest(nodeLo(n0, n1), nodeHi(n0, n1), o, aux.inv, amin, amax);
+                    bool hit = boxTest<false>(nodeLo(n0, n1), nodeHi(n0, n1), o, aux.inv, amin, amax);
+                    if (nanPossible) /* wave-uniform, rarely true */
+                        hit = boxTest<true>(nodeLo(n0, n1), nodeHi(n0, n1), o, aux.inv, amin, amax);
                     const bool inner = word >= NODE_CHILD;
                     const bool toLeaf = hit && !inner;
                     leafPrim = toLeaf ? word : leafPrim;
