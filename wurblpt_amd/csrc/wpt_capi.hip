@@ -717,7 +717,35 @@ wpt_status wpt_scene_upload(const wpt_scene_desc* desc, wpt_scene** out_scene)
     }
     UP(uploadArray(s, desc->spheres, desc->sphere_count, &s->view.spheres));
     UP(uploadArray(s, desc->rgl_brdfs, desc->rgl_count, &s->view.rglBrdfs));
-    UP(uploadArray(s, desc->rgl_data, size_t(desc->rgl_data_count), &s->view.rglData));
+    {
+        /* The measured BRDFs' pool, and behind it one interleaved table per BRDF whose colour and luminance warps share their
+         * grids (wpt_rgl.h, rglColourInterleaved): red, green, blue and luminance of a grid point side by side, so that the up to
+         * 128 look-ups an evaluation makes into those two warps come from 8 cache lines instead of 32.  The values are the
+         * pool's own; which copy a look-up reads changes no bit. */
+        std::vector<float> pool(desc->rgl_data, desc->rgl_data + desc->rgl_data_count);
+        std::vector<uint32_t> rgbl(desc->rgl_count, WPT_RGL_NONE);
+        for (uint32_t i = 0; i < desc->rgl_count; i++) {
+            const wpt_rgl_brdf& b = desc->rgl_brdfs[i];
+            if (!wptrgl::rglInterleavable(b))
+                continue;
+            const size_t size = size_t(b.rgb.size_x) * b.rgb.size_y;
+            const size_t slices = size_t(b.luminance.param_size[0]) * b.luminance.param_size[1];
+            const size_t at = (pool.size() + 3) & ~size_t(3); /* 16-byte records */
+            if (at + slices * size * 4 > 0xfffffff0ull)
+                continue;
+            pool.resize(at + slices * size * 4);
+            for (size_t sl = 0; sl < slices; sl++)
+                for (size_t e = 0; e < size; e++) {
+                    float* t = pool.data() + at + (sl * size + e) * 4;
+                    for (size_t c = 0; c < 3; c++)
+                        t[c] = desc->rgl_data[b.rgb.data + (sl * 3 + c) * size + e];
+                    t[3] = desc->rgl_data[b.luminance.data + sl * size + e];
+                }
+            rgbl[i] = uint32_t(at);
+        }
+        UP(uploadArray(s, pool.data(), pool.size(), &s->view.rglData));
+        UP(uploadArray(s, rgbl.data(), rgbl.size(), &s->view.rglRgbl));
+    }
     UP(uploadArray(s, desc->animations, desc->animation_count, &s->view.animations));
     UP(uploadArray(s, desc->keyframes, desc->keyframe_count, &s->view.keyframes));
     s->animationCount = desc->animation_count;

@@ -486,6 +486,7 @@ struct SceneView {
     const wpt_sphere* spheres;
     const wpt_rgl_brdf* rglBrdfs; /* measured BRDFs and the pool their tables live in */
     const float* rglData;
+    const uint32_t* rglRgbl; /* per measured BRDF: offset of its interleaved colour + luminance table in rglData, or WPT_RGL_NONE (wpt_rgl.h) */
     const float* envM;
     const int32_t* envMs;
     const float* envMcs;
@@ -1239,7 +1240,7 @@ template<uint32_t F> WPT_D Scatter materialScatter(const SceneView& sv, const wp
         pwo = a;
         p = 0.0f;
         if (!(wwi.z <= 0.0f)) { /* BRDF::sample's own first test */
-            wptrgl::rglIncidentCall<DeviceRglMath>(sv.rglBrdfs[m.tex[0]], sv.rglData, wwi, mc.rgl);
+            wptrgl::rglIncidentCall<DeviceRglMath>(sv.rglBrdfs[m.tex[0]], sv.rglData, wwi, mc.rgl, sv.rglRgbl[m.tex[0]]);
             mc.haveRgl = true;
             a = wptrgl::rglSampleCall<DeviceRglMath>(sv.rglBrdfs[m.tex[0]], sv.rglData, mc.rgl, uu, wwi, pwo, p);
         }
@@ -1464,7 +1465,7 @@ template<uint32_t F> WPT_D void materialEval(const SceneView& sv, const wpt_mate
             p = 0.0f;
             if (!(wwi.z <= 0.0f || wwo.z <= 0.0f)) {
                 if (!mc.haveRgl) {
-                    wptrgl::rglIncidentCall<DeviceRglMath>(b, sv.rglData, wwi, mc.rgl);
+                    wptrgl::rglIncidentCall<DeviceRglMath>(b, sv.rglData, wwi, mc.rgl, sv.rglRgbl[m.tex[0]]);
                     mc.haveRgl = true;
                 }
                 wptrgl::rglEvalPdfCall<DeviceRglMath>(b, sv.rglData, mc.rgl, wwi, wwo, a, p);

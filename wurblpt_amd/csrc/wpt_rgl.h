@@ -81,21 +81,22 @@ WPT_RGL_HD uint32_t findInterval(uint32_t size_, const Predicate& pred)
     return (uint32_t)r;
 }
 
-/* lookup<Dim> (powitacq_rgb.inl:563-581): multilinear interpolation over the parameter slices */
-template<int Dim>
+/* lookup<Dim> (powitacq_rgb.inl:563-581): multilinear interpolation over the parameter slices.  ES: the table's values lie ES floats
+ * apart (1: the reference's arrays; 4: the interleaved colour + luminance table, RglIncident::rgbl) */
+template<int Dim, int ES = 1>
 struct Lookup {
     static WPT_RGL_HD float at(const float* data, uint32_t i0, uint32_t size, const float* pw, const wpt_rgl_warp& w)
     {
         const uint32_t i1 = i0 + w.param_stride[Dim - 1] * size;
         const float w0 = pw[2 * Dim - 2], w1 = pw[2 * Dim - 1];
-        const float v0 = Lookup<Dim - 1>::at(data, i0, size, pw, w);
-        const float v1 = Lookup<Dim - 1>::at(data, i1, size, pw, w);
+        const float v0 = Lookup<Dim - 1, ES>::at(data, i0, size, pw, w);
+        const float v1 = Lookup<Dim - 1, ES>::at(data, i1, size, pw, w);
         return __builtin_fmaf(v0, w0, v1 * w1);
     }
 };
-template<>
-struct Lookup<0> {
-    static WPT_RGL_HD float at(const float* data, uint32_t index, uint32_t, const float*, const wpt_rgl_warp&) { return data[index]; }
+template<int ES>
+struct Lookup<0, ES> {
+    static WPT_RGL_HD float at(const float* data, uint32_t index, uint32_t, const float*, const wpt_rgl_warp&) { return data[(size_t)index * ES]; }
 };
 
 /* find_interval over a parameter grid of at most 16 values, read all at once: the bisection then runs over the sixteen
@@ -187,8 +188,8 @@ WPT_RGL_HD ParamCtx<3> paramCtxAppend(const ParamCtx<2>& first, const wpt_rgl_wa
 }
 
 /* Marginal2D::sample (powitacq_rgb.inl:322-432) */
-template<int Dim>
-WPT_RGL_HD V2 warpSample(const wpt_rgl_warp& w, const float* pool, V2 sample, const ParamCtx<Dim>& ctx, float& pdf)
+template<int Dim, int ES = 1>
+WPT_RGL_HD V2 warpSample(const wpt_rgl_warp& w, const float* pool, V2 sample, const ParamCtx<Dim>& ctx, float& pdf, const float* dataAt = nullptr)
 {
     sample.x = rclamp(sample.x, 1.0f - k_oneMinusEpsilon, k_oneMinusEpsilon);
     sample.y = rclamp(sample.y, 1.0f - k_oneMinusEpsilon, k_oneMinusEpsilon);
@@ -196,7 +197,7 @@ WPT_RGL_HD V2 warpSample(const wpt_rgl_warp& w, const float* pool, V2 sample, co
     const uint32_t sliceOffset = ctx.sliceOffset;
     const float* marginal = pool + w.marginal_cdf;
     const float* conditional = pool + w.conditional_cdf;
-    const float* data = pool + w.data;
+    const float* data = ES == 1 ? pool + w.data : dataAt; /* (the interleaved table holds the same values ES floats apart) */
 
     /* the row first */
     uint32_t offset = 0;
@@ -227,10 +228,10 @@ WPT_RGL_HD V2 warpSample(const wpt_rgl_warp& w, const float* pool, V2 sample, co
     sample.x -= fetchConditional(col);
     offset += col;
 
-    const float v00 = Lookup<Dim>::at(data, offset, sliceSize, pw, w);
-    const float v10 = Lookup<Dim>::at(data + 1, offset, sliceSize, pw, w);
-    const float v01 = Lookup<Dim>::at(data + w.size_x, offset, sliceSize, pw, w);
-    const float v11 = Lookup<Dim>::at(data + w.size_x + 1, offset, sliceSize, pw, w);
+    const float v00 = Lookup<Dim, ES>::at(data, offset, sliceSize, pw, w);
+    const float v10 = Lookup<Dim, ES>::at(data + ES, offset, sliceSize, pw, w);
+    const float v01 = Lookup<Dim, ES>::at(data + ES * w.size_x, offset, sliceSize, pw, w);
+    const float v11 = Lookup<Dim, ES>::at(data + ES * (w.size_x + 1), offset, sliceSize, pw, w);
     const float c0 = __builtin_fmaf((1.0f - sample.y), v00, sample.y * v01);
     const float c1 = __builtin_fmaf((1.0f - sample.y), v10, sample.y * v11);
     isConst = __builtin_fabsf(c0 - c1) < 1e-4f * (c0 + c1);
@@ -310,12 +311,12 @@ WPT_RGL_HD V2 warpInvert(const wpt_rgl_warp& w, const float* pool, V2 sample, co
     return warpInvert<Dim>(w, pool, sample, paramCtx<Dim>(w, pool, param), pdfOut);
 }
 
-template<int Dim>
-WPT_RGL_HD float warpEval(const wpt_rgl_warp& w, const float* pool, V2 pos, const ParamCtx<Dim>& ctx)
+template<int Dim, int ES = 1>
+WPT_RGL_HD float warpEval(const wpt_rgl_warp& w, const float* pool, V2 pos, const ParamCtx<Dim>& ctx, const float* dataAt = nullptr)
 {
     const float* pw = ctx.pw;
     const uint32_t sliceOffset = ctx.sliceOffset;
-    const float* data = pool + w.data;
+    const float* data = ES == 1 ? pool + w.data : dataAt;
     pos.x *= w.inv_patch_size[0];
     pos.y *= w.inv_patch_size[1];
     const uint32_t ox = umin((uint32_t)pos.x, w.size_x - 2u);
@@ -326,10 +327,10 @@ WPT_RGL_HD float warpEval(const wpt_rgl_warp& w, const float* pool, V2 pos, cons
     const uint32_t size = w.size_x * w.size_y;
     if (Dim != 0)
         index += sliceOffset * size;
-    const float v00 = Lookup<Dim>::at(data, index, size, pw, w);
-    const float v10 = Lookup<Dim>::at(data + 1, index, size, pw, w);
-    const float v01 = Lookup<Dim>::at(data + w.size_x, index, size, pw, w);
-    const float v11 = Lookup<Dim>::at(data + w.size_x + 1, index, size, pw, w);
+    const float v00 = Lookup<Dim, ES>::at(data, index, size, pw, w);
+    const float v10 = Lookup<Dim, ES>::at(data + ES, index, size, pw, w);
+    const float v01 = Lookup<Dim, ES>::at(data + ES * w.size_x, index, size, pw, w);
+    const float v11 = Lookup<Dim, ES>::at(data + ES * (w.size_x + 1), index, size, pw, w);
     return __builtin_fmaf(w0y, __builtin_fmaf(w0x, v00, w1x * v10), w1y * __builtin_fmaf(w0x, v01, w1x * v11))
         * (w.inv_patch_size[0] * w.inv_patch_size[1]);
 }
@@ -371,6 +372,61 @@ WPT_RGL_HD V3 normalize3(V3 v)
 
 /* the three colour channels of the spectral interpolant, clipped (POWITACQ_CLIP_RGB); `first` = the incident direction's
  * two parameters evaluated on the warp b.rgb */
+/* The same from the interleaved table (RglIncident::rgbl: red, green, blue, luminance of one grid point side by side, 16 bytes):
+ * warpEval<3> on b.rgb reads, for every corner of the patch, the channel's own slice and its neighbour's -- 2 x 4 parameter taps
+ * x 4 corners x 3 channels = 96 loads from 24 lines -- although the three channels interpolate the SAME three two-parameter values
+ * per corner (the channel parameter is 0, 1 or 2: one of its two weights is exactly 0, the value still takes part as the reference
+ * computes it).  Here each corner's three two-parameter values are evaluated once (the operations of Lookup<2> inside Lookup<3>, on
+ * the same numbers) and every channel combines its two with its own weights: 48 loads from 8 lines, the same bits. */
+WPT_RGL_HD bool rglInterleavable(const wpt_rgl_brdf& b)
+{
+    const wpt_rgl_warp& c = b.rgb;
+    const wpt_rgl_warp& l = b.luminance;
+    return c.dims == 3 && l.dims == 2 && c.size_x == l.size_x && c.size_y == l.size_y && c.param_size[2] == 3 && c.param_stride[2] == 1
+        && c.param_size[0] == l.param_size[0] && c.param_size[1] == l.param_size[1]
+        && c.param_stride[0] == 3 * l.param_stride[0] && c.param_stride[1] == 3 * l.param_stride[1];
+}
+WPT_RGL_HD V3 rglColourInterleaved(const wpt_rgl_brdf& b, const float* pool, const float* table, V2 pos, const ParamCtx<2>& first)
+{
+    const wpt_rgl_warp& w = b.rgb;
+    pos.x *= w.inv_patch_size[0];
+    pos.y *= w.inv_patch_size[1];
+    const uint32_t ox = umin((uint32_t)pos.x, w.size_x - 2u);
+    const uint32_t oy = umin((uint32_t)pos.y, w.size_y - 2u);
+    const float w1x = pos.x - (float)(int32_t)ox, w1y = pos.y - (float)(int32_t)oy;
+    const float w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    const uint32_t size = w.size_x * w.size_y;
+    /* the slice of (phi_i, theta_i) in the interleaved table: the colour warp's slice offset without its channel, over 3 */
+    const uint32_t index = ox + oy * w.size_x + (first.sliceOffset / 3u) * size;
+    const uint32_t corner[4] = { 0u, 1u, w.size_x, w.size_x + 1u };
+    float two[4][3]; /* per corner: Lookup<2> of the channel slices 0, 1, 2 (strides: the luminance warp's, = the colour warp's / 3) */
+    WPT_RGL_UNROLL
+    for (int k = 0; k < 4; k++)
+        WPT_RGL_UNROLL
+        for (int c = 0; c < 3; c++)
+            two[k][c] = Lookup<2, 4>::at(table + 4 * corner[k] + c, index, size, first.pw, b.luminance);
+    float fr[3];
+    WPT_RGL_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        float w0, w1;
+        const uint32_t ch = paramWeightsOf(w, pool, 2, (float)i, w0, w1); /* channel slice: stride 1 */
+        float v[4];
+        WPT_RGL_UNROLL
+        for (int k = 0; k < 4; k++) {
+            const float a = ch == 0 ? two[k][0] : two[k][1], bb = ch == 0 ? two[k][1] : two[k][2];
+            v[k] = __builtin_fmaf(a, w0, bb * w1);
+        }
+        fr[i] = __builtin_fmaf(w0y, __builtin_fmaf(w0x, v[0], w1x * v[1]), w1y * __builtin_fmaf(w0x, v[2], w1x * v[3]))
+            * (w.inv_patch_size[0] * w.inv_patch_size[1]);
+        fr[i] = rmax(0.0f, fr[i]);
+    }
+    V3 r;
+    r.x = fr[0];
+    r.y = fr[1];
+    r.z = fr[2];
+    return r;
+}
+
 WPT_RGL_HD V3 rglColour(const wpt_rgl_brdf& b, const float* pool, V2 sample, const ParamCtx<2>& first)
 {
     float fr[3];
@@ -394,11 +450,15 @@ struct RglIncident {
     V2 u_wi;
     ParamCtx<2> vndf, luminance, rgb;
     float d; /* 4 * sigma(u_wi) */
+    /* offset of this BRDF's interleaved colour + luminance table in the pool, or WPT_RGL_NONE: the device's copy of the pool has
+     * one per BRDF whose two warps share their grids (wpt_capi.hip builds it at upload; the test oracle has none) */
+    uint32_t rgbl;
 };
 template<class M>
-WPT_RGL_HD RglIncident rglIncident(const wpt_rgl_brdf& b, const float* pool, V3 wi)
+WPT_RGL_HD RglIncident rglIncident(const wpt_rgl_brdf& b, const float* pool, V3 wi, uint32_t rgbl = WPT_RGL_NONE)
 {
     RglIncident inc;
+    inc.rgbl = rgbl;
     inc.theta_i = elevation<M>(wi);
     inc.phi_i = M::atan2(wi.y, wi.x);
     inc.u_wi.x = theta2u<M>(inc.theta_i);
@@ -435,7 +495,8 @@ WPT_RGL_HD void rglEvalPdfWith(const wpt_rgl_brdf& b, const float* pool, const R
     float vndfPdf;
     const V2 sample = warpInvert<2>(b.vndf, pool, u_wm, inc.vndf, vndfPdf);
     /* eval */
-    V3 fr = rglColour(b, pool, sample, inc.rgb);
+    const bool interleaved = inc.rgbl != WPT_RGL_NONE;
+    V3 fr = interleaved ? rglColourInterleaved(b, pool, pool + inc.rgbl, sample, inc.rgb) : rglColour(b, pool, sample, inc.rgb);
     const float params[2] = { inc.phi_i, inc.theta_i };
     const float n = warpEval<0>(b.ndf, pool, u_wm, params);
     const float d = inc.d;
@@ -444,7 +505,7 @@ WPT_RGL_HD void rglEvalPdfWith(const wpt_rgl_brdf& b, const float* pool, const R
     fr.z = fr.z * n / d;
     frOut = fr;
     /* pdf */
-    const float pdf = warpEval<2>(b.luminance, pool, sample, inc.luminance);
+    const float pdf = interleaved ? warpEval<2, 4>(b.luminance, pool, sample, inc.luminance, pool + inc.rgbl + 3) : warpEval<2>(b.luminance, pool, sample, inc.luminance);
     const float sinThetaM = __builtin_sqrtf(sqr(wm.x) + sqr(wm.y));
     const float jacobian = rmax(2.0f * sqr(k_rgl_pi) * u_wm.x * sinThetaM, 1e-6f) * 4.0f * dot3(wi, wm);
     pdfOut = vndfPdf * pdf / jacobian;
@@ -465,7 +526,8 @@ WPT_RGL_HD V3 rglSampleWith(const wpt_rgl_brdf& b, const float* pool, const RglI
     sample.x = u.y;
     sample.y = u.x;
     float lumPdf;
-    sample = warpSample<2>(b.luminance, pool, sample, inc.luminance, lumPdf);
+    const bool interleaved = inc.rgbl != WPT_RGL_NONE;
+    sample = interleaved ? warpSample<2, 4>(b.luminance, pool, sample, inc.luminance, lumPdf, pool + inc.rgbl + 3) : warpSample<2>(b.luminance, pool, sample, inc.luminance, lumPdf);
     float ndfPdf;
     const V2 u_wm = warpSample<2>(b.vndf, pool, sample, inc.vndf, ndfPdf);
     float phi_m = u2phi(u_wm.y);
@@ -484,7 +546,7 @@ WPT_RGL_HD V3 rglSampleWith(const wpt_rgl_brdf& b, const float* pool, const RglI
     wo.z = wm.z * 2.0f * dwm - wi.z;
     if (wo.z <= 0)
         return zero;
-    V3 fr = rglColour(b, pool, sample, inc.rgb);
+    V3 fr = interleaved ? rglColourInterleaved(b, pool, pool + inc.rgbl, sample, inc.rgb) : rglColour(b, pool, sample, inc.rgb);
     const float params[2] = { inc.phi_i, inc.theta_i };
     const float n = warpEval<0>(b.ndf, pool, u_wm, params);
     const float d = inc.d;
@@ -538,9 +600,9 @@ WPT_RGL_ENTRY V3 rglSample(const wpt_rgl_brdf& b, const float* pool, V2 u, V3 wi
 /* the same for the kernels: out of line (few lanes run them, and they are long), the incident direction's context by
  * reference so that scatter and the evaluation towards the light share one */
 template<class M>
-WPT_RGL_ENTRY void rglIncidentCall(const wpt_rgl_brdf& b, const float* pool, V3 wi, RglIncident& inc)
+WPT_RGL_ENTRY void rglIncidentCall(const wpt_rgl_brdf& b, const float* pool, V3 wi, RglIncident& inc, uint32_t rgbl = WPT_RGL_NONE)
 {
-    inc = rglIncident<M>(b, pool, wi);
+    inc = rglIncident<M>(b, pool, wi, rgbl);
 }
 template<class M>
 WPT_RGL_ENTRY V3 rglSampleCall(const wpt_rgl_brdf& b, const float* pool, const RglIncident& inc, V2 u, V3 wi, V3& woOut, float& pdfOut)
