@@ -28,10 +28,10 @@
 
 #if defined(__HIPCC__)
 #define WPT_RGL_HD __host__ __device__ __forceinline__
-/* the model's entry points for the kernels: real calls (long code that few lanes of a mixed wave run), or inlined where a
- * translation unit asks for it (WPT_RGL_INLINE: the single kernel for measured BRDFs, 101.1 -> 104.7 Msamples/s on the Bistro-class
- * frame at 16 spp with 432 -> 400 B of scratch; the wavefront form's shade kernel, whose waves are sorted by kind, measured
- * 124.3 -> 123.4 with it and keeps the calls) */
+/* the model's entry points for the kernels: real calls (the counting and moving-scene kernels, where few lanes of a mixed wave run
+ * this long code), or inlined where a translation unit asks for it (WPT_RGL_INLINE: the product kernels for measured BRDFs --
+ * single kernel 101.1 -> 104.7 Msamples/s on the Bistro-class frame at 16 spp; the wavefront form's shade kernel with the
+ * interleaved table 120.7 as calls, 129.1 inlined, against 125.2 before the table: profiles/r04_measured_brdf_table.txt) */
 #ifdef WPT_RGL_INLINE
 #define WPT_RGL_ENTRY __host__ __device__ __forceinline__
 #else
@@ -386,7 +386,14 @@ WPT_RGL_HD bool rglInterleavable(const wpt_rgl_brdf& b)
         && c.param_size[0] == l.param_size[0] && c.param_size[1] == l.param_size[1]
         && c.param_stride[0] == 3 * l.param_stride[0] && c.param_stride[1] == 3 * l.param_stride[1];
 }
-WPT_RGL_HD V3 rglColourInterleaved(const wpt_rgl_brdf& b, const float* pool, const float* table, V2 pos, const ParamCtx<2>& first)
+struct alignas(16) RglQuad { /* one record of the interleaved table */
+    float r, g, b, lum;
+};
+/* the colour at `pos` and, with LUM, the luminance warp's value there (BRDF::eval and BRDF::pdf ask for both at one position):
+ * sixteen 16-byte loads -- four parameter taps for each of the patch's four corners -- serve all four values */
+template<bool LUM>
+WPT_RGL_HD V3 rglColourInterleaved(const wpt_rgl_brdf& b, const float* pool, const float* table, V2 pos, const ParamCtx<2>& first,
+        const ParamCtx<2>& lumCtx, float& lumOut)
 {
     const wpt_rgl_warp& w = b.rgb;
     pos.x *= w.inv_patch_size[0];
@@ -396,30 +403,61 @@ WPT_RGL_HD V3 rglColourInterleaved(const wpt_rgl_brdf& b, const float* pool, con
     const float w1x = pos.x - (float)(int32_t)ox, w1y = pos.y - (float)(int32_t)oy;
     const float w0x = 1.0f - w1x, w0y = 1.0f - w1y;
     const uint32_t size = w.size_x * w.size_y;
-    /* the slice of (phi_i, theta_i) in the interleaved table: the colour warp's slice offset without its channel, over 3 */
-    const uint32_t index = ox + oy * w.size_x + (first.sliceOffset / 3u) * size;
-    const uint32_t corner[4] = { 0u, 1u, w.size_x, w.size_x + 1u };
-    float two[4][3]; /* per corner: Lookup<2> of the channel slices 0, 1, 2 (strides: the luminance warp's, = the colour warp's / 3) */
+    const RglQuad* quads = reinterpret_cast<const RglQuad*>(table);
+    /* the slice of (phi_i, theta_i) in the interleaved table: the colour warp's slice offset without its channel, over 3; the
+     * luminance warp's own slice offset (the same number where the two grids hold the same values) */
+    const uint32_t at = ox + oy * w.size_x;
+    const uint32_t index = at + (first.sliceOffset / 3u) * size, indexLum = at + lumCtx.sliceOffset * size;
+    const uint32_t s0 = b.luminance.param_stride[0] * size, s1 = b.luminance.param_stride[1] * size;
+    /* every channel's weights and slice along the third parameter (0, 1, 2: one of the two weights is exactly 0) */
+    float cw0[3], cw1[3];
+    uint32_t ch[3];
     WPT_RGL_UNROLL
-    for (int k = 0; k < 4; k++)
+    for (int i = 0; i < 3; ++i)
+        ch[i] = paramWeightsOf(w, pool, 2, (float)i, cw0[i], cw1[i]);
+    const float* pw = first.pw;
+    const float* lw = lumCtx.pw;
+    float rows[2][4]; /* per row of the patch: fma(w0x, left corner, w1x * right corner) of red, green, blue, luminance */
+    WPT_RGL_UNROLL
+    for (int row = 0; row < 2; row++) {
+        float v[2][4];
         WPT_RGL_UNROLL
-        for (int c = 0; c < 3; c++)
-            two[k][c] = Lookup<2, 4>::at(table + 4 * corner[k] + c, index, size, first.pw, b.luminance);
+        for (int col = 0; col < 2; col++) {
+            const uint32_t corner = (uint32_t)col + (uint32_t)row * w.size_x;
+            const RglQuad q00 = quads[index + corner], q10 = quads[index + corner + s0], q01 = quads[index + corner + s1], q11 = quads[index + corner + s0 + s1];
+            /* Lookup<2> of the three channel slices (the operations of Lookup<2> inside Lookup<3>, on the same numbers) */
+            const float two[3] = {
+                __builtin_fmaf(__builtin_fmaf(q00.r, pw[0], q10.r * pw[1]), pw[2], __builtin_fmaf(q01.r, pw[0], q11.r * pw[1]) * pw[3]),
+                __builtin_fmaf(__builtin_fmaf(q00.g, pw[0], q10.g * pw[1]), pw[2], __builtin_fmaf(q01.g, pw[0], q11.g * pw[1]) * pw[3]),
+                __builtin_fmaf(__builtin_fmaf(q00.b, pw[0], q10.b * pw[1]), pw[2], __builtin_fmaf(q01.b, pw[0], q11.b * pw[1]) * pw[3]) };
+            WPT_RGL_UNROLL
+            for (int i = 0; i < 3; ++i) {
+                const float a = ch[i] == 0 ? two[0] : two[1], bb = ch[i] == 0 ? two[1] : two[2];
+                v[col][i] = __builtin_fmaf(a, cw0[i], bb * cw1[i]);
+            }
+            if (LUM) {
+                const RglQuad l00 = index == indexLum ? q00 : quads[indexLum + corner], l10 = index == indexLum ? q10 : quads[indexLum + corner + s0],
+                              l01 = index == indexLum ? q01 : quads[indexLum + corner + s1], l11 = index == indexLum ? q11 : quads[indexLum + corner + s0 + s1];
+                v[col][3] = __builtin_fmaf(__builtin_fmaf(l00.lum, lw[0], l10.lum * lw[1]), lw[2], __builtin_fmaf(l01.lum, lw[0], l11.lum * lw[1]) * lw[3]);
+            } else {
+                v[col][3] = 0.0f;
+            }
+        }
+        WPT_RGL_UNROLL
+        for (int i = 0; i < 4; ++i)
+            rows[row][i] = __builtin_fmaf(w0x, v[0][i], w1x * v[1][i]);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::: "memory"); /* the second row's loads stay behind the first row's arithmetic: registers */
+#endif
+    }
     float fr[3];
     WPT_RGL_UNROLL
     for (int i = 0; i < 3; ++i) {
-        float w0, w1;
-        const uint32_t ch = paramWeightsOf(w, pool, 2, (float)i, w0, w1); /* channel slice: stride 1 */
-        float v[4];
-        WPT_RGL_UNROLL
-        for (int k = 0; k < 4; k++) {
-            const float a = ch == 0 ? two[k][0] : two[k][1], bb = ch == 0 ? two[k][1] : two[k][2];
-            v[k] = __builtin_fmaf(a, w0, bb * w1);
-        }
-        fr[i] = __builtin_fmaf(w0y, __builtin_fmaf(w0x, v[0], w1x * v[1]), w1y * __builtin_fmaf(w0x, v[2], w1x * v[3]))
-            * (w.inv_patch_size[0] * w.inv_patch_size[1]);
+        fr[i] = __builtin_fmaf(w0y, rows[0][i], w1y * rows[1][i]) * (w.inv_patch_size[0] * w.inv_patch_size[1]);
         fr[i] = rmax(0.0f, fr[i]);
     }
+    if (LUM)
+        lumOut = __builtin_fmaf(w0y, rows[0][3], w1y * rows[1][3]) * (b.luminance.inv_patch_size[0] * b.luminance.inv_patch_size[1]);
     V3 r;
     r.x = fr[0];
     r.y = fr[1];
@@ -496,7 +534,8 @@ WPT_RGL_HD void rglEvalPdfWith(const wpt_rgl_brdf& b, const float* pool, const R
     const V2 sample = warpInvert<2>(b.vndf, pool, u_wm, inc.vndf, vndfPdf);
     /* eval */
     const bool interleaved = inc.rgbl != WPT_RGL_NONE;
-    V3 fr = interleaved ? rglColourInterleaved(b, pool, pool + inc.rgbl, sample, inc.rgb) : rglColour(b, pool, sample, inc.rgb);
+    float pdf = 0.0f; /* BRDF::pdf's luminance term: from the interleaved table it comes with the colour */
+    V3 fr = interleaved ? rglColourInterleaved<true>(b, pool, pool + inc.rgbl, sample, inc.rgb, inc.luminance, pdf) : rglColour(b, pool, sample, inc.rgb);
     const float params[2] = { inc.phi_i, inc.theta_i };
     const float n = warpEval<0>(b.ndf, pool, u_wm, params);
     const float d = inc.d;
@@ -505,7 +544,8 @@ WPT_RGL_HD void rglEvalPdfWith(const wpt_rgl_brdf& b, const float* pool, const R
     fr.z = fr.z * n / d;
     frOut = fr;
     /* pdf */
-    const float pdf = interleaved ? warpEval<2, 4>(b.luminance, pool, sample, inc.luminance, pool + inc.rgbl + 3) : warpEval<2>(b.luminance, pool, sample, inc.luminance);
+    if (!interleaved)
+        pdf = warpEval<2>(b.luminance, pool, sample, inc.luminance);
     const float sinThetaM = __builtin_sqrtf(sqr(wm.x) + sqr(wm.y));
     const float jacobian = rmax(2.0f * sqr(k_rgl_pi) * u_wm.x * sinThetaM, 1e-6f) * 4.0f * dot3(wi, wm);
     pdfOut = vndfPdf * pdf / jacobian;
@@ -546,7 +586,8 @@ WPT_RGL_HD V3 rglSampleWith(const wpt_rgl_brdf& b, const float* pool, const RglI
     wo.z = wm.z * 2.0f * dwm - wi.z;
     if (wo.z <= 0)
         return zero;
-    V3 fr = interleaved ? rglColourInterleaved(b, pool, pool + inc.rgbl, sample, inc.rgb) : rglColour(b, pool, sample, inc.rgb);
+    float unused = 0.0f;
+    V3 fr = interleaved ? rglColourInterleaved<false>(b, pool, pool + inc.rgbl, sample, inc.rgb, inc.luminance, unused) : rglColour(b, pool, sample, inc.rgb);
     const float params[2] = { inc.phi_i, inc.theta_i };
     const float n = warpEval<0>(b.ndf, pool, u_wm, params);
     const float d = inc.d;
