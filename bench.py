@@ -204,7 +204,13 @@ def roofline_of(name, scene, cnt, spp, count_sqrt, avg_ms, avg_samples, n_launch
         # the scene is LDS resident: what binds is vector issue.  Executed lane-operations = wave instructions x 64 lanes x
         # the fraction of lanes active in them (both from the committed PMC pass of this workload), at the live sample rate
         lane_ops = pmc["valu_insts_per_sample"] * 64.0 * pmc["valu_active_lane_fraction"] * avg_samples / (avg_ms * 1e-3) / 1e9
+        # `achieved` counts EXECUTED lane-operations, so it falls when instructions are taken out of the kernel although the frame
+        # gets faster (round 4: 645 -> 609 instructions per sample, 1020 -> 1055 Msamples/s, frac 0.181 -> 0.172); frac_at_round3_work
+        # prices the same frame with the work per sample round 3's kernel needed (645 x 64 x 0.3383 lane-operations), a fixed figure
+        round3_lane_ops_per_sample = 645.0 * 64.0 * 0.33826
         roofline = dict(common, bound="valu", achieved=lane_ops, peak=VALU_PEAK_GLANEOPS, unit="Glane-op/s", frac=lane_ops / VALU_PEAK_GLANEOPS,
+                        frac_at_round3_work=(round3_lane_ops_per_sample * avg_samples / (avg_ms * 1e-3) / 1e9 / VALU_PEAK_GLANEOPS
+                                             if name == "cornell_1024x1024_1024spp_ggx_glass" else None),
                         issue_slot_frac=pmc["valu_insts_per_sample"] * 2.0 * avg_samples / (avg_ms * 1e-3) / (1024 * 2.4e9),
                         active_lane_fraction=pmc["valu_active_lane_fraction"], valu_insts_per_sample=pmc["valu_insts_per_sample"],
                         note="scene in LDS: HBM sees the frame only (traffic); frac = issue_slot_frac x active_lane_fraction; "
