@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 4, first GPU call: parity of the cleaned kernels and of the wide walk, then config 4 under three libraries on ONE box
 # (round 2's tree at 4383e9e, round 3's at 5178f84, this tree; this tree also with the wide walk), twice over, then the other workloads
+# (r2tree / r3tree: git worktree add -f r2tree 4383e9e; make -C r2tree/wurblpt_amd/csrc -- and r3tree at 5178f84 with its library;
+# both were inside the repository for the call only, so that they travelled to the GPU box, and are removed again)
 set -o pipefail
 O=gpurun_out/r04a
 mkdir -p $O

@@ -2,6 +2,8 @@
 # round 4, second GPU call: the whole GPU suite on the changed kernels (node record as pairs, NaN test per ray, wide walk with its
 # stack of 96, the RCCL path at world size 1), config 4 with and without the wide walk, Cornell against round 3's library on the
 # same box, the scheduler's statistics for the instruction budget, and the default bench line with its three secondaries
+# (r2tree / r3tree: git worktree add -f r2tree 4383e9e; make -C r2tree/wurblpt_amd/csrc -- and r3tree at 5178f84 with its library;
+# both were inside the repository for the call only, so that they travelled to the GPU box, and are removed again)
 set -o pipefail
 O=gpurun_out/r04b
 mkdir -p $O
