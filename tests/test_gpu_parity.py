@@ -1218,6 +1218,20 @@ def test_triangle_storage_order_never_shows(dev, oracle):
             assert bits_equal(got, ref) and bits_equal(counted, ref) and gc == rc, flags
 
 
+def test_wide_walk_is_not_offered_to_a_tree_that_breaks_its_argument(dev, oracle):
+    """The wide walk's argument needs every child's box inside its parent's (then a child that passes implies the parent the
+    reference tested before it).  A caller's tree that breaks this -- here: the root's box cut short on one side, so that rays
+    from that side miss the root although its children's boxes would pass -- is uploaded without the wide form and walked as it
+    is: the frame is the oracle's, which walks the same broken tree like BVH::hit would."""
+    sc = host.courtyard_like(64, 40, seed=8, triangles=5000, tex_size=16)
+    root = sc.d.nodes[0]
+    assert root.kind == 0
+    root.hi[0] = 0.5 * (root.lo[0] + root.hi[0])
+    ref, _ = oracle.render(sc, 2)
+    _, got = _wide(dev, sc, 2, expect_wide=False)
+    assert bits_equal(got, ref)
+
+
 def test_fuzz_parity_with_the_wide_walk():
     """tools/fuzz_parity.py --wide, three rounds: 21 seeded random scenes of every family uploaded with the wide form."""
     import os
