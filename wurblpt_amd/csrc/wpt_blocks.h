@@ -87,6 +87,10 @@ struct Slot {
 struct PathHot {
     f3 o, d;      /* the ray being traced (Ray::origin, Ray::direction) */
     int rayKind;
+    /* wavefront form (blockShade<..., MERGED>): the light ray of the hit just shaded, which travels BESIDE the path's continuation;
+     * neeKind: 0 = none, RAY_NEE_LIGHT, RAY_NEE_ENV */
+    f3 neeO, neeD;
+    int neeKind;
     float time;   /* FEAT_ANIM: the path's time (Ray::time; the thread's AnimationCache is set to it, wurblpt.hpp:361) */
     /* FEAT_ANIM: the lane's AnimationCache, one entry deep -- the matrix of the animation it used last at `time`.
      * Consecutive leaf tests of a walk mostly hit triangles of one instance, and the lights share few animations. */
@@ -213,6 +217,7 @@ template<class PS> WPT_D void pathStateInit(PS& ps, uint32_t pixel, uint32_t px,
     ps.o = mk3(0.0f, 0.0f, 0.0f);
     ps.d = mk3(0.0f, 0.0f, 1.0f);
     ps.rayKind = RAY_PATH;
+    ps.neeKind = 0;
     ps.time = 0.0f;
     ps.animCached = -1;
 }
@@ -471,8 +476,15 @@ WPT_D int blockNew(const FrameArgs& fa, PS& ps, const SceneView& sv)
     return NEXT_TRACE;
 }
 
-/* tracePath, one path component (wurblpt.hpp:131-252); `best` is the path ray's result */
-template<uint32_t F, bool COUNT, class Tri4, class PS>
+/* tracePath, one path component (wurblpt.hpp:131-252); `best` is the path ray's result.
+ * MERGED (the wavefront form): a light ray does not hold the path up.  What follows its end in the reference -- the Russian roulette
+ * and the continuation, wurblpt.hpp:254-273 -- depends on the scatter alone, not on the light ray's answer, and the roulette's draw
+ * is the generator's next one either way (nothing draws while the light ray is traced); so the block goes on to advancePath at once
+ * and leaves the light ray in ps.neeO / neeD / neeKind to be traced beside the continuation.  Its answer is added by blockNeeResult
+ * at the start of the pixel's next shading, before anything else touches the accumulator: the additions keep the reference's order.
+ * What that needs of THIS hit -- the factor and the chosen hot spot (SLOT_NEE), the optical path length and the refractive index --
+ * waits in the two slots the single kernel uses for the continuation (SLOT_NEXTATT, SLOT_SRDIR x y z), which are free here. */
+template<uint32_t F, bool COUNT, class Tri4, class PS, bool MERGED = false>
 WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& ps, const Candidate& best, LaneCounters& lc, int waitBelow = 0)
 {
     const bool haveEnv = (F & FEAT_ENVMAP) && sv.envType != WPT_ENV_NONE;
@@ -610,14 +622,22 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
                 nee.x = neeFactor.x; nee.y = neeFactor.y; nee.z = neeFactor.z;
                 nee.w = hotSpotPrim;
                 ps.set(SLOT_NEE, nee);
-                ps.set4(SLOT_NEXTATT, nextAtt);
-                ps.set3(SLOT_SRDIR, sr.dir);
-                storePrng(ps, prng);
-                ps.o = h.p;
-                ps.d = directDir;
-                ps.rayKind = RAY_NEE_LIGHT;
-                section(6);
-                return NEXT_TRACE;
+                if (MERGED) {
+                    ps.set3(SLOT_NEXTATT, opl);
+                    ps.set3(SLOT_SRDIR, mk3(ray.ri.x, ray.ri.y, ray.ri.z));
+                    ps.neeO = h.p;
+                    ps.neeD = directDir;
+                    ps.neeKind = RAY_NEE_LIGHT;
+                } else {
+                    ps.set4(SLOT_NEXTATT, nextAtt);
+                    ps.set3(SLOT_SRDIR, sr.dir);
+                    storePrng(ps, prng);
+                    ps.o = h.p;
+                    ps.d = directDir;
+                    ps.rayKind = RAY_NEE_LIGHT;
+                    section(6);
+                    return NEXT_TRACE;
+                }
             }
         }
     } else if ((F & FEAT_ENVMAP) && sr.type == SCATTER_RANDOM && haveEnv && sv.envN > 0) {
@@ -632,14 +652,20 @@ WPT_D int blockShade(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& 
         if (dpdf > 0.0f) {
             const f4 neeFactor = sclr(divs(mul(att, directAtt), directPdf), powerHeuristicWeight(directPdf, dpdf));
             ps.set3(SLOT_NEE, mk3(neeFactor.x, neeFactor.y, neeFactor.z));
-            ps.set4(SLOT_NEXTATT, nextAtt);
-            ps.set3(SLOT_SRDIR, sr.dir);
-            storePrng(ps, prng);
-            ps.o = h.p;
-            ps.d = lightDir;
-            ps.rayKind = RAY_NEE_ENV;
-            section(7);
-            return NEXT_TRACE;
+            if (MERGED) {
+                ps.neeO = h.p;
+                ps.neeD = lightDir;
+                ps.neeKind = RAY_NEE_ENV; /* (its end needs no path lengths: the environment is infinitely far, wurblpt.hpp:244-248) */
+            } else {
+                ps.set4(SLOT_NEXTATT, nextAtt);
+                ps.set3(SLOT_SRDIR, sr.dir);
+                storePrng(ps, prng);
+                ps.o = h.p;
+                ps.d = lightDir;
+                ps.rayKind = RAY_NEE_ENV;
+                section(7);
+                return NEXT_TRACE;
+            }
         }
     }
     /* No next-event ray.  The scattered ray's refractive index: every ScatterRandom record
@@ -691,6 +717,30 @@ WPT_D int blockNeeEnd(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS&
     if (roulette)
         storePrng(ps, prng);
     return next;
+}
+
+/* MERGED: the answer of the light ray that travelled beside the continuation (ps.neeKind, ps.neeO, ps.neeD; `neeBest` its result):
+ * the first half of blockNeeEnd (wurblpt.hpp:208-218,240-250) with this hit's optical path length and refractive index from
+ * the slots blockShade<MERGED> left them in */
+template<uint32_t F, class Tri4, class PS>
+WPT_D void blockNeeResult(const SceneView& sv, const wpt_params& par, Tri4 tri4, PS& ps, const Candidate& neeBest)
+{
+    const Slot nee = ps.get(SLOT_NEE);
+    if (ps.neeKind == RAY_NEE_LIGHT) {
+        if (neeBest.prim == nee.w) {
+            Hit lh = finishHit<F>(sv, neeBest, ps.neeO, ps.neeD, ps.time, tri4);
+            const wpt_material& lm = resolveMaterial<F>(sv, lh.material, lh);
+            f4 rad = mul(mk4(nee.x, nee.y, nee.z, 0.0f), materialEmitted<F>(sv, lm, lh));
+            const Slot opl = ps.get(SLOT_NEXTATT), ri = ps.get(SLOT_SRDIR);
+            f3 oplLight = add(mk3(opl.x, opl.y, opl.z), scl(lh.a, mk3(ri.x, ri.y, ri.z)));
+            accumulateRadiance(par, oplLight, lh.a, rad, ps);
+        }
+    } else if (F & FEAT_ENVMAP) {
+        if (neeBest.prim == NO_HIT) {
+            f4 rad = mul(mk4(nee.x, nee.y, nee.z, 0.0f), envL(sv, ps.neeD));
+            accumulateRadiance(par, mk3(k_maxval, k_maxval, k_maxval), k_maxval, rad, ps);
+        }
+    }
 }
 
 } /* namespace wptk */

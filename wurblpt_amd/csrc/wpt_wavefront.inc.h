@@ -24,10 +24,18 @@
  *
  * Per lane of the launch: one record of 16 quadwords (256 B) in HBM --
  *   0..7   the cold words of wpt_blocks.h (generator, attenuations, accumulator, ...), one 128-byte line
- *   8      ray origin, time          9   ray direction, kind of ray
- *   10     candidate: primitive, distance, 1 / det, U        11   V, W
- *   12     a suspended walk: next node, bound
- *   13..15 free
+ *   8      the path ray's origin, time              9    its direction, the pixel's state word (WF_W_*)
+ *   10     its candidate: primitive, distance, 1 / det, U          11   V, W | the light ray's candidate: V, W
+ *   12     the light ray's candidate: primitive, distance, 1 / det, U
+ *   13     the light ray's origin | a suspended walk's next node     14   its direction | a suspended walk's bound
+ *   15     free
+ *
+ * Two rays per pixel and iteration (round 4).  A hit's light ray and the path's continuation are traced in the SAME iteration:
+ * what follows a light ray's end in the reference -- Russian roulette, continuation -- does not depend on its answer
+ * (wpt_blocks.h, blockShade<MERGED>), so the shade kernel sets both rays up, the trace kernel walks them one after the other
+ * in one lane (light ray first), and the next shading adds the light ray's answer before it does anything else
+ * (blockNeeResult): the accumulator sees the reference's additions in the reference's order.  Half the iterations, one
+ * round trip of a pixel's record per path component instead of two.
  *
  * The walk of a light ray towards the environment ends at its first accepted hit, as in the single kernel (the answer it is
  * traced for -- anything in the way? -- is known there).
@@ -51,13 +59,19 @@ constexpr uint32_t WF_SLOTS = 16; /* quadwords per lane record */
  * highest rate at two to four waves per SIMD and fall off beyond (tools/micro/node_fetch.hip: 262 G fetches per second at
  * four, 137 G at eight for 17 MB of nodes) -- the lines a compute unit's lanes have in flight outgrow its L1. */
 constexpr int WF_TRACE_WAVES = 4;
-enum { WF_RAY_O = 8, WF_RAY_D = 9, WF_HIT0 = 10, WF_HIT1 = 11, WF_WALK = 12 };
-constexpr uint32_t WF_RESUME = 0x100u; /* in the kind-of-ray word: the record holds a suspended walk */
+enum { WF_RAY_O = 8, WF_RAY_D = 9, WF_HIT0 = 10, WF_HIT1 = 11, WF_NEE_HIT = 12, WF_NEE_O = 13, WF_NEE_D = 14 };
+/* the pixel's state word (record quadword 9, w) */
+constexpr uint32_t WF_W_PATH = 1u;        /* a path ray is to be traced (or has been: its candidate is in the record) */
+constexpr uint32_t WF_W_NEE_SHIFT = 1;    /* bits 1-2: the light ray beside it: 0 none, RAY_NEE_LIGHT, RAY_NEE_ENV */
+constexpr uint32_t WF_W_NEE_MASK = 3u << WF_W_NEE_SHIFT;
+constexpr uint32_t WF_W_FINISH = 8u;      /* the pixel's samples are through; its last light ray's answer is still to be added */
+constexpr uint32_t WF_RESUME = 0x100u;    /* the record holds a suspended walk ... */
+constexpr uint32_t WF_RESUME_PATH = 0x200u; /* ... of the path ray (the light ray is through), else of the light ray */
 
 /* kinds a traced pixel is filed under for shading; a wave of wf_shade serves one kind */
 enum {
     WF_B_MISS = 0,     /* path ray left the scene: environment radiance, next sample */
-    WF_B_NEE = 1,      /* a next-event ray came back */
+    WF_B_NEE = 1,      /* no path ray: the pixel's last light ray came back */
     WF_B_LIGHT = 2,    /* path ray on an emitter: emission, path ends */
     WF_B_LAMBERT = 3,
     WF_B_MODPHONG = 4,
@@ -104,10 +118,10 @@ enum { T_NODE = 0, T_LEAF = 1, T_DONE = 2, T_IDLE = 3, T_SUSPEND = 4 };
 
 /* kind of shading a traced ray needs (TwoSided resolved as resolveMaterial does, material.hpp:273-320).  Only the
  * grouping of lanes into waves depends on it, never a value. */
-template<bool SPHERES> WPT_D uint32_t shadeKind(const SceneView& sv, uint32_t rayKind, uint32_t prim, float invDet)
+template<bool SPHERES> WPT_D uint32_t shadeKind(const SceneView& sv, uint32_t word, uint32_t prim, float invDet)
 {
-    if (rayKind != RAY_PATH)
-        return WF_B_NEE;
+    if (!(word & WF_W_PATH))
+        return WF_B_NEE; /* nothing to shade: a last light ray's answer, then the pixel is written */
     if (prim == NO_HIT)
         return WF_B_MISS;
     uint32_t mat;
@@ -189,6 +203,22 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
     best.prim = NO_HIT;
     best.a = best.invDet = best.U = best.V = best.W = 0.0f;
     float4 pn0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pn1 = pn0;
+    bool pathPhase = true; /* the lane walks its pixel's path ray (else: the light ray beside it) */
+    /* the lane starts the ray of its phase from the root */
+    auto startRay = [&](const float4* rec, uint32_t word) {
+        const float4 ro = rec[pathPhase ? WF_RAY_O : WF_NEE_O], rd = rec[pathPhase ? WF_RAY_D : WF_NEE_D];
+        o = mk3(ro.x, ro.y, ro.z);
+        d = mk3(rd.x, rd.y, rd.z);
+        aux = rayAux(d);
+        if (rayMayNan(o, aux.inv)) /* only such rays test their slab distances for NaN per box (wpt_device.h) */
+            aux.k |= RAY_MAY_NAN;
+        node = 0;
+        amax = k_maxval;
+        best.prim = NO_HIT;
+        state = T_NODE;
+        /* a light ray towards the environment: its walk ends at the first accepted hit (wpt_pathtrace.inc.h) */
+        shadowRay = !pathPhase && a.k.shadowWalksEnd != 0 && ((word & WF_W_NEE_MASK) >> WF_W_NEE_SHIFT) == (uint32_t)RAY_NEE_ENV;
+    };
 
     for (;;) {
         /* ---- deal rays to the lanes that have none ---- */
@@ -215,30 +245,22 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                     dealt = true;
                     gid = queue[chunkNext + rank];
                     const float4* rec = a.state + (size_t)gid * WF_SLOTS;
-                    const float4 ro = rec[WF_RAY_O], rd = rec[WF_RAY_D];
-                    o = mk3(ro.x, ro.y, ro.z);
-                    d = mk3(rd.x, rd.y, rd.z);
-                    aux = rayAux(d);
-                    if (rayMayNan(o, aux.inv)) /* only such rays test their slab distances for NaN per box (wpt_device.h) */
-                        aux.k |= RAY_MAY_NAN;
-                    node = 0;
-                    amax = k_maxval;
-                    best.prim = NO_HIT;
-                    if (__float_as_uint(rd.w) & WF_RESUME) { /* a suspended walk goes on */
-                        const float4 h0 = rec[WF_HIT0], h1 = rec[WF_HIT1], wk = rec[WF_WALK];
+                    const uint32_t word = __float_as_uint(rec[WF_RAY_D].w);
+                    /* the light ray first (if there is one and it is not through yet), then the path ray */
+                    pathPhase = (word & WF_RESUME) ? (word & WF_RESUME_PATH) != 0 : (word & WF_W_NEE_MASK) == 0;
+                    startRay(rec, word);
+                    if (word & WF_RESUME) { /* a suspended walk goes on */
+                        const float4 h0 = rec[pathPhase ? WF_HIT0 : WF_NEE_HIT], h1 = rec[WF_HIT1];
                         best.prim = __float_as_uint(h0.x);
                         best.a = h0.y;
                         best.invDet = h0.z;
                         best.U = h0.w;
-                        best.V = h1.x;
-                        best.W = h1.y;
-                        node = __float_as_uint(wk.x);
-                        amax = wk.y;
+                        best.V = pathPhase ? h1.x : h1.z;
+                        best.W = pathPhase ? h1.y : h1.w;
+                        node = __float_as_uint(rec[WF_NEE_O].w);
+                        amax = rec[WF_NEE_D].w;
                     }
                     stepsLeft = a.stepBudget ? a.stepBudget : 0xffffffffu;
-                    state = T_NODE;
-                    /* a light ray towards the environment: its walk ends at the first accepted hit (wpt_pathtrace.inc.h) */
-                    shadowRay = a.k.shadowWalksEnd != 0 && (__float_as_uint(rd.w) & ~WF_RESUME) == (uint32_t)RAY_NEE_ENV;
                 }
                 fetchNode(node, dealt, pn0, pn1);
                 chunkNext += take;
@@ -309,29 +331,42 @@ __global__ __launch_bounds__(WG, WF_TRACE_WAVES) void wf_trace(const WfArgs a)
                 fetchNode(node, wantNode, pn0, pn1);
             }
         }
-        /* ---- finished rays: the candidate goes to the pixel's record, the pixel to the queue of its kind; rays out of
-         * steps are written back as they stand and queued for the next trace ---- */
+        /* ---- finished rays: the candidate goes to the pixel's record; a light ray's lane goes on with the pixel's path ray;
+         * a pixel whose rays are through goes to the queue of its kind; rays out of steps are written back as they stand and
+         * queued for the next trace ---- */
         if (__ballot(state == T_DONE || state == T_SUSPEND) != 0) {
             uint32_t kind = WF_BUCKETS;
             const bool suspend = state == T_SUSPEND;
+            bool again = false; /* the lane has started its pixel's path ray */
             if (state == T_DONE || suspend) {
                 float4* rec = a.state + (size_t)gid * WF_SLOTS;
-                rec[WF_HIT0] = make_float4(__uint_as_float(best.prim), best.a, best.invDet, best.U);
-                rec[WF_HIT1] = make_float4(best.V, best.W, 0.0f, 0.0f);
-                uint32_t* kindWord = reinterpret_cast<uint32_t*>(rec + WF_RAY_D) + 3;
-                const uint32_t kw = *kindWord; /* the kind of ray is read again here: one register less while walking */
+                rec[pathPhase ? WF_HIT0 : WF_NEE_HIT] = make_float4(__uint_as_float(best.prim), best.a, best.invDet, best.U);
+                float* vw = reinterpret_cast<float*>(rec + WF_HIT1) + (pathPhase ? 0 : 2);
+                vw[0] = best.V;
+                vw[1] = best.W;
+                uint32_t* wordAt = reinterpret_cast<uint32_t*>(rec + WF_RAY_D) + 3;
+                const uint32_t word = *wordAt; /* read again here: one register less while walking */
+                const uint32_t clean = word & ~(WF_RESUME | WF_RESUME_PATH);
                 if (suspend) {
-                    rec[WF_WALK] = make_float4(__uint_as_float(node), amax, 0.0f, 0.0f);
-                    if (!(kw & WF_RESUME))
-                        *kindWord = kw | WF_RESUME;
+                    reinterpret_cast<uint32_t*>(rec + WF_NEE_O)[3] = node;
+                    reinterpret_cast<float*>(rec + WF_NEE_D)[3] = amax;
+                    *wordAt = clean | WF_RESUME | (pathPhase ? WF_RESUME_PATH : 0u);
+                    state = T_IDLE;
+                } else if (!pathPhase && (word & WF_W_PATH)) {
+                    if (word != clean)
+                        *wordAt = clean;
+                    pathPhase = true;
+                    startRay(rec, clean);
+                    again = true;
                 } else {
-                    if (kw & WF_RESUME)
-                        *kindWord = kw & ~WF_RESUME; /* through: the record holds a result again */
+                    if (word != clean)
+                        *wordAt = clean; /* through: the record holds results only */
                     if (a.buckets)
-                        kind = shadeKind<SPHERES>(sv, kw & ~WF_RESUME, best.prim, best.invDet);
+                        kind = shadeKind<SPHERES>(sv, clean, best.prim, best.invDet);
+                    state = T_IDLE;
                 }
-                state = T_IDLE;
             }
+            fetchNode(node, again, pn0, pn1);
             const unsigned long long suspended = __ballot(suspend);
             if (suspended != 0) {
                 uint32_t base = 0;
@@ -452,10 +487,12 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
     bool have = entry < count;
     uint32_t gid = 0;
     float4* rec = a.state;
-    Candidate best;
-    best.prim = NO_HIT;
+    Candidate best, neeBest;
+    best.prim = neeBest.prim = NO_HIT;
     best.a = best.invDet = best.U = best.V = best.W = 0.0f;
+    neeBest.a = neeBest.invDet = neeBest.U = neeBest.V = neeBest.W = 0.0f;
     int next = NEXT_DONE;
+    uint32_t word = 0; /* the pixel's state as the trace left it: WF_W_* */
     if (INIT) {
         gid = a.laneFirst + entry;
         uint32_t pixel = a.k.blockStart;
@@ -468,7 +505,8 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
         ps.time = 0.0f;
         ps.animCached = -1;
         ps.rayKind = RAY_PATH;
-        ps.o = ps.d = mk3(0.0f, 0.0f, 1.0f);
+        ps.neeKind = 0;
+        ps.o = ps.d = ps.neeO = ps.neeD = mk3(0.0f, 0.0f, 1.0f);
         if (have) {
             gid = queueIn[entry];
             rec = a.state + (size_t)gid * WF_SLOTS;
@@ -476,11 +514,11 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
             for (int k = 0; k < SLOT_COUNT; k++)
                 ps.base[k * WG] = rec[k];
             const float4 ro = rec[WF_RAY_O], rd = rec[WF_RAY_D], h0 = rec[WF_HIT0], h1 = rec[WF_HIT1];
+            word = __float_as_uint(rd.w);
             ps.o = mk3(ro.x, ro.y, ro.z);
             ps.time = ro.w;
             ps.d = mk3(rd.x, rd.y, rd.z);
-            ps.rayKind = (int)__float_as_uint(rd.w);
-            if (__float_as_uint(rd.w) & WF_RESUME)
+            if (word & WF_RESUME)
                 have = false; /* (walking the ray queue) a suspended walk: the trace has queued it again itself */
             best.prim = __float_as_uint(h0.x);
             best.a = h0.y;
@@ -488,19 +526,40 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
             best.U = h0.w;
             best.V = h1.x;
             best.W = h1.y;
+            ps.neeKind = (int)((word & WF_W_NEE_MASK) >> WF_W_NEE_SHIFT);
+            if (ps.neeKind != 0) {
+                const float4 n0 = rec[WF_NEE_HIT], no = rec[WF_NEE_O], nd = rec[WF_NEE_D];
+                neeBest.prim = __float_as_uint(n0.x);
+                neeBest.a = n0.y;
+                neeBest.invDet = n0.z;
+                neeBest.U = n0.w;
+                neeBest.V = h1.z;
+                neeBest.W = h1.w;
+                ps.neeO = mk3(no.x, no.y, no.z);
+                ps.neeD = mk3(nd.x, nd.y, nd.z);
+            }
         }
     }
+    bool finish = false; /* the pixel's samples are through and a light ray is still out: one more iteration for its answer */
     if (have) {
         LaneCounters lc = LANE_COUNTERS_ZERO;
         if (!INIT) {
-            if (ps.rayKind == RAY_PATH)
-                next = blockShade<F, false>(sv, par, tri4, ps, best, lc, 0); /* tracePath, one path component (wurblpt.hpp:131-252) */
+            /* the answer of the light ray that travelled beside this path ray, first: the accumulator's additions in the
+             * reference's order (wurblpt.hpp:208-218,240-250, then :131-178 of the next component) */
+            if (ps.neeKind != 0)
+                blockNeeResult<F>(sv, par, tri4, ps, neeBest);
+            ps.neeKind = 0;
+            if (word & WF_W_PATH)
+                next = blockShade<F, false, TriGeomFromScene, PathLds<WG>, true>(sv, par, tri4, ps, best, lc, 0); /* tracePath, one path component (wurblpt.hpp:131-273) */
             else
-                next = blockNeeEnd<F>(sv, par, tri4, ps, best);            /* the next-event ray's contribution, then the path continues */
+                next = NEXT_DONE; /* (WF_W_FINISH) nothing but that answer was left */
         }
-        if (next == NEXT_NEW) { /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
+        if (next == NEXT_NEW) /* the pixel's next sample (wurblpt.hpp:348-360), or nothing more */
             next = blockNew<F>(fa, ps, sv);
-            if (next == NEXT_DONE) {
+        if (next == NEXT_DONE) {
+            if (ps.neeKind != 0) {
+                finish = true; /* the last path ended behind a hit whose light ray is still to be traced */
+            } else {
                 /* SensorRGB::finishPixel (sensor_rgb.hpp:82-87) */
                 const uint32_t pxy = ps.getW(SLOT_SRDIR);
                 const size_t at = (size_t)(pxy >> 16) * a.k.width + (pxy & 0xffffu);
@@ -511,16 +570,21 @@ __global__ __launch_bounds__(WG, WF_SHADE_WAVES) void wf_shade(const WfArgs a)
                 out[2] = a.k.invSamples * acc.z;
             }
         }
-        if (next == NEXT_TRACE) {
+        if (next == NEXT_TRACE || finish) {
 #pragma unroll
             for (int k = 0; k < SLOT_COUNT; k++)
                 rec[k] = ps.base[k * WG];
+            const uint32_t out = (next == NEXT_TRACE ? WF_W_PATH : WF_W_FINISH) | ((uint32_t)ps.neeKind << WF_W_NEE_SHIFT);
             rec[WF_RAY_O] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.time);
-            rec[WF_RAY_D] = make_float4(ps.d.x, ps.d.y, ps.d.z, __uint_as_float((uint32_t)ps.rayKind));
+            rec[WF_RAY_D] = make_float4(ps.d.x, ps.d.y, ps.d.z, __uint_as_float(out));
+            if (ps.neeKind != 0) {
+                rec[WF_NEE_O] = make_float4(ps.neeO.x, ps.neeO.y, ps.neeO.z, 0.0f);
+                rec[WF_NEE_D] = make_float4(ps.neeD.x, ps.neeD.y, ps.neeD.z, 0.0f);
+            }
         }
     }
     /* ---- the pixels that go on are queued for the next trace: one atomic per workgroup ---- */
-    const bool alive = have && next == NEXT_TRACE;
+    const bool alive = have && (next == NEXT_TRACE || finish);
     const unsigned long long aliveMask = __ballot(alive);
     const uint32_t wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63u) == 0)

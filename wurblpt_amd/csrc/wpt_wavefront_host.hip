@@ -100,7 +100,10 @@ hipError_t renderWavefront(const KernelArgs& args, const WfLaunchers& kernels, c
     const uint32_t lanes = args.blockSize;
     /* groups of whole workgroups, none smaller than a quarter of what the device holds at once */
     const uint32_t resident = std::max(1u, args.cuCount) * WF_TRACE_WAVES * WG;
-    uint32_t groupCount = cfg.groups ? cfg.groups : 2u;
+    /* one group by default: since a hit's light ray travels beside the continuation (half the iterations, fuller launches) the
+     * overlap of two groups' kernels no longer pays for the smaller launches (measured BRDFs, 16 spp: 135.7 Msamples/s with one
+     * group, 133.6 with two, 130.1 with three, 121.3 with four; round 3's form: 317 / 322 / 311 / 429 ms on the Sponza-class frame) */
+    uint32_t groupCount = cfg.groups ? cfg.groups : 1u;
     groupCount = std::min(groupCount, MAX_GROUPS);
     while (groupCount > 1 && lanes / groupCount < resident / 4u)
         groupCount--;
