@@ -316,6 +316,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cornell_1024x1024_1024spp_ggx_glass", choices=sorted(WORKLOADS))
     ap.add_argument("--samples-sqrt", type=int, default=0, help="override spp (debug only; changes the workload name)")
+    ap.add_argument("--count-sqrt", type=int, default=0, help="counted pass (work per sample for the roofline) on the same pixels with this samples_sqrt instead of the frame's (roofline.counted_on says so); 0 = the frame's own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: do not measure the workloads whose scene is fetched from HBM (BASELINE configs 3 - 5) beside the primary one")
@@ -427,7 +428,7 @@ def main():
     sharded = distributed or args.force_blocks > 0
     if not sharded:
         # ---- N = 1: one render call per step ----
-        m, frame = measure_one_gpu(name, w, scene, dscene, args.steps, args.warmup, cpu_seconds, lib_id, torch, device, host, barrier, walk_flags)
+        m, frame = measure_one_gpu(name, w, scene, dscene, args.steps, args.warmup, cpu_seconds, lib_id, torch, device, host, barrier, walk_flags, count_sqrt=args.count_sqrt or None)
         verified = None
         out = {
             "metric": "Msamples/s", "value": m["value"], "unit": "Msamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,

@@ -36,7 +36,7 @@ done
 echo done courtyard
 fi
 if [[ $PART == *m* ]]; then
-M="--workload measured_like_3840x2160_529spp_rgl --steps 1 --warmup 0 --no-secondary"
+M="--workload measured_like_3840x2160_529spp_rgl --steps 1 --warmup 0 --no-secondary --count-sqrt 6"
 timeout -k 10 700 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_${TAG}_measured -o stats --output-format csv -- python3 bench.py $M --no-cpu-baseline > gpurun_out/stats_${TAG}_measured.log 2>&1 || exit 1
 for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "VALUBusy VALUUtilization"; do
   N=$(echo $P | tr " " "_" | cut -c1-40)

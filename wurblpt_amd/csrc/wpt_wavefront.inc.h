@@ -13,14 +13,14 @@
  *              (per-wave staging in LDS, one atomic per flush of up to 64 pixels).
  *   wf_shade   one lane per filed pixel, a wave per kind: the pixel's cold words are copied from its record into the LDS
  *              slots the blocks of wpt_blocks.h work on (the layout of the single kernel's long round), one path
- *              component is evaluated (blockShade / blockNeeEnd, then blockNew where the path ended), record and next
- *              ray are written back and the pixel is queued for the next trace (one atomic per workgroup).
+ *              component is evaluated (blockNeeResult for the light ray that travelled beside the path ray, blockShade, then
+ *              blockNew where the path ended), record and next rays are written back and the pixel is queued for the next trace
+ *              (one atomic per workgroup).
  *
- * One pixel still has one ray in flight and draws from its one generator in the reference's order (prng.hpp:79-101,
- * wurblpt.hpp:342-366): a frame is the same bit for bit as the single kernel's and the oracle's.  An iteration is
- * trace + shade; the number of iterations is the largest number of rays any pixel of the launch traces.  The launch's
- * lanes are cut into groups that iterate on streams of their own, so that one group's shading runs beside another's
- * walk and the end of one kernel (its longest rays) is filled by the other.
+ * A pixel draws from its one generator in the reference's order (prng.hpp:79-101, wurblpt.hpp:342-366) and its accumulator receives the
+ * reference's additions in the reference's order: a frame is the same bit for bit as the single kernel's and the oracle's.  An iteration
+ * is trace + shade; the number of iterations is the largest number of path rays any pixel of the launch traces.  The launch's lanes may be
+ * cut into groups that iterate on streams of their own (wpt_set_wavefront; one group by default).
  *
  * Per lane of the launch: one record of 16 quadwords (256 B) in HBM --
  *   0..7   the cold words of wpt_blocks.h (generator, attenuations, accumulator, ...), one 128-byte line
