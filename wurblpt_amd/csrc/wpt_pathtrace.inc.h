@@ -167,6 +167,12 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
      * Msamples/s on the Cornell frame (2: 839, 4: 841, 6: 836, 8: 791: lanes that reach a leaf wait out the rest); from
      * HBM the steps are memory round trips and nothing is gained. */
     constexpr int STEPS = LDSSCENE ? 3 : 1;
+    /* Lanes at the end of a light ray that the walk serves itself (0: they wait for the long round).  Kernels that fetch the scene
+     * from HBM wait for memory, not for instruction issue: there a lane that walks on sooner is worth the extra run of the short
+     * block (Sponza-class 152.7 -> 158.0 Msamples/s with 3 or 4 lanes, 157.3 / 156.8 with 8 / 12, 155.1 with 2; measured BRDFs in
+     * the single kernel 106.1 -> 112.5; 10 M triangles 67.97 -> 68.09).  With the scene in LDS the frame is bound by the
+     * instructions its waves issue and the same costs (Cornell 1055.6 against 1038.7 / 1049.1 / 1036.0 with 8 / 16 / 24). */
+    constexpr int NEE_IN_WALK = LDSSCENE ? 0 : 4;
     /* [ math tables ][ cold path words: SLOT_COUNT x WG float4 ][ LDSSCENE: nodes, triangle positions ] */
     extern __shared__ float4 lds[];
     float4* const ldsCold = lds + TABLE_BYTES / 16;
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
              * of the iteration before, so that the fetch runs behind the loop's ballots and branches */
             float4 pn0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pn1 = pn0;
             /* does any ray of the wave need its slab distances tested for NaN? (rays start in the long round only) */
-            const bool nanPossible = sv.boxesMayBeNan != 0 || __ballot((aux.k & RAY_MAY_NAN) != 0 && (state == S_NODE || state == S_LEAF)) != 0;
+            bool nanPossible = sv.boxesMayBeNan != 0 || __ballot((aux.k & RAY_MAY_NAN) != 0 && (state == S_NODE || state == S_LEAF)) != 0;
             /* AABB::mayHit + the stackless form of BVH::hit's walk: one node step of the lanes in state NODE (WIDE: of those among
              * them that walk the binary tree) */
                 auto binaryStep = [&]() {
@@ -407,6 +413,25 @@ __global__ __launch_bounds__(WG, OCC) void wpt_pathtrace(const KernelArgs args)
                 const int nLeaf = __popcll(__ballot(state == S_LEAF));
                 if (nNode + nLeaf < leaveBelow)
                     break;
+                /* The end of a light ray is a short block (its contribution, roulette, the continuation's start): lanes that
+                 * wait for it do not have to wait for the long round -- once NEE_IN_WALK of them are there, the walk serves them
+                 * and they walk on with the rest.  (The same block as in the long round; a lane's order of operations is its own.) */
+                if (NEE_IN_WALK > 0 && !COUNT) {
+                    const int nNee = __popcll(__ballot(state == S_NEEEND));
+                    if (nNee >= NEE_IN_WALK) {
+                        if (state == S_NEEEND)
+                            afterBlock(blockNeeEnd<F>(sv, par, tri4, ps, best));
+                        if (state == S_START) {
+                            beginRay();
+                            if (PREFETCH) {
+                                pn0 = node4(2 * node);
+                                pn1 = node4(2 * node + 1);
+                            }
+                        }
+                        nanPossible = nanPossible || __ballot((aux.k & RAY_MAY_NAN) != 0 && state == S_NODE) != 0; /* rays have started */
+                        continue;
+                    }
+                }
                 /* a leaf test is ~3 node steps long; it runs once enough lanes wait for it
                  * (leafBias/8 of the walking lanes), because waiting lanes thin out the walk */
                 if (nLeaf * (int)args.leafBias >= nNode * 8 && nLeaf > 0) {
