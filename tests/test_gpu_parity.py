@@ -1052,12 +1052,14 @@ def test_wavefront_kernels_bit_exact(dev, oracle, groups, chunk, flags):
 def test_wavefront_is_the_default_only_where_it_was_measured_faster(dev, oracle):
     """Large frames of scenes with measured BRDFs go to the wavefront kernels by themselves; everything else, counting launches
     and moving scenes stay with the single kernel whatever is asked for."""
-    sc = host.measured_like(1024, 1024, host.rgl_fixture("iso"), host.rgl_fixture("aniso"), seed=5, detail=0.03, tex_size=16, env_width=32, importance_n=8)
+    sc = host.measured_like(2048, 1024, host.rgl_fixture("iso"), host.rgl_fixture("aniso"), seed=5, detail=0.03, tex_size=16, env_width=32, importance_n=8)
     tables = oracle.envmap_tables(sc)
     ds = dev.DeviceScene(sc)            # the device builds its own tables at upload
     sc.set_envmap_tables(*tables)
-    got, _ = ds.render(1)
+    got, _ = ds.render(1)               # 2^21 lanes: from there on the wavefront form is the faster one (tools/wf_threshold_probe.py)
     assert dev.lib().wpt_kernel_name() == b"wf_trace + wf_shade"
+    half, _ = ds.render(1, block=(0, 1024 * 1024))   # half of them: the single kernel
+    assert dev.lib().wpt_kernel_name() == b"wpt_pathtrace" and bits_equal(half[:512], got[:512])
     try:
         _wavefront(dev, 2)
         single, _ = ds.render(1)
@@ -1066,7 +1068,7 @@ def test_wavefront_is_the_default_only_where_it_was_measured_faster(dev, oracle)
         _wavefront(dev, 0)
     assert bits_equal(got, single)
     rows = slice(500, 502)
-    ref, _ = oracle.render(sc, 1, block=(500 * 1024, 2 * 1024))
+    ref, _ = oracle.render(sc, 1, block=(500 * 2048, 2 * 2048))
     assert bits_equal(got[rows], ref[rows])
     small = dev.DeviceScene(host.cornell(64, 64, 1, 2))
     small.render(2)

@@ -959,11 +959,13 @@ static wpt_status renderLaunch(wpt_scene* scene, const wpt_camera* camera, const
     /* Wavefront form (wpt_wavefront.inc.h): trace and shade as two kernels that hand rays through HBM.  Not for counting
      * launches and moving scenes (those instantiations exist for the single kernel only). */
     const bool wfExists = !count && !anim;
-    /* The library's own choice (measured): frames of a million pixels and more whose scene has measured
-     * BRDFs -- long shading that pays for being sorted by kind of material (Bistro-class frame 111 against 90 Msamples/s).
-     * Scenes whose time is the walk stay with the single kernel: the wavefront trace meets the same wall of the memory
-     * system (Sponza-class 105 against 134, 10 M triangles 38 against 63) and pays for the rays' way through HBM on top. */
-    const bool wfAuto = rgl && block_size >= (1u << 20);
+    /* The library's own choice (measured): launches of 2^21 lanes and more whose scene has measured BRDFs --
+     * long shading that pays for being sorted by kind of material, and enough lanes to fill the trace and the shade kernel one
+     * after the other (tools/wf_threshold_probe.py, 16 spp, single kernel / wavefront: 115.5 / 100.7 Msamples/s at 2^20 lanes,
+     * 118.0 / 116.4 at 1.97 M, 113.6 / 126.9 at 4.1 M, 114.0 / 135.3 at 8.3 M).  Scenes whose time is the walk stay with the
+     * single kernel: the wavefront trace meets the same wall of the memory system (Sponza-class 120.6 against 158, 10 M
+     * triangles 38 against 63 in round 3) and pays for the rays' way through HBM on top. */
+    const bool wfAuto = rgl && block_size >= (1u << 21);
     if (wfExists && (g_wfMode == 1u || (g_wfMode == 0u && wfAuto))) {
         args.pool = nullptr;
         args.cuCount = uint32_t(scene->cuCount);
